@@ -1,0 +1,215 @@
+/* skrec_hip.h -- C ABI of libskrec_hip.so, the MI355X (gfx950) implementation of
+ * scikit-recommender's data-parallel hot path.
+ *
+ * Rules of the boundary
+ *   - plain C: no C++ types, no exceptions, no torch types; every pointer named d_* is a DEVICE
+ *     pointer (HBM), every other pointer is a host pointer;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued on it
+ *     and nothing synchronises the host unless the function says so;
+ *   - caller-owned buffers, like the reference's native functions (randint.h:75, evaluate.h:57);
+ *   - every function returns 0 on success or a negative skr_status; skr_last_error() gives the text.
+ *     Where the reference would spin forever or crash on bad input (randint.h:38-48 with an
+ *     exclusion set covering the range; metric_dict[] with an unknown id, evaluate.h:50) this
+ *     library returns SKR_EINVAL instead.
+ *   - integer widths follow the reference: item/user ids and sizes are 32-bit `int`
+ *     (pyx_init.pyx:6-16 asserts it), CSR row pointers are int64.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * root, skrec/...).  INTEGRATION.md shows the reference-side binding for each.
+ */
+#ifndef SKREC_HIP_H
+#define SKREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum skr_status {
+    SKR_OK = 0,
+    SKR_EINVAL = -1,   /* bad argument (the text says which) */
+    SKR_EHIP = -2,     /* a HIP runtime call failed */
+    SKR_ENOMEM = -3,   /* workspace too small / allocation failed */
+    SKR_ENODEV = -4,   /* no gfx950 device visible */
+    SKR_EOVERFLOW = -5 /* an internal bounded buffer overflowed (result invalid) */
+} skr_status;
+
+/* metric ids = skrec/utils/py/evaluator.py:57 and utils/py/cython/include/metric.h:112-118 */
+enum { SKR_PRECISION = 1, SKR_RECALL = 2, SKR_MAP = 3, SKR_NDCG = 4, SKR_MRR = 5 };
+
+int skr_abi_version(void);            /* bumped on every signature change */
+const char* skr_last_error(void);     /* thread-local, valid until the next failing call */
+int skr_device_count(void);           /* number of visible HIP devices (0 on a CPU-only host) */
+int skr_device_summary(char* buf, size_t n); /* "gfx950 256CU ..." of the current device */
+/* Longest row of a device CSR (host result; synchronises).  The host mirror uses it for the
+ * reference's argument checks (pyx_random.pyx:49) and for the fused evaluator's precondition. */
+int skr_csr_max_row_len(const int64_t* d_rowptr, int n_rows, int* out_max, void* stream);
+
+/* ============================================================================================
+ * S -- negative sampling
+ * replaces: c_randint_choice / _random_int / global `std::mt19937 _gen(2020)`
+ *           (utils/py/cython/include/randint.h:20-88), its Cython glue pyx_randint_choice
+ *           (utils/py/cython/pyx_random.pyx:20-76) and the per-user Python loop
+ *           _sampling_negative_items (io/data_iterator.py:81-94).
+ * ========================================================================================== */
+typedef struct skr_sampler skr_sampler; /* owns one MT19937 stream, resident in HBM */
+
+/* seed 2020 reproduces the reference's process-global stream (randint.h:20). */
+int skr_sampler_create(uint32_t seed, skr_sampler** out);
+int skr_sampler_destroy(skr_sampler* s);
+/* Raw state exchange (624 untempered words + position 0..624), host buffers; synchronises. */
+int skr_sampler_get_state(skr_sampler* s, uint32_t* words624, int* pos);
+int skr_sampler_set_state(skr_sampler* s, const uint32_t* words624, int pos);
+/* Total raw 32-bit words consumed since creation / set_state (synchronises). */
+int skr_sampler_draws(skr_sampler* s, uint64_t* n);
+
+/* One call of c_randint_choice (randint.h:75): `size` draws from [0, high), written to d_result.
+ *   replace      as the reference's bool;
+ *   d_prob       NULL (uniform, randint.h:84) or float[high] weights (discrete, randint.h:79);
+ *   d_exclusion  NULL or int[n_exclusion] SORTED ascending, unique (replaces unordered_set<int>).
+ * Runs the reference's serial algorithm on the device (one lane), bit-exact with the reference
+ * stream; meant for the API-surface calls (random.py:9), not for epochs.  Validates like
+ * pyx_random.pyx:34-54 and returns SKR_EINVAL where the reference raises ValueError. */
+int skr_randint_choice(skr_sampler* s, int high, int size, int replace, const float* d_prob,
+                       const int32_t* d_exclusion, int n_exclusion, int32_t* d_result, void* stream);
+
+/* A whole epoch of _sampling_negative_items (data_iterator.py:81-94) in one call, EXACT STREAM:
+ * for users 0..n_users-1 ascending, rows with no positives skipped, n_pos(u)*num_neg uniform draws
+ * from [0, num_items) rejecting u's train positives -- consuming the sampler's MT19937 stream in
+ * exactly the reference's order, so d_out is bit-identical to the reference's concatenated array
+ * and the stream continues into the next epoch.
+ *   d_rowptr      int64[n_users+1] CSR offsets of the train positives
+ *   d_pos_sorted  int32[nnz] positives, ascending within each row (membership test only; the
+ *                 pairing with positives in file order is the caller's, data_iterator.py:30-42)
+ *   nnz           == rowptr[n_users] (the caller knows it; avoids a device read-back)
+ *   d_out         int32[nnz*num_neg]  (== reshape [nnz, num_neg] when num_neg > 1, :91)
+ * Synchronises the stream once at the end (it must learn how many words were consumed). */
+int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
+                           const int32_t* d_pos_sorted, int64_t nnz, int num_neg, int32_t* d_out, void* stream);
+
+/* The same distribution, embarrassingly parallel: slot a of user u in epoch e draws from a
+ * xoshiro128++ stream keyed by (seed, epoch, global slot index), Lemire-mapped to [0, num_items),
+ * retried until not in u's positives.  Bit-exact with its CPU twin (tests/fast_sampler_twin.py),
+ * equal to the reference in law only; independent of how users are sharded over GPUs when
+ * slot_offset is the global index of this shard's first slot.  Never synchronises.  A row that
+ * covers the whole catalogue (rejected with ValueError by pyx_random.pyx:49; the host mirror checks
+ * it) yields -1 instead of spinning. */
+int skr_sample_epoch_fast(uint64_t seed, uint64_t epoch, int64_t slot_offset, int num_items, int n_users,
+                          const int64_t* d_rowptr, const int32_t* d_pos_sorted, int64_t nnz, int num_neg,
+                          int32_t* d_out, void* stream);
+
+/* ============================================================================================
+ * E -- full-catalogue top-K evaluation
+ * replaces: cpp_evaluate_matrix / eval_one_user (utils/py/cython/include/evaluate.h:24-76),
+ *           the five metric functions (include/metric.h:19-118), eval_score_matrix
+ *           (utils/py/cython/pyx_eval_matrix.pyx:22-37), and -- in the fused form -- also
+ *           _MF.predict / _LightGCN.predict's U[b] @ V.T (+bias) (recommender/BPRMF.py:84-88,
+ *           LightGCN.py:102-107) and the -inf train masking loop (utils/py/evaluator.py:197-200).
+ * Tie rule (documented deviation): equal scores rank by ascending item id; the reference's order
+ * among exact ties is whatever libstdc++'s heap leaves (evaluate.h:42-43).
+ * ========================================================================================== */
+
+/* Drop-in for cpp_evaluate_matrix (evaluate.h:57): d_scores [n_users, ld] row-major fp32 (first
+ * n_items columns used), already train-masked by the caller.
+ *   d_test_rowptr/d_test_items  CSR of each row's ground truth, items SORTED ascending, unique
+ *   metric[n_metric]            host array of metric ids 1..5, output is metric-major
+ *   d_rows      float[n_users, n_metric*top_k]   per-user metric rows (may be NULL)
+ *   d_topk_ids  int32[n_users, top_k]            the arg-top-K lists (may be NULL)
+ *   d_sums      double[n_metric*top_k]           += column sums over users (may be NULL)
+ * Requires 1 <= top_k <= min(n_items, SKR_MAX_TOPK). */
+#define SKR_MAX_TOPK 128
+int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
+                    const int64_t* d_test_rowptr, const int32_t* d_test_items,
+                    const int* metric, int n_metric, int top_k,
+                    float* d_rows, int32_t* d_topk_ids, double* d_sums, void* stream);
+
+/* Fused scoring + masking + top-K, no [B, I] matrix in HBM:
+ *   score(b, i) = dot(d_user_table[d_users[b]], d_item_table[i]) (+ d_item_bias[i] if non-NULL),
+ *   train positives of user d_users[b] excluded, K best (score desc, id asc) written per row.
+ *   d_user_table [*, dim], d_item_table [n_items, dim] fp32 row-major, dim == 64
+ *   d_users      int32[B] user ids (also index the train CSR rows)
+ *   d_train_rowptr/d_train_items  CSR over ALL users, items sorted ascending (may be NULL: no mask)
+ *   d_topk_ids int32[B, top_k], d_topk_scores float[B, top_k] (may be NULL)
+ *   d_work / work_bytes   scratch from skr_eval_fused_workspace(B, top_k)
+ * Requires n_items - max train row length >= top_k (else SKR_EINVAL: use skr_eval_scores). */
+size_t skr_eval_fused_workspace(int B, int top_k);
+int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B,
+                        const float* d_item_table, const float* d_item_bias, int n_items, int dim,
+                        const int64_t* d_train_rowptr, const int32_t* d_train_items,
+                        int top_k, int32_t* d_topk_ids, float* d_topk_scores,
+                        void* d_work, size_t work_bytes, void* stream);
+
+/* evaluator.py:197-200 on the device: d_scores[b, i] = -inf for every train item i of user
+ * d_users[b] (generic path, when a foreign model hands over a dense [B, n_items] score matrix). */
+int skr_mask_train(float* d_scores, int B, int n_items, int64_t ld, const int32_t* d_users,
+                   const int64_t* d_train_rowptr, const int32_t* d_train_items, void* stream);
+
+/* Metric rows from arg-top-K lists (metric.h:19-109); truth row of list b is d_truth_rows[b]
+ * (NULL: row b).  Same outputs as skr_eval_scores. */
+int skr_rank_metrics(const int32_t* d_topk_ids, int B, int top_k, const int32_t* d_truth_rows,
+                     const int64_t* d_test_rowptr, const int32_t* d_test_items,
+                     const int* metric, int n_metric, float* d_rows, double* d_sums, void* stream);
+
+/* ============================================================================================
+ * T -- BPR lookup-and-score forward/backward, optimiser, graph propagation
+ * replaces stock torch ops of the reference (no native counterpart there):
+ *   _MF.forward + bpr_loss + l2_loss + autograd backward   recommender/BPRMF.py:77-82,114-126,
+ *                                                           utils/torch.py:20-21,62-74
+ *   torch.optim.Adam (dense, every row every step)          BPRMF.py:99,127
+ *   torch.sparse.mm(norm_adj, E) per layer, layer mean      LightGCN.py:89-100
+ *   cosine re-weighting, layer sum                          LayerGCN.py:207-220
+ * All tables fp32 row-major with dim == 64.
+ * ========================================================================================== */
+
+/* One BPR batch, forward + backward, gradients ACCUMULATED (atomically) into dense buffers that
+ * the caller zeroed:  x = <P_u,Q_i> + b_i - <P_u,Q_j> - b_j ;  loss_b = softplus(-x)
+ *   d_loss[0] += sum_b loss_b * loss_scale      (BPRMF: 1, sum, BPRMF.py:117; LightGCN: 1/n, mean)
+ *   d_loss[1] += 0.5*sum of squares of the gathered REG rows (l2_loss, torch.py:66-74)
+ *   grads of the score part go to d_gP/d_gQ/d_gb (tables the scores were computed from);
+ *   reg * reg_scale * row goes to d_gRP/d_gRQ (+ d_gb for the bias), computed from d_RP/d_RQ --
+ *   for BPRMF these are the same tables (BPRMF.py:118-124); for LightGCN/LayerGCN the scores use
+ *   the propagated tables and the regulariser the ego tables (LightGCN.py:192-196).
+ *   d_bias / d_gb may be NULL (no item bias). */
+int skr_bpr_step(const float* d_P, const float* d_Q, const float* d_bias,
+                 const float* d_RP, const float* d_RQ,
+                 const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n,
+                 float loss_scale, float reg, float reg_scale,
+                 float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ,
+                 float* d_loss, void* stream);
+
+/* torch.optim.Adam.step for one dense parameter (single-tensor path): for every element
+ *   m = m + (g-m)*(1-b1);  v = v*b2 + (1-b2)*g*g;
+ *   p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * step_t is the 1-based step count.  If zero_grad != 0 the gradient buffer is zeroed in the same
+ * pass (the next step's optimizer.zero_grad(), BPRMF.py:125). */
+int skr_adam_step(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int64_t step_t, int zero_grad,
+                  void* stream);
+
+/* Y = A * X for a CSR matrix with fp32 values and dim == 64 (torch.sparse.mm, LightGCN.py:94);
+ *   optional fused epilogues:  Y += d_addend (same shape, may be NULL);
+ *                              d_accum += accum_scale * Y (layer mean/sum, may be NULL). */
+int skr_csr_spmm(int n_rows, const int64_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                 const float* d_X, int dim, int64_t nnz, const float* d_addend, float* d_Y,
+                 float* d_accum, float accum_scale, void* stream);
+
+/* LayerGCN layer refinement (LayerGCN.py:214-216): w_r = cos(Y_r, E_r) (torch eps 1e-8),
+ * Z_r = w_r * Y_r; d_accum += Z (may be NULL); d_w[n_rows] keeps w for the backward. */
+int skr_layer_refine_fwd(const float* d_Y, const float* d_E, int64_t n_rows, int dim,
+                         float* d_Z, float* d_w, float* d_accum, void* stream);
+/* Backward of the above: given dZ -> dY (written) and dE (accumulated). */
+int skr_layer_refine_bwd(const float* d_Y, const float* d_E, const float* d_w, const float* d_dZ,
+                         int64_t n_rows, int dim, float* d_dY, float* d_dE, void* stream);
+
+/* Row gather out[k] = table[idx[k]] (F.embedding) and  y = a*x + y  helpers used by the host
+ * mirror so that no torch kernel sits on the hot path. */
+int skr_gather_rows(const float* d_table, const int32_t* d_idx, int64_t n, int dim, float* d_out, void* stream);
+int skr_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
+int skr_scale(float a, float* d_x, int64_t n, void* stream);                 /* x *= a */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKREC_HIP_H */

@@ -287,3 +287,146 @@ def ranking_evaluate(predict, user_train, user_test, metric=None, top_k=50, batc
     id2m = {v: k for k, v in METRIC2ID.items()}
     names = [f"{id2m[i]}@{k}" for i in ids for k in top_show]
     return names, final, allr
+
+
+# ------------------------------------------------------------------------------------------------
+# T: model maths (numpy fp32, explicit gradients -- no autograd), pinned by tests/golden/*.npz
+# ------------------------------------------------------------------------------------------------
+def _softplus_neg(x):
+    """-logsigmoid(x) the way torch evaluates it: -(min(0,x) - log1p(exp(-|x|)))  (utils/torch.py:63)"""
+    x = x.astype(np.float32)
+    return -(np.minimum(np.float32(0), x) - np.log1p(np.exp(-np.abs(x)))).astype(np.float32)
+
+
+def _sigmoid_neg(x):
+    z = np.exp(-np.abs(x)).astype(np.float32)
+    return np.where(x >= 0, z / (1 + z), 1 / (1 + z)).astype(np.float32)
+
+
+class Adam:
+    """torch.optim.Adam, single-tensor path (dense; every element every step) -- BPRMF.py:99,127."""
+
+    def __init__(self, params, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+        self.p = params
+        self.m = [np.zeros_like(p) for p in params]
+        self.v = [np.zeros_like(p) for p in params]
+        self.lr, self.b1, self.b2, self.eps, self.t = lr, b1, b2, eps, 0
+
+    def step(self, grads):
+        self.t += 1
+        bc1 = 1.0 - self.b1 ** self.t
+        bc2 = 1.0 - self.b2 ** self.t
+        step_size = np.float32(self.lr / bc1)
+        bc2s = np.float32(bc2 ** 0.5)
+        f = np.float32
+        for p, g, m, v in zip(self.p, grads, self.m, self.v):
+            m += f(1.0 - self.b1) * (g - m)
+            v *= f(self.b2)
+            v += (f(1.0 - self.b2) * g) * g
+            denom = np.sqrt(v) / bc2s + f(self.eps)
+            p += (-step_size * m) / denom
+
+
+def bpr_batch(P, Q, bias, RP, RQ, u, i, j, loss_scale, reg, reg_scale):
+    """One BPR batch: loss parts and dense gradients.  Scores from (P, Q, bias), regulariser rows from
+    (RP, RQ) -- BPRMF.py:114-124 (same tables) / LightGCN.py:187-196 (propagated vs ego tables).
+    Returns (bpr_loss*loss_scale, l2, gP, gQ, gb, gRP, gRQ); gRP/gRQ alias gP/gQ when tables alias."""
+    f = np.float32
+    pu, qi, qj = P[u], Q[i], Q[j]
+    xi = (pu * qi).sum(1, dtype=np.float32)
+    xj = (pu * qj).sum(1, dtype=np.float32)
+    if bias is not None:
+        xi = xi + bias[i]
+        xj = xj + bias[j]
+    x = (xi - xj).astype(np.float32)
+    loss = f(_softplus_neg(x).sum(dtype=np.float64)) * f(loss_scale)
+    c = (-_sigmoid_neg(x) * f(loss_scale)).astype(np.float32)
+    gP, gQ = np.zeros_like(P), np.zeros_like(Q)
+    gb = np.zeros_like(bias) if bias is not None else None
+    same = RP is P
+    gRP = gP if same else np.zeros_like(RP)
+    gRQ = gQ if same else np.zeros_like(RQ)
+    np.add.at(gP, u, c[:, None] * (qi - qj))
+    np.add.at(gQ, i, c[:, None] * pu)
+    np.add.at(gQ, j, -c[:, None] * pu)
+    ru, ri, rj = RP[u], RQ[i], RQ[j]
+    l2 = 0.5 * ((ru.astype(np.float64) ** 2).sum() + (ri.astype(np.float64) ** 2).sum() + (rj.astype(np.float64) ** 2).sum())
+    rs = f(reg * reg_scale)
+    np.add.at(gRP, u, rs * ru)
+    np.add.at(gRQ, i, rs * ri)
+    np.add.at(gRQ, j, rs * rj)
+    if bias is not None:
+        l2 += 0.5 * ((bias[i].astype(np.float64) ** 2).sum() + (bias[j].astype(np.float64) ** 2).sum())
+        np.add.at(gb, i, c + rs * bias[i])
+        np.add.at(gb, j, -c + rs * bias[j])
+    return loss, f(l2), gP, gQ, gb, gRP, gRQ
+
+
+def lightgcn_propagate(A, E0, n_layers):
+    """_forward_gcn (LightGCN.py:89-100): mean of E0, A E0, ..., A^K E0 (A: scipy CSR fp32)."""
+    layers = [E0]
+    x = E0
+    for _ in range(n_layers):
+        x = (A @ x).astype(np.float32)
+        layers.append(x)
+    return np.stack(layers, axis=1).mean(axis=1, dtype=np.float32)
+
+
+def lightgcn_step(A, E0, n_users, u, i, j, n_layers, reg, batch_size_cfg):
+    """loss + dense gradient wrt E0 of one LightGCN batch (LightGCN.py:180-199)."""
+    f = np.float32
+    Ebar = lightgcn_propagate(A, E0, n_layers)
+    n = len(u)
+    loss, l2, gPu, gQi, _, gRu, gRi = bpr_batch(Ebar[:n_users], Ebar[n_users:], None, E0[:n_users], E0[n_users:],
+                                                u, i, j, 1.0 / n, reg, 1.0 / batch_size_cfg)
+    H = (np.concatenate([gPu, gQi], 0) * f(1.0 / (n_layers + 1))).astype(np.float32)
+    G = H
+    At = A.T.tocsr()
+    for _ in range(n_layers):
+        G = (At @ G).astype(np.float32) + H
+    return loss, l2, (G + np.concatenate([gRu, gRi], 0)).astype(np.float32)
+
+
+def _cos_rows(Y, E, eps=1e-8):
+    ny = np.maximum(np.sqrt((Y * Y).sum(1, dtype=np.float32)), f32(eps))
+    ne = np.maximum(np.sqrt((E * E).sum(1, dtype=np.float32)), f32(eps))
+    return ((Y / ny[:, None]) * (E / ne[:, None])).sum(1, dtype=np.float32), ny, ne
+
+
+f32 = np.float32
+
+
+def layergcn_forward(A, E0, n_layers):
+    """_LayerGCN.forward (LayerGCN.py:207-220): returns (sum of refined layers, [Y_k], [w_k])."""
+    X, out, Ys, Ws = E0, np.zeros_like(E0), [], []
+    for _ in range(n_layers):
+        Y = (A @ X).astype(np.float32)
+        w, _, _ = _cos_rows(Y, E0)
+        X = (w[:, None] * Y).astype(np.float32)
+        out = out + X
+        Ys.append(Y)
+        Ws.append(w)
+    return out.astype(np.float32), Ys, Ws
+
+
+def layergcn_step(A, E0, n_users, u, i, j, n_layers, reg):
+    """loss + dense gradient wrt E0 of one LayerGCN batch (calculate_loss, LayerGCN.py:245-253)."""
+    out, Ys, Ws = layergcn_forward(A, E0, n_layers)
+    loss, l2, gPu, gQi, _, gRu, gRi = bpr_batch(out[:n_users], out[n_users:], None, E0[:n_users], E0[n_users:],
+                                                u, i, j, 1.0, reg, 1.0)
+    gO = np.concatenate([gPu, gQi], 0)
+    gE = np.concatenate([gRu, gRi], 0).astype(np.float32)
+    dZ = gO
+    for k in range(n_layers - 1, -1, -1):
+        Y, w = Ys[k], Ws[k]
+        _, ny, ne = _cos_rows(Y, E0)
+        yh, eh = Y / ny[:, None], E0 / ne[:, None]
+        dw = (dZ * Y).sum(1, dtype=np.float32)
+        dY = w[:, None] * dZ + dw[:, None] * (eh - w[:, None] * yh) / ny[:, None]
+        gE = gE + dw[:, None] * (yh - w[:, None] * eh) / ne[:, None]
+        back = (A.T @ dY.astype(np.float32)).astype(np.float32)
+        if k > 0:
+            dZ = gO + back
+        else:
+            gE = gE + back
+    return loss, l2, gE.astype(np.float32)

@@ -1,0 +1,627 @@
+// sampler.hip -- S rows of the hot path: negative sampling on gfx950.
+//
+// Reference being replaced (paths under skrec/):
+//   utils/py/cython/include/randint.h:20      std::mt19937 _gen(2020)   (process-global stream)
+//   utils/py/cython/include/randint.h:23-88   _random_int / c_randint_choice
+//   io/data_iterator.py:81-94                 _sampling_negative_items  (per-user Python loop)
+//
+// Three device paths:
+//   1. randint_serial_kernel   the reference's serial algorithm, one lane (API-surface calls)
+//   2. exact epoch             mt_generate_kernel -> exact_assign_kernel -> mt_commit_kernel:
+//                              the MT19937 word stream is produced in bulk, then ONE workgroup
+//                              resolves "which draw fills which slot" chunk by chunk with a
+//                              fixed-point iteration on the (rare) rejections; bit-exact with the
+//                              reference stream, latency-bound by construction (a serial chain).
+//   3. fast epoch              sample_fast_kernel: slot-keyed xoshiro128++ + rejection against
+//                              LDS-staged CSR positives; HBM-bound (8 B per sampled negative).
+#include "skr_common.h"
+
+#include <vector>
+
+namespace {
+
+constexpr int MT_N = 624;
+constexpr int MT_M = 397;
+
+__host__ __device__ __forceinline__ uint32_t mt_temper(uint32_t z) {
+    z ^= (z >> 11);
+    z ^= (z << 7) & 0x9d2c5680u;
+    z ^= (z << 15) & 0xefc60000u;
+    z ^= (z >> 18);
+    return z;
+}
+__host__ __device__ __forceinline__ uint32_t mt_untemper(uint32_t y) {
+    y ^= (y >> 18);
+    y ^= (y << 15) & 0xefc60000u;
+    uint32_t t = y;  // invert y ^= (y << 7) & 0x9d2c5680
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    y = t;
+    t = y ^ (y >> 11);  // invert y ^= (y >> 11)
+    y = y ^ (t >> 11);
+    return y;
+}
+__host__ __device__ __forceinline__ uint32_t mt_mix(uint32_t hi, uint32_t lo) {
+    uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. serial path: c_randint_choice on one lane
+// ------------------------------------------------------------------------------------------------
+struct MtRef {  // MT19937 living in global memory, advanced by a single lane
+    uint32_t* mt;
+    int p;
+    unsigned long long n;
+    __device__ void twist() {
+        for (int k = 0; k < MT_N; ++k)
+            mt[k] = mt[(k + MT_M) % MT_N] ^ mt_mix(mt[k], mt[(k + 1) % MT_N]);
+        p = 0;
+    }
+    __device__ uint32_t next() {
+        if (p >= MT_N) twist();
+        ++n;
+        return mt_temper(mt[p++]);
+    }
+    // std::uniform_int_distribution<int>(0, range-1), libstdc++-11 Lemire path
+    __device__ int below(uint32_t range) {
+        uint64_t prod = static_cast<uint64_t>(next()) * range;
+        uint32_t low = static_cast<uint32_t>(prod);
+        if (low < range) {
+            const uint32_t thr = (0u - range) % range;
+            while (low < thr) {
+                prod = static_cast<uint64_t>(next()) * range;
+                low = static_cast<uint32_t>(prod);
+            }
+        }
+        return static_cast<int>(prod >> 32);
+    }
+    __device__ double canonical() {  // std::generate_canonical<double, 53>
+        const double R = 4294967296.0;
+        double sum = static_cast<double>(next());
+        sum += static_cast<double>(next()) * R;
+        double ret = sum / (R * R);
+        if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;
+        return ret;
+    }
+};
+
+__global__ void randint_serial_kernel(uint32_t* state, int* pos, unsigned long long* draws, int high, int size,
+                                      int replace, const float* prob, double* cp, const int32_t* excl, int n_excl,
+                                      int32_t* result) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    MtRef g{state, *pos, 0ull};
+    if (prob) {  // std::discrete_distribution: normalise, partial sums, last = 1 (bits/random.tcc)
+        double sum = 0.0;
+        for (int i = 0; i < high; ++i) sum += static_cast<double>(prob[i]);
+        double acc = 0.0;
+        for (int i = 0; i < high; ++i) {
+            acc += static_cast<double>(prob[i]) / sum;
+            cp[i] = acc;
+        }
+        cp[high - 1] = 1.0;
+    }
+    int i = 0;
+    while (i < size) {
+        int s;
+        if (prob) {
+            const double p = g.canonical();
+            int lo = 0, hi = high;  // std::lower_bound
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (cp[mid] < p) lo = mid + 1; else hi = mid;
+            }
+            s = lo;
+        } else {
+            s = g.below(static_cast<uint32_t>(high));
+        }
+        bool rejected = excl && skr::contains_sorted(excl, 0, n_excl, s);
+        if (!rejected && !replace) {  // randint.h:53-70: accepted values join the exclusion set
+            for (int k = 0; k < i; ++k)
+                if (result[k] == s) { rejected = true; break; }
+        }
+        if (!rejected) result[i++] = s;
+    }
+    *pos = g.p;
+    *draws += g.n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2a. bulk MT19937 word generation (one workgroup, LDS-resident state, 3-phase parallel twist)
+// ------------------------------------------------------------------------------------------------
+constexpr int GEN_T = 256;
+
+__global__ __launch_bounds__(GEN_T) void mt_generate_kernel(const uint32_t* __restrict__ state,
+                                                            const int* __restrict__ pos_p,
+                                                            uint32_t* __restrict__ raw, int64_t n) {
+    __shared__ uint32_t mt[MT_N];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MT_N; i += GEN_T) mt[i] = state[i];
+    __syncthreads();
+    int p = *pos_p;
+    int64_t k = 0;
+    while (k < n) {
+        if (p >= MT_N) {
+            uint32_t v = 0;
+            // new[i] = old[i+397] ^ mix(old[i], old[i+1])                     i in [0, 227)
+            if (tid < MT_N - MT_M) v = mt[tid + MT_M] ^ mt_mix(mt[tid], mt[tid + 1]);
+            __syncthreads();
+            if (tid < MT_N - MT_M) mt[tid] = v;
+            __syncthreads();
+            // new[i] = new[i-227] ^ mix(old[i], old[i+1])                     i in [227, 454)
+            if (tid < MT_N - MT_M) v = mt[tid] ^ mt_mix(mt[tid + 227], mt[tid + 228]);
+            __syncthreads();
+            if (tid < MT_N - MT_M) mt[tid + 227] = v;
+            __syncthreads();
+            // new[i] = new[i-227] ^ mix(old[i], old[i+1])                     i in [454, 623)
+            if (tid < 169) v = mt[tid + 227] ^ mt_mix(mt[tid + 454], mt[tid + 455]);
+            __syncthreads();
+            if (tid < 169) mt[tid + 454] = v;
+            __syncthreads();
+            // new[623] = new[396] ^ mix(old[623], new[0])
+            if (tid == 0) mt[623] = mt[396] ^ mt_mix(mt[623], mt[0]);
+            __syncthreads();
+            p = 0;
+        }
+        const int64_t left = n - k;
+        const int m = static_cast<int>(left < (MT_N - p) ? left : (MT_N - p));
+        for (int t = tid; t < m; t += GEN_T) raw[k + t] = mt_temper(mt[p + t]);
+        k += m;
+        p += m;
+        __syncthreads();
+    }
+}
+
+// 2c. advance the stored state by `consumed` words of the buffer generated above.
+// The tempered words of a whole block ARE that block's state (tempering is a bijection).
+__global__ void mt_commit_kernel(uint32_t* state, int* pos_p, unsigned long long* draws,
+                                 const uint32_t* __restrict__ raw, int64_t n_raw, const int64_t* ctl) {
+    const int64_t consumed = ctl[1];
+    const int p0 = *pos_p;
+    const int64_t r0 = MT_N - p0;  // words of the current block that were still unread
+    __shared__ int64_t kb_s;
+    __shared__ int newpos_s;
+    if (threadIdx.x == 0) {
+        if (consumed < r0) {
+            kb_s = -1;
+            newpos_s = p0 + static_cast<int>(consumed);
+        } else {
+            int64_t b = (consumed - r0) / MT_N;
+            int64_t kb = r0 + b * MT_N;
+            if (kb + MT_N <= n_raw) {
+                kb_s = kb;
+                newpos_s = static_cast<int>(consumed - kb);
+            } else if (b >= 1) {  // consumed == n_raw exactly at a block boundary
+                kb_s = kb - MT_N;
+                newpos_s = MT_N;
+            } else {
+                kb_s = -1;
+                newpos_s = MT_N;
+            }
+        }
+        *draws += static_cast<unsigned long long>(consumed);
+    }
+    __syncthreads();
+    if (kb_s >= 0)
+        for (int i = threadIdx.x; i < MT_N; i += blockDim.x) state[i] = mt_untemper(raw[kb_s + i]);
+    if (threadIdx.x == 0) *pos_p = newpos_s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2b. exact assignment: which draw fills which slot
+// ------------------------------------------------------------------------------------------------
+constexpr int AS_T = 1024;
+constexpr int AS_PER = 8;
+constexpr int AS_C = AS_T * AS_PER;
+
+// largest u in [lo, hi] with rowptr[u] <= q   (rows with no positives can never own q)
+__device__ __forceinline__ int owner_of(const int64_t* __restrict__ rowptr, int lo, int hi, int64_t q) {
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (rowptr[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(AS_T) void exact_assign_kernel(
+    const uint32_t* __restrict__ raw, int64_t n_raw, uint32_t high, const int64_t* __restrict__ rowptr, int n_users,
+    const int32_t* __restrict__ pos_sorted, int num_neg, int64_t n_slots, int64_t slot_start, int32_t* __restrict__ out,
+    int64_t* __restrict__ ctl) {
+    __shared__ int wave_tot[AS_T / SKR_WAVE];
+    __shared__ int s_ulo, s_uhi;
+    __shared__ int s_last_idx;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const uint32_t lemire_thr = (0u - high) % high;
+
+    int64_t slot_base = slot_start;
+    int64_t draw_base = 0;
+    while (slot_base < n_slots && draw_base < n_raw) {
+        const int64_t left = n_raw - draw_base;
+        const int clen = static_cast<int>(left < AS_C ? left : AS_C);
+        // users that can own a slot of this chunk
+        if (tid == 0) {
+            s_ulo = owner_of(rowptr, 0, n_users - 1, slot_base / num_neg);
+            int64_t last = slot_base + clen - 1;
+            if (last > n_slots - 1) last = n_slots - 1;
+            s_uhi = owner_of(rowptr, 0, n_users - 1, last / num_neg);
+            s_last_idx = -1;
+        }
+        // this lane's draws: value, Lemire rejection
+        int val[AS_PER];
+        uint32_t lem = 0, inr = 0, rej = 0;  // bit masks over the AS_PER draws
+#pragma unroll
+        for (int e = 0; e < AS_PER; ++e) {
+            const int idx = tid * AS_PER + e;
+            uint32_t x = 0;
+            if (idx < clen) {
+                x = raw[draw_base + idx];
+                inr |= 1u << e;
+            }
+            const uint64_t prod = static_cast<uint64_t>(x) * high;
+            val[e] = static_cast<int>(prod >> 32);
+            if (idx < clen && static_cast<uint32_t>(prod) < lemire_thr) lem |= 1u << e;
+        }
+        rej = lem;
+        __syncthreads();
+        const int ulo = s_ulo, uhi = s_uhi;
+        int my_off = 0, total = 0;
+        // fixed point: rej -> slot of every draw -> owner -> membership -> rej
+        for (int iter = 0; iter < AS_C + 2; ++iter) {
+            const int acc_cnt = __popc(inr & ~rej);
+            int incl = skr::wave_incl_scan(acc_cnt);
+            if (lane == 63) wave_tot[wv] = incl;
+            __syncthreads();
+            int wbase = 0;
+            total = 0;
+#pragma unroll
+            for (int w = 0; w < AS_T / SKR_WAVE; ++w) {
+                const int t = wave_tot[w];
+                if (w < wv) wbase += t;
+                total += t;
+            }
+            my_off = wbase + incl - acc_cnt;
+            uint32_t nrej = lem;
+            int run = my_off;
+#pragma unroll
+            for (int e = 0; e < AS_PER; ++e) {
+                const uint32_t bit = 1u << e;
+                if (!(inr & bit)) continue;
+                const int64_t slot = slot_base + run;
+                if (!(rej & bit)) ++run;
+                if (lem & bit) continue;
+                if (slot >= n_slots) continue;  // never consumed: leave un-rejected, ignored below
+                const int u = owner_of(rowptr, ulo, uhi, slot / num_neg);
+                if (skr::contains_sorted(pos_sorted, rowptr[u], rowptr[u + 1], val[e])) nrej |= bit;
+            }
+            const int changed = (nrej != rej);
+            rej = nrej;
+            if (!__syncthreads_or(changed)) break;  // also orders wave_tot for the next round
+        }
+        // `rej` is the fixed point and my_off/total were computed from it in the last round.
+        {
+            int run = my_off;
+#pragma unroll
+            for (int e = 0; e < AS_PER; ++e) {
+                const uint32_t bit = 1u << e;
+                if (!(inr & bit) || (rej & bit)) continue;
+                const int64_t slot = slot_base + run;
+                ++run;
+                if (slot < n_slots) {
+                    out[slot] = val[e];
+                    if (slot == n_slots - 1) s_last_idx = tid * AS_PER + e;
+                }
+            }
+        }
+        __syncthreads();
+        int64_t filled = slot_base + total;
+        int consumed = clen;
+        if (filled >= n_slots) {
+            filled = n_slots;
+            consumed = s_last_idx + 1;
+        }
+        __syncthreads();
+        slot_base = filled;
+        draw_base += consumed;
+    }
+    if (tid == 0) {
+        ctl[0] = slot_base;
+        ctl[1] = draw_base;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. fast path: slot-keyed xoshiro128++ with rejection against LDS-staged positives
+// ------------------------------------------------------------------------------------------------
+constexpr int FS_T = 256;
+constexpr int FS_PER = 8;
+constexpr int FS_SLOTS = FS_T * FS_PER;  // slots per workgroup
+constexpr int FS_POS_CAP = 6144;         // positives staged in LDS (24 KB)
+constexpr int FS_ROW_CAP = 2048;         // row offsets staged in LDS (8 KB)
+
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t& x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+struct Xoshiro128pp {
+    uint32_t s0, s1, s2, s3;
+    __host__ __device__ void seed(uint64_t seed, uint64_t epoch, uint64_t slot) {
+        uint64_t x = seed;
+        uint64_t k = splitmix64(x) ^ (epoch * 0xD1B54A32D192ED03ull);
+        x = k;
+        k = splitmix64(x) ^ slot;
+        x = k;
+        const uint64_t a = splitmix64(x), b = splitmix64(x);
+        s0 = static_cast<uint32_t>(a); s1 = static_cast<uint32_t>(a >> 32);
+        s2 = static_cast<uint32_t>(b); s3 = static_cast<uint32_t>(b >> 32);
+        if ((s0 | s1 | s2 | s3) == 0) s0 = 1;
+    }
+    __host__ __device__ uint32_t next() {
+        const uint32_t r = rotl32(s0 + s3, 7) + s0;
+        const uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t;
+        s3 = rotl32(s3, 11);
+        return r;
+    }
+};
+
+__global__ __launch_bounds__(FS_T) void sample_fast_kernel(uint64_t seed, uint64_t epoch, int64_t slot_offset,
+                                                           uint32_t high, int n_users,
+                                                           const int64_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ pos_sorted, int num_neg,
+                                                           int64_t n_slots, int32_t* __restrict__ out) {
+    __shared__ int32_t l_pos[FS_POS_CAP];
+    __shared__ int32_t l_row[FS_ROW_CAP + 1];
+    __shared__ int s_ulo, s_uhi;
+    const int tid = threadIdx.x;
+    const int64_t a0 = static_cast<int64_t>(blockIdx.x) * FS_SLOTS;
+    if (a0 >= n_slots) return;
+    int64_t a1 = a0 + FS_SLOTS;
+    if (a1 > n_slots) a1 = n_slots;
+    if (tid == 0) {
+        s_ulo = owner_of(rowptr, 0, n_users - 1, a0 / num_neg);
+        s_uhi = owner_of(rowptr, 0, n_users - 1, (a1 - 1) / num_neg);
+    }
+    __syncthreads();
+    const int ulo = s_ulo, uhi = s_uhi;
+    const int64_t pbeg = rowptr[ulo], pend = rowptr[uhi + 1];
+    const bool staged = (uhi - ulo + 1 <= FS_ROW_CAP) && (pend - pbeg <= FS_POS_CAP);  // block-uniform
+    if (staged) {
+        for (int i = tid; i <= uhi - ulo + 1; i += FS_T) l_row[i] = static_cast<int32_t>(rowptr[ulo + i] - pbeg);
+        for (int64_t i = tid; i < pend - pbeg; i += FS_T) l_pos[i] = pos_sorted[pbeg + i];
+    }
+    __syncthreads();
+    const uint32_t lemire_thr = (0u - high) % high;
+#pragma unroll 1
+    for (int e = 0; e < FS_PER; ++e) {
+        const int64_t a = a0 + e * FS_T + tid;  // coalesced stores
+        if (a >= a1) break;
+        const int64_t q = a / num_neg;
+        int64_t rb, re;
+        if (staged) {
+            const int32_t ql = static_cast<int32_t>(q - pbeg);
+            int lo = 0, hi = uhi - ulo;
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (l_row[mid] <= ql) lo = mid; else hi = mid - 1;
+            }
+            rb = l_row[lo];
+            re = l_row[lo + 1];
+        } else {
+            const int u = owner_of(rowptr, ulo, uhi, q);
+            rb = rowptr[u];
+            re = rowptr[u + 1];
+        }
+        Xoshiro128pp g;
+        g.seed(seed, epoch, static_cast<uint64_t>(slot_offset + a));
+        // Bounded so that an (invalid) row covering the whole catalogue cannot hang the GPU; the
+        // host mirror rejects such rows up front exactly like pyx_random.pyx:49.  With one free item
+        // the bound is missed with probability < e^-64.
+        int cand = -1;
+        for (uint64_t tries = 0, cap = 64ull * high + 1024; tries < cap; ++tries) {
+            const uint64_t prod = static_cast<uint64_t>(g.next()) * high;
+            if (static_cast<uint32_t>(prod) < lemire_thr) continue;
+            const int c = static_cast<int>(prod >> 32);
+            const bool hit = staged ? skr::contains_sorted(l_pos, rb, re, c)
+                                    : skr::contains_sorted(pos_sorted, rb, re, c);
+            if (!hit) { cand = c; break; }
+        }
+        out[a] = cand;
+    }
+}
+
+__global__ void max_row_len_kernel(const int64_t* __restrict__ rowptr, int n_rows, int* __restrict__ out_max) {
+    int m = 0;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n_rows;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int len = static_cast<int>(rowptr[i + 1] - rowptr[i]);
+        m = len > m ? len : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(m, o, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_max, m);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct skr_sampler {
+    uint32_t* d_state = nullptr;            // 624 words
+    int* d_pos = nullptr;                   // next word (0..624)
+    unsigned long long* d_draws = nullptr;  // words consumed
+    int64_t* d_ctl = nullptr;               // [0] slots filled, [1] words consumed, [2] scratch (max row len)
+    uint32_t* d_raw = nullptr;
+    size_t raw_cap = 0;  // in words
+};
+
+namespace skr {
+int max_row_len(const int64_t* d_rowptr, int n_rows, int* d_scratch, hipStream_t st, int* out) {
+    SKR_HIP(hipMemsetAsync(d_scratch, 0, sizeof(int), st));
+    int blocks = (n_rows + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(max_row_len_kernel, dim3(blocks), dim3(256), 0, st, d_rowptr, n_rows, d_scratch);
+    SKR_LAUNCH_CHECK();
+    SKR_HIP(hipMemcpyAsync(out, d_scratch, sizeof(int), hipMemcpyDeviceToHost, st));
+    SKR_HIP(hipStreamSynchronize(st));
+    return SKR_OK;
+}
+}  // namespace skr
+
+extern "C" {
+
+int skr_sampler_create(uint32_t seed, skr_sampler** out) {
+    SKR_REQUIRE(out != nullptr, "skr_sampler_create: out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return skr::fail(SKR_ENODEV, "no HIP device visible");
+    skr_sampler* s = new skr_sampler();
+    SKR_HIP(hipMalloc(&s->d_state, MT_N * sizeof(uint32_t)));
+    SKR_HIP(hipMalloc(&s->d_pos, sizeof(int)));
+    SKR_HIP(hipMalloc(&s->d_draws, sizeof(unsigned long long)));
+    SKR_HIP(hipMalloc(&s->d_ctl, 4 * sizeof(int64_t)));
+    std::vector<uint32_t> mt(MT_N);
+    mt[0] = seed;  // std::mt19937::seed(value)
+    for (int i = 1; i < MT_N; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + static_cast<uint32_t>(i);
+    *out = s;
+    return skr_sampler_set_state(s, mt.data(), MT_N);
+}
+
+int skr_sampler_destroy(skr_sampler* s) {
+    if (!s) return SKR_OK;
+    hipFree(s->d_state);
+    hipFree(s->d_pos);
+    hipFree(s->d_draws);
+    hipFree(s->d_ctl);
+    hipFree(s->d_raw);
+    delete s;
+    return SKR_OK;
+}
+
+int skr_sampler_get_state(skr_sampler* s, uint32_t* words624, int* pos) {
+    SKR_REQUIRE(s && words624 && pos, "skr_sampler_get_state: NULL argument");
+    SKR_HIP(hipDeviceSynchronize());
+    SKR_HIP(hipMemcpy(words624, s->d_state, MT_N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SKR_HIP(hipMemcpy(pos, s->d_pos, sizeof(int), hipMemcpyDeviceToHost));
+    return SKR_OK;
+}
+
+int skr_sampler_set_state(skr_sampler* s, const uint32_t* words624, int pos) {
+    SKR_REQUIRE(s && words624, "skr_sampler_set_state: NULL argument");
+    SKR_REQUIRE(pos >= 0 && pos <= MT_N, "skr_sampler_set_state: pos %d outside [0, 624]", pos);
+    SKR_HIP(hipDeviceSynchronize());
+    SKR_HIP(hipMemcpy(s->d_state, words624, MT_N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SKR_HIP(hipMemcpy(s->d_pos, &pos, sizeof(int), hipMemcpyHostToDevice));
+    SKR_HIP(hipMemset(s->d_draws, 0, sizeof(unsigned long long)));
+    return SKR_OK;
+}
+
+int skr_sampler_draws(skr_sampler* s, uint64_t* n) {
+    SKR_REQUIRE(s && n, "skr_sampler_draws: NULL argument");
+    SKR_HIP(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    SKR_HIP(hipMemcpy(&v, s->d_draws, sizeof(v), hipMemcpyDeviceToHost));
+    *n = v;
+    return SKR_OK;
+}
+
+int skr_randint_choice(skr_sampler* s, int high, int size, int replace, const float* d_prob,
+                       const int32_t* d_exclusion, int n_exclusion, int32_t* d_result, void* stream) {
+    SKR_REQUIRE(s && d_result, "skr_randint_choice: NULL argument");
+    SKR_REQUIRE(high > 1, "'high' must be larger than 1.");                        // pyx_random.pyx:34
+    SKR_REQUIRE(size > 0, "'size' must be a positive integer.");                   // :36
+    SKR_REQUIRE(n_exclusion >= 0 && (n_exclusion == 0 || d_exclusion), "exclusion pointer/length mismatch");
+    SKR_REQUIRE(n_exclusion < high, "The length of 'exclusion' must be smaller than 'high'.");  // :49
+    SKR_REQUIRE(replace || high - n_exclusion > size, "There is not enough integers to be sampled.");  // :53
+    hipStream_t st = skr::as_stream(stream);
+    double* d_cp = nullptr;
+    if (d_prob) SKR_HIP(hipMalloc(&d_cp, static_cast<size_t>(high) * sizeof(double)));
+    hipLaunchKernelGGL(randint_serial_kernel, dim3(1), dim3(64), 0, st, s->d_state, s->d_pos, s->d_draws, high, size,
+                       replace, d_prob, d_cp, n_exclusion ? d_exclusion : nullptr, n_exclusion, d_result);
+    SKR_LAUNCH_CHECK();
+    if (d_cp) {
+        SKR_HIP(hipStreamSynchronize(st));
+        SKR_HIP(hipFree(d_cp));
+    }
+    return SKR_OK;
+}
+
+int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
+                           const int32_t* d_pos_sorted, int64_t nnz, int num_neg, int32_t* d_out, void* stream) {
+    SKR_REQUIRE(s && d_rowptr && d_pos_sorted && d_out, "skr_sample_epoch_exact: NULL argument");
+    SKR_REQUIRE(num_items > 1, "'high' must be larger than 1.");
+    SKR_REQUIRE(n_users > 0 && num_neg > 0, "skr_sample_epoch_exact: n_users and num_neg must be positive");
+    SKR_REQUIRE(nnz >= 0, "skr_sample_epoch_exact: negative nnz");
+    hipStream_t st = skr::as_stream(stream);
+    if (nnz == 0) return SKR_OK;
+    int max_len = 0;
+    int rc = skr::max_row_len(d_rowptr, n_users, reinterpret_cast<int*>(s->d_ctl + 2), st, &max_len);
+    if (rc) return rc;
+    SKR_REQUIRE(max_len < num_items, "The length of 'exclusion' must be smaller than 'high'.");  // pyx_random.pyx:49
+    const int64_t n_slots = nnz * num_neg;
+    SKR_REQUIRE(n_slots < (int64_t(1) << 31), "more than 2^31-1 samples per call (the reference's int limit)");
+    int64_t filled = 0;
+    int pos = 0;
+    while (filled < n_slots) {
+        SKR_HIP(hipMemcpyAsync(&pos, s->d_pos, sizeof(int), hipMemcpyDeviceToHost, st));
+        SKR_HIP(hipStreamSynchronize(st));
+        const int64_t need = n_slots - filled;
+        const int64_t want = need + need / 8 + 4096;  // head-room for rejected draws
+        const int64_t r0 = MT_N - pos;
+        int64_t n_gen = r0 + ((want - r0 + MT_N - 1) / MT_N) * MT_N;  // ends on a block boundary
+        if (n_gen < r0) n_gen = r0;
+        if (static_cast<size_t>(n_gen) > s->raw_cap) {
+            if (s->d_raw) SKR_HIP(hipFree(s->d_raw));
+            s->d_raw = nullptr;
+            s->raw_cap = 0;
+            SKR_HIP(hipMalloc(&s->d_raw, static_cast<size_t>(n_gen) * sizeof(uint32_t)));
+            s->raw_cap = static_cast<size_t>(n_gen);
+        }
+        hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(GEN_T), 0, st, s->d_state, s->d_pos, s->d_raw, n_gen);
+        SKR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(exact_assign_kernel, dim3(1), dim3(AS_T), 0, st, s->d_raw, n_gen,
+                           static_cast<uint32_t>(num_items), d_rowptr, n_users, d_pos_sorted, num_neg, n_slots, filled,
+                           d_out, s->d_ctl);
+        SKR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mt_commit_kernel, dim3(1), dim3(256), 0, st, s->d_state, s->d_pos, s->d_draws, s->d_raw,
+                           n_gen, s->d_ctl);
+        SKR_LAUNCH_CHECK();
+        int64_t ctl[2] = {0, 0};
+        SKR_HIP(hipMemcpyAsync(ctl, s->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));
+        SKR_HIP(hipStreamSynchronize(st));
+        if (ctl[0] <= filled && ctl[1] == 0) return skr::fail(SKR_EHIP, "exact sampler made no progress");
+        filled = ctl[0];
+    }
+    return SKR_OK;
+}
+
+int skr_sample_epoch_fast(uint64_t seed, uint64_t epoch, int64_t slot_offset, int num_items, int n_users,
+                          const int64_t* d_rowptr, const int32_t* d_pos_sorted, int64_t nnz, int num_neg,
+                          int32_t* d_out, void* stream) {
+    SKR_REQUIRE(d_rowptr && d_pos_sorted && d_out, "skr_sample_epoch_fast: NULL argument");
+    SKR_REQUIRE(num_items > 1, "'high' must be larger than 1.");
+    SKR_REQUIRE(n_users > 0 && num_neg > 0, "skr_sample_epoch_fast: n_users and num_neg must be positive");
+    SKR_REQUIRE(nnz >= 0, "skr_sample_epoch_fast: negative nnz");
+    hipStream_t st = skr::as_stream(stream);
+    const int64_t n_slots = nnz * num_neg;
+    if (n_slots == 0) return SKR_OK;
+    const int64_t blocks = (n_slots + FS_SLOTS - 1) / FS_SLOTS;
+    SKR_REQUIRE(blocks < (int64_t(1) << 31), "too many slots for one launch");
+    hipLaunchKernelGGL(sample_fast_kernel, dim3(static_cast<unsigned>(blocks)), dim3(FS_T), 0, st, seed, epoch,
+                       slot_offset, static_cast<uint32_t>(num_items), n_users, d_rowptr, d_pos_sorted, num_neg, n_slots,
+                       d_out);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,423 @@
+// train.hip -- T rows: BPR lookup-and-score forward/backward, dense Adam, CSR propagation.
+//
+// Replaces the stock torch ops the reference issues per step (no native code there):
+//   recommender/BPRMF.py:77-82,114-127   gathers, inner_product, bpr_loss.sum(), l2_loss, backward, Adam
+//   recommender/LightGCN.py:89-100       torch.sparse.mm per layer + stack/mean
+//   recommender/LayerGCN.py:207-220      sparse.mm + cosine_similarity re-weighting + layer sum
+//   utils/torch.py:20-21,62-74           inner_product, bpr_loss, l2_loss
+//
+// Every kernel maps the d = 64 embedding row onto the 64 lanes of one wavefront: a row is one
+// coalesced 256-byte access, dot products are wave reductions, gradient scatter-adds are one
+// 256-byte global_atomic_add_f32 per row (the shape the memory-side atomic units like).
+#include "skr_common.h"
+
+#include <cmath>
+
+namespace {
+
+constexpr int D = 64;
+
+// ------------------------------------------------------------------------------------------------
+// K1: fused BPR batch (forward + backward)
+// ------------------------------------------------------------------------------------------------
+constexpr int BPR_WAVES = 4;
+
+__global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ bias,
+    const float* __restrict__ RP, const float* __restrict__ RQ, const int32_t* __restrict__ u_ids,
+    const int32_t* __restrict__ i_ids, const int32_t* __restrict__ j_ids, int n, float loss_scale, float reg,
+    float reg_scale, float* __restrict__ gP, float* __restrict__ gQ, float* __restrict__ gb, float* __restrict__ gRP,
+    float* __restrict__ gRQ, float* __restrict__ loss) {
+    __shared__ float s_loss[BPR_WAVES], s_l2[BPR_WAVES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float acc_loss = 0.0f, acc_l2 = 0.0f;
+    const float rs = reg * reg_scale;
+    for (int b = blockIdx.x * BPR_WAVES + wv; b < n; b += gridDim.x * BPR_WAVES) {
+        const int64_t u = u_ids[b], i = i_ids[b], j = j_ids[b];
+        const float pu = P[u * D + lane], qi = Q[i * D + lane], qj = Q[j * D + lane];
+        // x_ui - x_uj; the two inner products are reduced separately like inner_product() does
+        float xi = skr::wave_sum(pu * qi), xj = skr::wave_sum(pu * qj);
+        float bi = 0.0f, bj = 0.0f;
+        if (bias) {
+            bi = bias[i];
+            bj = bias[j];
+            xi += bi;
+            xj += bj;
+        }
+        const float x = xi - xj;
+        // -logsigmoid(x) = -(min(0,x) - log1p(exp(-|x|)))   (torch's log_sigmoid forward)
+        const float z = expf(-fabsf(x));
+        const float l = -(fminf(0.0f, x) - log1pf(z));
+        // d/dx = -sigmoid(-x)
+        const float sig_neg = (x >= 0.0f) ? z / (1.0f + z) : 1.0f / (1.0f + z);
+        const float c = -sig_neg * loss_scale;
+        // score-part gradients
+        atomicAdd(&gP[u * D + lane], c * (qi - qj));
+        atomicAdd(&gQ[i * D + lane], c * pu);
+        atomicAdd(&gQ[j * D + lane], -c * pu);
+        // regulariser rows (may be other tables than the score tables)
+        const float ru = RP[u * D + lane], ri = RQ[i * D + lane], rj = RQ[j * D + lane];
+        float sq = skr::wave_sum(ru * ru + ri * ri + rj * rj);
+        if (rs != 0.0f) {
+            atomicAdd(&gRP[u * D + lane], rs * ru);
+            atomicAdd(&gRQ[i * D + lane], rs * ri);
+            atomicAdd(&gRQ[j * D + lane], rs * rj);
+        }
+        if (bias) {
+            sq += bi * bi + bj * bj;
+            if (lane == 0 && gb) {
+                atomicAdd(&gb[i], c + rs * bi);
+                atomicAdd(&gb[j], -c + rs * bj);
+            }
+        }
+        acc_loss += l;
+        acc_l2 += 0.5f * sq;
+    }
+    if (lane == 0) {
+        s_loss[wv] = acc_loss;
+        s_l2[wv] = acc_l2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.0f, b2 = 0.0f;
+        for (int w = 0; w < BPR_WAVES; ++w) {
+            a += s_loss[w];
+            b2 += s_l2[w];
+        }
+        atomicAdd(&loss[0], a * loss_scale);
+        atomicAdd(&loss[1], b2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: dense Adam (torch.optim.Adam single-tensor path), 16-byte vectors, grid-stride
+// ------------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float one_minus_b1, b2, one_minus_b2, neg_step_size, bc2_sqrt, eps;
+};
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamArgs& a) {
+    m = m + a.one_minus_b1 * (g - m);           // exp_avg.lerp_(grad, 1-beta1)
+    v = v * a.b2 + (a.one_minus_b2 * g) * g;    // mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p + (a.neg_step_size * m) / denom;      // addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, AdamArgs a, int zero_grad) {
+    const int64_t n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4; i += stride) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        adam_elem(pp.x, gg.x, mm.x, vv.x, a);
+        adam_elem(pp.y, gg.y, mm.y, vv.y, a);
+        adam_elem(pp.z, gg.z, mm.z, vv.z, a);
+        adam_elem(pp.w, gg.w, mm.w, vv.w, a);
+        p4[i] = pp;
+        m4[i] = mm;
+        v4[i] = vv;
+        if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // tail (n not a multiple of 4)
+    for (int64_t i = (n4 << 2) + blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_elem(pp, g[i], mm, vv, a);
+        p[i] = pp;
+        m[i] = mm;
+        v[i] = vv;
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: CSR SpMM, d = 64, nnz-balanced: one wavefront per CH consecutive non-zeros
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_CH = 512;     // non-zeros per wavefront
+constexpr int SP_WAVES = 4;
+
+__device__ __forceinline__ int64_t row_of(const int64_t* __restrict__ rowptr, int n_rows, int64_t e) {
+    int64_t lo = 0, hi = n_rows - 1;  // largest r with rowptr[r] <= e
+    while (lo < hi) {
+        int64_t mid = (lo + hi + 1) >> 1;
+        if (rowptr[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ bool row_is_split(int64_t rb, int64_t re) { return (rb / SP_CH) != ((re - 1) / SP_CH); }
+
+// rows no chunk completes: empty rows get their final value here, split rows are zeroed for atomics
+__global__ void spmm_prep_kernel(int n_rows, const int64_t* __restrict__ rowptr, const float* __restrict__ addend,
+                                 float* __restrict__ Y, float* __restrict__ accum, float accum_scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
+    if (r >= n_rows) return;
+    const int64_t rb = rowptr[r], re = rowptr[r + 1];
+    if (re == rb) {
+        const float y = addend ? addend[r * D + lane] : 0.0f;
+        Y[r * D + lane] = y;
+        if (accum) accum[r * D + lane] += accum_scale * y;
+    } else if (row_is_split(rb, re)) {
+        Y[r * D + lane] = 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(SP_WAVES * 64) void spmm_main_kernel(int n_rows, const int64_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ col,
+                                                                  const float* __restrict__ val,
+                                                                  const float* __restrict__ X,
+                                                                  const float* __restrict__ addend, float* __restrict__ Y,
+                                                                  float* __restrict__ accum, float accum_scale,
+                                                                  int64_t nnz) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = blockIdx.x * static_cast<int64_t>(SP_WAVES) + (threadIdx.x >> 6);
+    const int64_t e0 = w * SP_CH;
+    if (e0 >= nnz) return;
+    const int64_t e1 = (e0 + SP_CH < nnz) ? e0 + SP_CH : nnz;
+    int64_t r = row_of(rowptr, n_rows, e0);
+    int64_t e = e0;
+    while (e < e1) {
+        while (rowptr[r + 1] <= e) ++r;  // skip rows that ended (empty rows included)
+        const int64_t rb = rowptr[r], re = rowptr[r + 1];
+        const int64_t se = re < e1 ? re : e1;
+        float acc = 0.0f;
+        for (int64_t c0 = e; c0 < se; c0 += 64) {
+            const int m = static_cast<int>(se - c0 < 64 ? se - c0 : 64);
+            int cl = 0;
+            float vl = 0.0f;
+            if (lane < m) {
+                cl = col[c0 + lane];
+                vl = val[c0 + lane];
+            }
+            int k = 0;
+            for (; k + 4 <= m; k += 4) {  // four independent 256-byte row gathers in flight
+                const int c_0 = __shfl(cl, k), c_1 = __shfl(cl, k + 1), c_2 = __shfl(cl, k + 2), c_3 = __shfl(cl, k + 3);
+                const float x0 = X[static_cast<int64_t>(c_0) * D + lane], x1 = X[static_cast<int64_t>(c_1) * D + lane];
+                const float x2 = X[static_cast<int64_t>(c_2) * D + lane], x3 = X[static_cast<int64_t>(c_3) * D + lane];
+                acc = fmaf(__shfl(vl, k), x0, acc);
+                acc = fmaf(__shfl(vl, k + 1), x1, acc);
+                acc = fmaf(__shfl(vl, k + 2), x2, acc);
+                acc = fmaf(__shfl(vl, k + 3), x3, acc);
+            }
+            for (; k < m; ++k) {
+                const int c_0 = __shfl(cl, k);
+                acc = fmaf(__shfl(vl, k), X[static_cast<int64_t>(c_0) * D + lane], acc);
+            }
+        }
+        if (!row_is_split(rb, re)) {  // this wave saw the whole row: finish it here
+            float y = acc;
+            if (addend) y += addend[r * D + lane];
+            Y[r * D + lane] = y;
+            if (accum) accum[r * D + lane] += accum_scale * y;
+        } else {
+            atomicAdd(&Y[r * D + lane], acc);
+        }
+        e = se;
+    }
+}
+
+__global__ void spmm_fix_kernel(int n_rows, const int64_t* __restrict__ rowptr, const float* __restrict__ addend,
+                                float* __restrict__ Y, float* __restrict__ accum, float accum_scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
+    if (r >= n_rows) return;
+    const int64_t rb = rowptr[r], re = rowptr[r + 1];
+    if (re > rb && row_is_split(rb, re)) {
+        float y = Y[r * D + lane];
+        if (addend) {
+            y += addend[r * D + lane];
+            Y[r * D + lane] = y;
+        }
+        if (accum) accum[r * D + lane] += accum_scale * y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerGCN refinement (LayerGCN.py:214-216) forward / backward, one wavefront per row
+// ------------------------------------------------------------------------------------------------
+constexpr float COS_EPS = 1e-8f;  // F.cosine_similarity default
+
+__global__ void refine_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ E, int64_t n_rows,
+                                  float* __restrict__ Z, float* __restrict__ w_out, float* __restrict__ accum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
+    if (r >= n_rows) return;
+    const float y = Y[r * D + lane], e = E[r * D + lane];
+    const float ny = fmaxf(sqrtf(skr::wave_sum(y * y)), COS_EPS);
+    const float ne = fmaxf(sqrtf(skr::wave_sum(e * e)), COS_EPS);
+    const float w = skr::wave_sum((y / ny) * (e / ne));
+    const float z = w * y;
+    Z[r * D + lane] = z;
+    if (accum) accum[r * D + lane] += z;
+    if (lane == 0) w_out[r] = w;
+}
+
+__global__ void refine_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ E, const float* __restrict__ w_in,
+                                  const float* __restrict__ dZ, int64_t n_rows, float* __restrict__ dY,
+                                  float* __restrict__ dE) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
+    if (r >= n_rows) return;
+    const float y = Y[r * D + lane], e = E[r * D + lane], dz = dZ[r * D + lane];
+    const float w = w_in[r];
+    const float nyr = sqrtf(skr::wave_sum(y * y)), ner = sqrtf(skr::wave_sum(e * e));
+    const float ny = fmaxf(nyr, COS_EPS), ne = fmaxf(ner, COS_EPS);
+    const float yh = y / ny, eh = e / ne;
+    const float dw = skr::wave_sum(dz * y);
+    // d(yh)/dy = (I - yh yh^T)/ny when the norm is not clamped, I/eps when it is (clamp_min has zero slope)
+    const float gy = (nyr > COS_EPS) ? (eh - w * yh) / ny : eh / ny;
+    const float ge = (ner > COS_EPS) ? (yh - w * eh) / ne : yh / ne;
+    dY[r * D + lane] = w * dz + dw * gy;
+    dE[r * D + lane] += dw * ge;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx, int64_t n,
+                                   float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
+    if (k >= n) return;
+    out[k * D + lane] = table[static_cast<int64_t>(idx[k]) * D + lane];
+}
+
+__global__ void axpy_kernel(float a, const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride)
+        y[i] = fmaf(a, x[i], y[i]);
+}
+
+__global__ void scale_kernel(float a, float* __restrict__ x, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) x[i] *= a;
+}
+
+inline unsigned rows_to_blocks(int64_t n_rows) { return static_cast<unsigned>((n_rows * 64 + 255) / 256); }
+
+}  // namespace
+
+extern "C" {
+
+int skr_bpr_step(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
+                 const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n, float loss_scale, float reg,
+                 float reg_scale, float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ, float* d_loss,
+                 void* stream) {
+    SKR_REQUIRE(d_P && d_Q && d_RP && d_RQ && d_u && d_i && d_j && d_gP && d_gQ && d_gRP && d_gRQ && d_loss,
+                "skr_bpr_step: NULL argument");
+    SKR_REQUIRE(n >= 0, "skr_bpr_step: negative batch size");
+    if (n == 0) return SKR_OK;
+    int blocks = (n + BPR_WAVES - 1) / BPR_WAVES;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bpr_step_kernel, dim3(blocks), dim3(BPR_WAVES * 64), 0, skr::as_stream(stream), d_P, d_Q, d_bias,
+                       d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP, d_gRQ, d_loss);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_adam_step(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int64_t step_t, int zero_grad, void* stream) {
+    SKR_REQUIRE(d_p && d_g && d_m && d_v, "skr_adam_step: NULL argument");
+    SKR_REQUIRE(n >= 0 && step_t >= 1, "skr_adam_step: n must be >= 0 and step_t >= 1");
+    SKR_REQUIRE(((reinterpret_cast<uintptr_t>(d_p) | reinterpret_cast<uintptr_t>(d_g) | reinterpret_cast<uintptr_t>(d_m) |
+                  reinterpret_cast<uintptr_t>(d_v)) & 15) == 0, "skr_adam_step: buffers must be 16-byte aligned");
+    if (n == 0) return SKR_OK;
+    // torch/optim/adam.py _single_tensor_adam: python-double scalars, cast to fp32 at the tensor ops
+    const double b1 = static_cast<double>(beta1), b2 = static_cast<double>(beta2);
+    const double bc1 = 1.0 - std::pow(b1, static_cast<double>(step_t));
+    const double bc2 = 1.0 - std::pow(b2, static_cast<double>(step_t));
+    AdamArgs a;
+    a.one_minus_b1 = static_cast<float>(1.0 - b1);
+    a.b2 = beta2;
+    a.one_minus_b2 = static_cast<float>(1.0 - b2);
+    a.neg_step_size = static_cast<float>(-(static_cast<double>(lr) / bc1));
+    a.bc2_sqrt = static_cast<float>(std::sqrt(bc2));
+    a.eps = eps;
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream), d_p, d_g,
+                       d_m, d_v, n, a, zero_grad);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_csr_spmm(int n_rows, const int64_t* d_rowptr, const int32_t* d_col, const float* d_val, const float* d_X,
+                 int dim, int64_t nnz, const float* d_addend, float* d_Y, float* d_accum, float accum_scale,
+                 void* stream) {
+    SKR_REQUIRE(d_rowptr && d_col && d_val && d_X && d_Y, "skr_csr_spmm: NULL argument");
+    SKR_REQUIRE(dim == D, "skr_csr_spmm: dim must be 64 (got %d)", dim);
+    SKR_REQUIRE(n_rows >= 0 && nnz >= 0, "skr_csr_spmm: negative size");
+    SKR_REQUIRE(d_Y != d_X, "skr_csr_spmm: in-place propagation is not supported");
+    if (n_rows == 0) return SKR_OK;
+    hipStream_t st = skr::as_stream(stream);
+    hipLaunchKernelGGL(spmm_prep_kernel, dim3(rows_to_blocks(n_rows)), dim3(256), 0, st, n_rows, d_rowptr, d_addend, d_Y,
+                       d_accum, accum_scale);
+    SKR_LAUNCH_CHECK();
+    if (nnz > 0) {
+        const int64_t waves = (nnz + SP_CH - 1) / SP_CH;
+        hipLaunchKernelGGL(spmm_main_kernel, dim3(static_cast<unsigned>((waves + SP_WAVES - 1) / SP_WAVES)),
+                           dim3(SP_WAVES * 64), 0, st, n_rows, d_rowptr, d_col, d_val, d_X, d_addend, d_Y, d_accum,
+                           accum_scale, nnz);
+        SKR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(spmm_fix_kernel, dim3(rows_to_blocks(n_rows)), dim3(256), 0, st, n_rows, d_rowptr, d_addend,
+                           d_Y, d_accum, accum_scale);
+        SKR_LAUNCH_CHECK();
+    }
+    return SKR_OK;
+}
+
+int skr_layer_refine_fwd(const float* d_Y, const float* d_E, int64_t n_rows, int dim, float* d_Z, float* d_w,
+                         float* d_accum, void* stream) {
+    SKR_REQUIRE(d_Y && d_E && d_Z && d_w, "skr_layer_refine_fwd: NULL argument");
+    SKR_REQUIRE(dim == D, "skr_layer_refine_fwd: dim must be 64 (got %d)", dim);
+    if (n_rows <= 0) return SKR_OK;
+    hipLaunchKernelGGL(refine_fwd_kernel, dim3(rows_to_blocks(n_rows)), dim3(256), 0, skr::as_stream(stream), d_Y, d_E,
+                       n_rows, d_Z, d_w, d_accum);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_layer_refine_bwd(const float* d_Y, const float* d_E, const float* d_w, const float* d_dZ, int64_t n_rows, int dim,
+                         float* d_dY, float* d_dE, void* stream) {
+    SKR_REQUIRE(d_Y && d_E && d_w && d_dZ && d_dY && d_dE, "skr_layer_refine_bwd: NULL argument");
+    SKR_REQUIRE(dim == D, "skr_layer_refine_bwd: dim must be 64 (got %d)", dim);
+    if (n_rows <= 0) return SKR_OK;
+    hipLaunchKernelGGL(refine_bwd_kernel, dim3(rows_to_blocks(n_rows)), dim3(256), 0, skr::as_stream(stream), d_Y, d_E,
+                       d_w, d_dZ, n_rows, d_dY, d_dE);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_gather_rows(const float* d_table, const int32_t* d_idx, int64_t n, int dim, float* d_out, void* stream) {
+    SKR_REQUIRE(d_table && d_idx && d_out, "skr_gather_rows: NULL argument");
+    SKR_REQUIRE(dim == D, "skr_gather_rows: dim must be 64 (got %d)", dim);
+    if (n <= 0) return SKR_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows_to_blocks(n)), dim3(256), 0, skr::as_stream(stream), d_table, d_idx,
+                       n, d_out);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream) {
+    SKR_REQUIRE(d_x && d_y, "skr_axpy: NULL argument");
+    if (n <= 0) return SKR_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(axpy_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream), a, d_x, d_y,
+                       n);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_scale(float a, float* d_x, int64_t n, void* stream) {
+    SKR_REQUIRE(d_x, "skr_scale: NULL argument");
+    if (n <= 0) return SKR_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream), a, d_x, n);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+"""ctypes binding of ``libskrec_hip.so`` (C ABI declared in ``include/skrec_hip.h``).
+
+This is the only way the host mirror reaches the hot path: there is no CPU fallback.  If the
+library is missing, or no gfx950 device is visible when a kernel is needed, the call raises.
+PyTorch is used for device memory and streams only: tensors go in as ``data_ptr()`` and the
+current stream as ``cuda_stream``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # scikit-recommender_amd/
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libskrec_hip.so")
+CSRC_DIR = os.path.join(_PKG_ROOT, "csrc")
+
+vp, i32, i64, u32, u64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/skrec_hip.h declares
+SIGNATURES = {
+    "skr_abi_version": (i32, []),
+    "skr_last_error": (C.c_char_p, []),
+    "skr_device_count": (i32, []),
+    "skr_device_summary": (i32, [C.c_char_p, sz]),
+    "skr_csr_max_row_len": (i32, [vp, i32, C.POINTER(i32), vp]),
+    "skr_sampler_create": (i32, [u32, C.POINTER(vp)]),
+    "skr_sampler_destroy": (i32, [vp]),
+    "skr_sampler_get_state": (i32, [vp, vp, C.POINTER(i32)]),
+    "skr_sampler_set_state": (i32, [vp, vp, i32]),
+    "skr_sampler_draws": (i32, [vp, C.POINTER(u64)]),
+    "skr_randint_choice": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp]),
+    "skr_sample_epoch_exact": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, vp]),
+    "skr_sample_epoch_fast": (i32, [u64, u64, i64, i32, i32, vp, vp, i64, i32, vp, vp]),
+    "skr_eval_scores": (i32, [vp, i32, i32, i64, vp, vp, C.POINTER(i32), i32, i32, vp, vp, vp, vp]),
+    "skr_eval_fused_workspace": (sz, [i32, i32]),
+    "skr_eval_fused_topk": (i32, [vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, sz, vp]),
+    "skr_mask_train": (i32, [vp, i32, i32, i64, vp, vp, vp, vp]),
+    "skr_rank_metrics": (i32, [vp, i32, i32, vp, vp, vp, C.POINTER(i32), i32, vp, vp, vp]),
+    "skr_bpr_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "skr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp]),
+    "skr_csr_spmm": (i32, [i32, vp, vp, vp, vp, i32, i64, vp, vp, vp, f32, vp]),
+    "skr_layer_refine_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp]),
+    "skr_layer_refine_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+    "skr_gather_rows": (i32, [vp, vp, i64, i32, vp, vp]),
+    "skr_axpy": (i32, [f32, vp, vp, i64, vp]),
+    "skr_scale": (i32, [f32, vp, i64, vp]),
+}
+
+SKR_MAX_TOPK = 128
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.run(["make", "-C", CSRC_DIR, "-j4"], check=True)
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared library (no GPU needed for loading / symbol checks)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"(there is no CPU fallback for the hot path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = the .so and the header disagree
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().skr_last_error()
+        raise (ValueError if rc == -1 else HipError)(msg.decode() if msg else f"libskrec_hip error {rc}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available() or lib().skr_device_count() == 0:
+        raise HipError("no MI355X / HIP device is visible: the skrec hot path runs on the GPU only")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """device (or host) address of a torch tensor / numpy array / None"""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return t.data_ptr()
+
+
+def metric_array(ids):
+    return (i32 * len(ids))(*[int(x) for x in ids])

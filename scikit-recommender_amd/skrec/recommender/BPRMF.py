@@ -1,0 +1,117 @@
+"""BPRMF on MI355X (reference: skrec/recommender/BPRMF.py).
+
+Paper: BPR: Bayesian Personalized Ranking from Implicit Feedback (Rendle et al.).
+Same config, same initialisation (weights are drawn on the CPU with torch's generator in the
+reference's order, so a given ``--seed`` yields the reference's initial tables), same loss
+(sum over the batch of -log sigmoid(x_ui - x_uj) + reg * 0.5 * sum of squares of the gathered rows,
+BPRMF.py:117-124) and the same dense Adam.  One training step is two kinds of launches:
+``skr_bpr_step`` (gather + score + loss + gradient scatter fused) and ``skr_adam_step`` per table.
+"""
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..io import PairwiseIterator
+from ..run_config import RunConfig
+from ..utils.py import EarlyStopping, ModelConfig
+from ..utils.torch import get_initializer
+from .base import AbstractRecommender, DenseAdam
+
+__all__ = ["BPRMF", "BPRMFConfig"]
+
+
+class BPRMFConfig(ModelConfig):
+    def __init__(self, lr=1e-3, reg=1e-3, n_dim=64, batch_size=1024, epochs=1000, early_stop=200, **kwargs):
+        super().__init__()
+        self.lr: float = lr
+        self.reg: float = reg
+        self.n_dim: int = n_dim
+        self.batch_size: int = batch_size
+        self.epochs: int = epochs
+        self.early_stop: int = early_stop
+
+    @classmethod
+    def param_space(cls):
+        return {"lr": [0.001, 0.005, 0.01, 0.05], "reg": [0.0, 0.001, 0.005, 0.01, 0.05]}
+
+    def _validate(self):
+        assert isinstance(self.lr, float) and self.lr > 0
+        assert isinstance(self.reg, float) and self.reg >= 0
+        assert isinstance(self.n_dim, int) and self.n_dim > 0
+        assert isinstance(self.batch_size, int) and self.batch_size > 0
+        assert isinstance(self.epochs, int) and self.epochs >= 0
+        assert isinstance(self.early_stop, int)
+
+
+def _init_tables(num_users, num_items, dim):
+    """CPU-side construction in the reference's order (_MF.__init__, BPRMF.py:57-75): three
+    nn.Embedding constructors (each draws N(0,1)), then normal(0, 0.01) x2 and zeros."""
+    ue, ie, be = nn.Embedding(num_users, dim), nn.Embedding(num_items, dim), nn.Embedding(num_items, 1)
+    get_initializer("normal")(ue.weight)
+    get_initializer("normal")(ie.weight)
+    get_initializer("zeros")(be.weight)
+    return ue.weight.detach(), ie.weight.detach(), be.weight.detach().reshape(-1)
+
+
+class BPRMF(AbstractRecommender):
+    def __init__(self, run_config: RunConfig, model_config: Dict):
+        self.config = BPRMFConfig(**model_config)
+        super().__init__(run_config, self.config)
+        self.num_users, self.num_items = self.dataset.num_users, self.dataset.num_items
+        if self.config.n_dim != 64:
+            raise NotImplementedError("the MI355X kernels are specialised for n_dim=64 (one row per wavefront)")
+        self.device = _hip.require_gpu()
+        U, V, b = _init_tables(self.num_users, self.num_items, self.config.n_dim)
+        self.user_embeddings = U.to(self.device).contiguous()
+        self.item_embeddings = V.to(self.device).contiguous()
+        self.item_biases = b.to(self.device).contiguous()
+        self.optimizer = DenseAdam([self.user_embeddings, self.item_embeddings, self.item_biases], lr=self.config.lr)
+        self.step_losses = None  # device [n_steps, 2]: (bpr sum, l2) per step of the last epoch
+        self.sampler_mode = getattr(run_config, "sampler_mode", None)
+
+    def train_step(self, users, pos, neg, loss_slot):
+        """one mini-batch; ``users/pos/neg`` are int32 device tensors"""
+        gU, gV, gb = self.optimizer.grads
+        _hip.check(_hip.lib().skr_bpr_step(
+            _hip.ptr(self.user_embeddings), _hip.ptr(self.item_embeddings), _hip.ptr(self.item_biases),
+            _hip.ptr(self.user_embeddings), _hip.ptr(self.item_embeddings),
+            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), 1.0, self.config.reg, 1.0,
+            _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(gb), _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(loss_slot), _hip.stream()))
+        self.optimizer.step()
+
+    def train_epoch(self, data_iter):
+        self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
+        for k, (u, i, j) in enumerate(data_iter.iter_device()):
+            self.train_step(u.contiguous(), i.contiguous(), j.contiguous(), self.step_losses[k])
+
+    def fit(self):
+        data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
+                                     drop_last=False, sampler_mode=self.sampler_mode)
+        self.logger.info("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
+        early_stopping = EarlyStopping(metric="NDCG@10", patience=self.config.early_stop)
+        for epoch in range(self.config.epochs):
+            self.train_epoch(data_iter)
+            cur_result = self.evaluate()
+            self.logger.info(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
+            if early_stopping(cur_result):
+                self.logger.info("early stop")
+                break
+        self.logger.info("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
+        return early_stopping.best_result
+
+    def evaluate(self, test_users=None):
+        return self.evaluator.evaluate(self, test_users)
+
+    def predict_factors(self):
+        return self.user_embeddings, self.item_embeddings, self.item_biases
+
+    def predict(self, users) -> np.ndarray:
+        """dense [len(users), num_items] scores (API surface of BPRMF.py:145-147; the evaluator uses
+        the fused kernel through ``predict_factors`` instead)"""
+        users = torch.from_numpy(np.asarray(users)).long().to(self.device)
+        ratings = torch.matmul(self.user_embeddings[users], self.item_embeddings.T)
+        ratings += self.item_biases
+        return ratings.cpu().numpy()

@@ -1,0 +1,166 @@
+"""LayerGCN on MI355X (reference: skrec/recommender/LayerGCN.py).
+
+Paper: Layer-refined Graph Convolutional Networks for Recommendation (Zhou et al., ICDE 2023).
+Per layer (LayerGCN.py:212-216):  Y = A X ;  w = cos(Y, E0) row-wise ;  X' = w * Y  (the re-weighted
+tensor feeds the next layer); output = SUM of the K refined layers (E0 itself excluded, :218);
+loss = sum_b -log sigmoid(x_ui - x_uj) + reg * 0.5 * ||ego rows||^2 (:231, :242, :252); dense Adam,
+constant learning rate (the LambdaLR factor is 1.0 ** (epoch / 50), :274-276).
+``skr_csr_spmm`` does the propagation, ``skr_layer_refine_fwd/_bwd`` the cosine re-weighting and its
+hand-derived backward; A is symmetric so the backward propagation is the same kernel.
+Edge dropout (``dropout > 0``, :133-152) is not implemented yet.
+"""
+from typing import Dict
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..io import PairwiseIterator
+from ..run_config import RunConfig
+from ..utils.py import EarlyStopping, ModelConfig
+from .base import AbstractRecommender, DenseAdam
+from .LightGCN import DeviceCSR
+
+__all__ = ["LayerGCN", "LayerGCNConfig"]
+
+
+class LayerGCNConfig(ModelConfig):
+    def __init__(self, lr=1e-3, reg=1e-2, embed_dim=64, n_layers=4, dropout=0.0, batch_size=2048, epochs=1000,
+                 early_stop=200, **kwargs):
+        super().__init__()
+        self.lr: float = lr
+        self.reg: float = reg
+        self.embed_dim: int = embed_dim
+        self.n_layers: int = n_layers
+        self.dropout: float = dropout
+        self.batch_size: int = batch_size
+        self.epochs: int = epochs
+        self.early_stop: int = early_stop
+
+    @classmethod
+    def param_space(cls):
+        return {"n_layers": [4], "reg": [1e-02, 1e-03, 1e-04, 1e-05], "dropout": [0.0, 0.1, 0.2]}
+
+
+def build_layergcn_adjacency(inter_coo, n_users, n_items):
+    """get_norm_adj_mat (LayerGCN.py:173-197): binary bipartite adjacency, D^-1/2 A D^-1/2 with
+    1e-7 added to the degrees, computed in float64 and rounded to float32 at the end."""
+    n = n_users + n_items
+    r = np.asarray(inter_coo.row, dtype=np.int64)
+    c = np.asarray(inter_coo.col, dtype=np.int64) + n_users
+    A = sp.csr_matrix((np.ones(2 * len(r), dtype=np.float32), (np.concatenate([r, c]), np.concatenate([c, r]))),
+                      shape=(n, n))
+    A.data[:] = 1.0  # duplicate pairs collapse to one edge (the reference goes through a dict)
+    deg = np.asarray((A > 0).sum(axis=1)).reshape(-1) + 1e-7
+    d = sp.diags(np.power(deg, -0.5))
+    return (d * A * d).astype(np.float32)
+
+
+class LayerGCN(AbstractRecommender):
+    def __init__(self, run_config: RunConfig, model_config: Dict):
+        self.config = LayerGCNConfig(**model_config)
+        super().__init__(run_config, self.config)
+        cfg = self.config
+        self.num_users, self.num_items = self.dataset.num_users, self.dataset.num_items
+        if cfg.embed_dim != 64:
+            raise NotImplementedError("the MI355X kernels are specialised for embed_dim=64")
+        if cfg.dropout > 0.0:
+            raise NotImplementedError("LayerGCN edge dropout is not implemented yet (dropout must be 0.0)")
+        self.device = _hip.require_gpu()
+        inter = self.dataset.train_data.to_coo_matrix().astype(np.float32)
+        # parameters first, like _LayerGCN.__init__ (:114-115): xavier_uniform on plain tensors
+        ue = nn.init.xavier_uniform_(torch.empty(self.num_users, cfg.embed_dim))
+        ie = nn.init.xavier_uniform_(torch.empty(self.num_items, cfg.embed_dim))
+        self.adj = DeviceCSR(build_layergcn_adjacency(inter, self.num_users, self.num_items), self.device)
+        N = self.num_users + self.num_items
+        self.ego = torch.cat([ue, ie], dim=0).to(self.device).contiguous()
+        self.optimizer = DenseAdam([self.ego], lr=cfg.lr)
+        z = lambda: torch.zeros((N, 64), dtype=torch.float32, device=self.device)  # noqa: E731
+        K = cfg.n_layers
+        self.out = z()                                   # sum of refined layers
+        self._y = [z() for _ in range(K)]                # A X_k kept for the backward
+        self._w = [torch.zeros(N, dtype=torch.float32, device=self.device) for _ in range(K)]
+        self._z = [z(), z()]                             # refined layer ping-pong
+        self._g_out = z()
+        self._t = [z(), z()]
+        self.step_losses = None
+        self.sampler_mode = getattr(run_config, "sampler_mode", None)
+
+    @property
+    def user_embeddings(self):
+        return self.ego[:self.num_users]
+
+    @property
+    def item_embeddings(self):
+        return self.ego[self.num_users:]
+
+    def forward(self):
+        L, st = _hip.lib(), _hip.stream()
+        N = self.ego.shape[0]
+        self.out.zero_()
+        x = self.ego
+        for k in range(self.config.n_layers):
+            self.adj.spmm(x, self._y[k])
+            zk = self._z[k & 1]
+            _hip.check(L.skr_layer_refine_fwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), N, 64, _hip.ptr(zk),
+                                              _hip.ptr(self._w[k]), _hip.ptr(self.out), st))
+            x = zk
+        return self.out
+
+    def train_step(self, users, pos, neg, loss_slot):
+        cfg, nu = self.config, self.num_users
+        L, st = _hip.lib(), _hip.stream()
+        N = self.ego.shape[0]
+        self.forward()
+        gO, (gE,) = self._g_out, self.optimizer.grads
+        gO.zero_()
+        _hip.check(L.skr_bpr_step(
+            _hip.ptr(self.out[:nu]), _hip.ptr(self.out[nu:]), None, _hip.ptr(self.ego[:nu]), _hip.ptr(self.ego[nu:]),
+            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), 1.0, cfg.reg, 1.0,
+            _hip.ptr(gO[:nu]), _hip.ptr(gO[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot), st))
+        # backward: dZ_K = gO ; dY_k, dE0 += refine_bwd(dZ_k) ; dZ_{k-1} = gO + A dY_k ; dE0 += A dY_1
+        dz = gO
+        dy, tmp = self._t
+        for k in range(cfg.n_layers - 1, -1, -1):
+            _hip.check(L.skr_layer_refine_bwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), _hip.ptr(self._w[k]),
+                                              _hip.ptr(dz), N, 64, _hip.ptr(dy), _hip.ptr(gE), st))
+            if k > 0:
+                self.adj.spmm(dy, tmp, addend=gO)
+                dz = tmp
+            else:
+                self.adj.spmm(dy, tmp, accum=gE, accum_scale=1.0)
+        self.optimizer.step()
+
+    def train_epoch(self, data_iter):
+        self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
+        for k, (u, i, j) in enumerate(data_iter.iter_device()):
+            self.train_step(u.contiguous(), i.contiguous(), j.contiguous(), self.step_losses[k])
+
+    def fit(self):
+        data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
+                                     drop_last=False, sampler_mode=self.sampler_mode)
+        self.logger.info("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
+        early_stopping = EarlyStopping(metric="NDCG@10", patience=self.config.early_stop)
+        for epoch in range(self.config.epochs):
+            self.train_epoch(data_iter)
+            cur_result = self.evaluate()
+            self.logger.info(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
+            if early_stopping(cur_result):
+                self.logger.info("early stop")
+                break
+        self.logger.info("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
+        return early_stopping.best_result
+
+    def evaluate(self, test_users=None):
+        self.forward()   # one propagation per evaluation (the reference repeats it per batch, :255-262)
+        return self.evaluator.evaluate(self, test_users)
+
+    def predict_factors(self):
+        return self.out[:self.num_users], self.out[self.num_users:], None
+
+    def predict(self, users):
+        self.forward()
+        users = torch.from_numpy(np.asarray(users)).long().to(self.device)
+        return torch.matmul(self.out[:self.num_users][users], self.out[self.num_users:].T).cpu().numpy()

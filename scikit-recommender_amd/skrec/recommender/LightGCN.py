@@ -1,0 +1,225 @@
+"""LightGCN on MI355X (reference: skrec/recommender/LightGCN.py).
+
+Paper: LightGCN: Simplifying and Powering Graph Convolution Network for Recommendation (He et al.).
+Reference semantics are kept: the full-graph K-layer propagation runs forward AND backward on every
+mini-batch (LightGCN.py:89-100, :180-199), the BPR loss is a mean, the L2 term uses the ego rows and
+is divided by the CONFIGURED batch size (:191-196), Adam is dense.  Each propagation is
+``skr_csr_spmm`` (CSR, one wavefront per 512 non-zeros, 64 lanes = 64 dims) with the layer mean
+fused into its epilogue; the backward pass reuses the same kernel because the normalised adjacency
+of every ``adj_type`` used here is applied as A^T = A for 'pre'/'plain' and explicitly transposed
+otherwise.
+"""
+import os
+from typing import Dict
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..io import PairwiseIterator
+from ..run_config import RunConfig
+from ..utils.common import make_sure_dirs, normalize_adj_matrix
+from ..utils.py import EarlyStopping, ModelConfig
+from ..utils.torch import get_initializer
+from .base import AbstractRecommender, DenseAdam
+
+__all__ = ["LightGCN", "LightGCNConfig", "DeviceCSR"]
+
+
+class LightGCNConfig(ModelConfig):
+    def __init__(self, lr=1e-3, reg=1e-3, embed_size=64, n_layers=3, adj_type="pre", batch_size=1024, epochs=1000,
+                 early_stop=100, **kwargs):
+        super().__init__()
+        self.lr: float = lr
+        self.reg: float = reg
+        self.embed_size: int = embed_size
+        self.n_layers: int = n_layers
+        self.adj_type: str = adj_type  # plain, norm, gcmc, pre
+        self.batch_size: int = batch_size
+        self.epochs: int = epochs
+        self.early_stop: int = early_stop
+
+    def _validate(self):
+        assert isinstance(self.lr, float) and self.lr > 0
+        assert isinstance(self.reg, float) and self.reg >= 0
+        assert isinstance(self.embed_size, int) and self.embed_size > 0
+        assert isinstance(self.n_layers, int) and self.n_layers > 0
+        assert self.adj_type in {"plain", "norm", "gcmc", "pre"}
+        assert isinstance(self.batch_size, int) and self.batch_size > 0
+        assert isinstance(self.epochs, int) and self.epochs >= 0
+        assert isinstance(self.early_stop, int)
+
+
+class DeviceCSR(object):
+    """A scipy matrix as (rowptr int64, col int32, val fp32) in HBM; duplicates summed, columns
+    ascending per row -- the same canonical form as the reference's coalesced COO tensor
+    (utils/torch.py:32-35)."""
+
+    def __init__(self, mat, device):
+        csr = sp.csr_matrix(mat).astype(np.float32)
+        csr.sum_duplicates()
+        csr.sort_indices()
+        self.shape = csr.shape
+        self.nnz = int(csr.nnz)
+        self.rowptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(device)
+        self.col = torch.from_numpy(csr.indices.astype(np.int32)).to(device)
+        self.val = torch.from_numpy(csr.data.astype(np.float32)).to(device)
+        if self.nnz == 0:
+            self.col = torch.zeros(1, dtype=torch.int32, device=device)
+            self.val = torch.zeros(1, dtype=torch.float32, device=device)
+
+    def spmm(self, X, Y, addend=None, accum=None, accum_scale=1.0):
+        """Y = A @ X (+ addend); accum += accum_scale * Y"""
+        _hip.check(_hip.lib().skr_csr_spmm(self.shape[0], _hip.ptr(self.rowptr), _hip.ptr(self.col), _hip.ptr(self.val),
+                                           _hip.ptr(X), 64, self.nnz, _hip.ptr(addend), _hip.ptr(Y), _hip.ptr(accum),
+                                           float(accum_scale), _hip.stream()))
+        return Y
+
+
+def build_adjacency(users_np, items_np, num_users, num_items, adj_type):
+    """LightGCN._create_adj_mat (LightGCN.py:142-169)"""
+    n_nodes = num_users + num_items
+    ones = np.ones_like(users_np, dtype=np.float32)
+    upper = sp.csr_matrix((ones, (users_np, items_np + num_users)), shape=(n_nodes, n_nodes))
+    adj = upper + upper.T
+    if adj_type == "plain":
+        return adj
+    if adj_type == "norm":
+        return normalize_adj_matrix(adj + sp.eye(adj.shape[0]), norm_method="left")
+    if adj_type == "gcmc":
+        return normalize_adj_matrix(adj, norm_method="left")
+    if adj_type == "pre":
+        return normalize_adj_matrix(adj, norm_method="symmetric")
+    mean_adj = normalize_adj_matrix(adj, norm_method="left")
+    return mean_adj + sp.eye(mean_adj.shape[0])
+
+
+class LightGCN(AbstractRecommender):
+    def __init__(self, run_config: RunConfig, model_config: Dict):
+        self.config = LightGCNConfig(**model_config)
+        super().__init__(run_config, self.config)
+        cfg = self.config
+        self.num_users, self.num_items = self.dataset.num_users, self.dataset.num_items
+        if cfg.embed_size != 64:
+            raise NotImplementedError("the MI355X kernels are specialised for embed_size=64")
+        self.device = _hip.require_gpu()
+        adj = self._load_adj_mat(cfg.adj_type)
+        self.adj = DeviceCSR(adj, self.device)
+        # backward needs A^T; 'pre' and 'plain' are symmetric, 'norm'/'gcmc' are not
+        self.adj_t = self.adj if cfg.adj_type in ("pre", "plain") else DeviceCSR(sp.csr_matrix(adj).T, self.device)
+        # xavier_uniform init in the reference's order (_LightGCN.__init__, LightGCN.py:71-80)
+        ue, ie = nn.Embedding(self.num_users, cfg.embed_size), nn.Embedding(self.num_items, cfg.embed_size)
+        get_initializer("xavier_uniform")(ue.weight)
+        get_initializer("xavier_uniform")(ie.weight)
+        N = self.num_users + self.num_items
+        self.ego = torch.cat([ue.weight.detach(), ie.weight.detach()], dim=0).to(self.device).contiguous()  # E0
+        self.optimizer = DenseAdam([self.ego], lr=cfg.lr)
+        z = lambda: torch.zeros((N, 64), dtype=torch.float32, device=self.device)  # noqa: E731
+        self.final = z()          # layer mean, E-bar
+        self._x = [z(), z()]      # propagation ping-pong
+        self._g_final = z()       # dL/dE-bar, then H = dL/dE-bar / (K+1)
+        self._g = [z(), z()]      # backward ping-pong
+        self._final_is_current = False
+        self.step_losses = None
+        self.sampler_mode = getattr(run_config, "sampler_mode", None)
+
+    # views -----------------------------------------------------------------------------------------
+    @property
+    def user_embeddings(self):
+        return self.ego[:self.num_users]
+
+    @property
+    def item_embeddings(self):
+        return self.ego[self.num_users:]
+
+    def _load_adj_mat(self, adj_type):
+        out_dir = os.path.join(self.dataset.data_dir, f"_{self.__class__.__name__}_data")
+        make_sure_dirs(out_dir)
+        path = os.path.join(out_dir, f"{adj_type}_adj.npz")
+        if os.path.exists(path):   # same cache side file as the reference (LightGCN.py:130-140)
+            return sp.load_npz(path)
+        adj = self._create_adj_mat(adj_type)
+        sp.save_npz(path, adj)
+        return adj
+
+    def _create_adj_mat(self, adj_type):
+        pairs = self.dataset.train_data.to_user_item_pairs()
+        return build_adjacency(pairs[:, 0], pairs[:, 1], self.num_users, self.num_items, adj_type)
+
+    # propagation -----------------------------------------------------------------------------------
+    def propagate(self):
+        """E-bar = mean(E0, A E0, ..., A^K E0)  (_forward_gcn, LightGCN.py:89-100)"""
+        K = self.config.n_layers
+        scale = 1.0 / (K + 1)
+        self.final.zero_()
+        _hip.check(_hip.lib().skr_axpy(scale, _hip.ptr(self.ego), _hip.ptr(self.final), self.ego.numel(), _hip.stream()))
+        x = self.ego
+        for k in range(K):
+            y = self._x[k & 1]
+            self.adj.spmm(x, y, accum=self.final, accum_scale=scale)
+            x = y
+        return self.final
+
+    def train_step(self, users, pos, neg, loss_slot):
+        cfg, nu = self.config, self.num_users
+        K = cfg.n_layers
+        n = users.numel()
+        self.propagate()
+        self._final_is_current = False
+        gF, (gE,) = self._g_final, self.optimizer.grads
+        gF.zero_()
+        _hip.check(_hip.lib().skr_bpr_step(
+            _hip.ptr(self.final[:nu]), _hip.ptr(self.final[nu:]), None, _hip.ptr(self.ego[:nu]), _hip.ptr(self.ego[nu:]),
+            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), n, 1.0 / n, cfg.reg, 1.0 / cfg.batch_size,
+            _hip.ptr(gF[:nu]), _hip.ptr(gF[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot),
+            _hip.stream()))
+        # backward through the mean and the K propagations: dL/dE0 += sum_k (A^T)^k H, H = gF/(K+1)
+        _hip.check(_hip.lib().skr_scale(1.0 / (K + 1), _hip.ptr(gF), gF.numel(), _hip.stream()))
+        x = gF
+        for k in range(K):
+            y = self._g[k & 1]
+            last = (k == K - 1)
+            self.adj_t.spmm(x, y, addend=gF, accum=gE if last else None, accum_scale=1.0)
+            x = y
+        self.optimizer.step()
+
+    def train_epoch(self, data_iter):
+        self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
+        for k, (u, i, j) in enumerate(data_iter.iter_device()):
+            self.train_step(u.contiguous(), i.contiguous(), j.contiguous(), self.step_losses[k])
+
+    def fit(self):
+        data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
+                                     drop_last=False, sampler_mode=self.sampler_mode)
+        self.logger.info("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
+        early_stopping = EarlyStopping(metric="NDCG@10", patience=self.config.early_stop)
+        for epoch in range(self.config.epochs):
+            self.train_epoch(data_iter)
+            cur_result = self.evaluate()
+            self.logger.info(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
+            if early_stopping(cur_result):
+                self.logger.info("early stop")
+                break
+        self.logger.info("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
+        return early_stopping.best_result
+
+    def eval(self):
+        """recompute and cache the final embeddings (_LightGCN.eval, LightGCN.py:109-111)"""
+        self.propagate()
+        self._final_is_current = True
+
+    def evaluate(self, test_users=None):
+        self.eval()
+        return self.evaluator.evaluate(self, test_users)
+
+    def predict_factors(self):
+        if not self._final_is_current:
+            raise ValueError("Please first switch to 'eval' mode.")
+        return self.final[:self.num_users], self.final[self.num_users:], None
+
+    def predict(self, users):
+        uf, vf, _ = self.predict_factors()
+        users = torch.from_numpy(np.asarray(users)).long().to(self.device)
+        return torch.matmul(uf[users], vf.T).cpu().numpy()

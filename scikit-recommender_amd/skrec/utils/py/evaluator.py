@@ -1,0 +1,276 @@
+"""``RankingEvaluator`` on the GPU (reference: skrec/utils/py/evaluator.py).
+
+Same constructor, same ``evaluate(model, test_users=None) -> MetricReport``, same metric names and
+column order.  Two device paths, both through libskrec_hip.so:
+
+* **fused** -- taken when the model exposes ``predict_factors() -> (user_table, item_table, bias|None)``
+  (fp32 device tensors, 64 columns): ``skr_eval_fused_topk`` scores every test user against the whole
+  catalogue on FP32 MFMA, masks train items and keeps the top-K without ever forming the [B, I]
+  score matrix; ``skr_rank_metrics`` turns the lists into metric rows.
+* **generic** -- any object with ``predict(users) -> ndarray [B, I]`` (the reference's contract,
+  evaluator.py:180-193): the scores are uploaded, train items masked (``skr_mask_train``) and
+  ranked by ``skr_eval_scores``, the drop-in for ``cpp_evaluate_matrix``.
+
+Aggregation: the reference takes a float32 ``np.mean`` over the per-user rows (evaluator.py:207-208).
+Up to ``_HOST_MEAN_MAX`` users we do exactly that on the (bit-identical) rows; beyond it the rows are
+summed in fp64 on the device, which is what the 1e-5 parity at 1 M users is defined against.
+"""
+import itertools
+from collections import OrderedDict
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from ... import _hip
+
+__all__ = ["MetricReport", "RankingEvaluator", "EarlyStopping"]
+
+_HOST_MEAN_MAX = 1 << 18
+_FUSED_CHUNK = 1 << 15     # users per fused launch (64 MB of candidate scratch)
+
+
+class MetricReport(object):
+    def __init__(self, metrics: Sequence[str], values: Sequence[float]):
+        assert len(metrics) == len(values), f"The lengths of metrics and values " \
+                                            f"are not equal ({len(metrics)}!={len(values)})."
+        self._results = OrderedDict(zip(metrics, values))
+
+    def metrics(self):
+        return self._results.keys()
+
+    def values(self):
+        return self._results.values()
+
+    def items(self):
+        return self._results.items()
+
+    @property
+    def results(self) -> Dict[str, float]:
+        return self._results
+
+    @property
+    def metrics_str(self) -> str:
+        return "\t".join(f"{m}".ljust(12) for m in self.metrics())
+
+    @property
+    def values_str(self) -> str:
+        return "\t".join(f"{v:.8f}".ljust(12) for v in self.values())
+
+    def __getitem__(self, item):
+        if item not in self._results:
+            raise KeyError(item)
+        return self._results[item]
+
+    def __str__(self):
+        return str(self._results)
+
+
+_metric2id = {"Precision": 1, "Recall": 2, "MAP": 3, "NDCG": 4, "MRR": 5}
+_id2metric = {v: k for k, v in _metric2id.items()}
+
+
+def _dict_to_csr(d, n_rows, sort_rows=True):
+    """dict user -> items  ==>  (rowptr int64 [n_rows+1], items int32 sorted & unique per row)"""
+    rowptr = np.zeros(n_rows + 1, np.int64)
+    rows = {}
+    for u, items in d.items():
+        a = np.unique(np.asarray(items, dtype=np.int64)).astype(np.int32) if sort_rows else np.asarray(items, np.int32)
+        rows[int(u)] = a
+        rowptr[int(u) + 1] = len(a)
+    np.cumsum(rowptr, out=rowptr)
+    flat = np.zeros(max(int(rowptr[-1]), 1), np.int32)
+    for u, a in rows.items():
+        flat[rowptr[u]:rowptr[u] + len(a)] = a
+    return rowptr, flat
+
+
+class RankingEvaluator(object):
+    """Evaluator for the item-ranking task; metrics ``Precision, Recall, MAP, NDCG, MRR``.
+    In leave-one-out evaluation ``Recall`` equals HitRatio (evaluator.py:75-76)."""
+
+    def __init__(self, user_train_dict: Optional[Dict[int, np.ndarray]], user_test_dict: Dict[int, np.ndarray],
+                 metric: Union[None, str, Tuple[str], List[str]] = None, top_k: Union[int, List[int], Tuple[int]] = 50,
+                 batch_size: int = 256, num_thread: int = 8):
+        if metric is None:
+            metric = ["Precision", "Recall", "MAP", "NDCG", "MRR"]
+        elif isinstance(metric, str):
+            metric = [metric]
+        elif isinstance(metric, (tuple, list)):
+            metric = list(metric)
+        else:
+            raise TypeError("The type of 'metric' (%s) is invalid!" % metric.__class__.__name__)
+        for m in metric:
+            assert m in _metric2id, f"'{metric}' is not in ('Precision', 'Recall', 'MAP', 'NDCG', 'MRR')."
+        self.user_pos_train = dict()
+        self.user_pos_test = dict()
+        self._dev = None  # device CSRs, built lazily
+        self.set_train_data(user_train_dict)
+        self.set_test_data(user_test_dict)
+        self.metrics_num = len(metric)
+        self.metrics = [_metric2id[m] for m in metric]
+        self.num_thread = num_thread   # API parity; the GPU path has no thread pool
+        self.batch_size = batch_size
+        if isinstance(top_k, (int, np.integer)):
+            self.max_top = int(top_k)
+            self.top_show = np.arange(top_k) + 1
+        else:
+            self.max_top = int(max(top_k))
+            self.top_show = np.sort(top_k)
+        if self.max_top > _hip.SKR_MAX_TOPK:
+            raise NotImplementedError(f"top_k up to {_hip.SKR_MAX_TOPK} is supported by the HIP kernels "
+                                      f"(got {self.max_top})")
+
+    def set_train_data(self, user_train_dict: Optional[Dict[int, np.ndarray]] = None):
+        self.user_pos_train = user_train_dict if user_train_dict is not None else dict()
+        self._dev = None
+
+    def set_test_data(self, user_test_dict: Dict[int, np.ndarray]):
+        assert len(user_test_dict) > 0, "'user_test_dict' can be empty."
+        self.user_pos_test = user_test_dict
+        self._dev = None
+
+    @property
+    def metrics_list(self) -> List[str]:
+        return [f"{_id2metric[mid]}@{str(k)}" for mid in self.metrics for k in self.top_show]
+
+    @property
+    def metrics_str(self) -> str:
+        return "\t".join(f"{m}".ljust(12) for m in self.metrics_list)
+
+    # ---- device state ----------------------------------------------------------------------------
+    def _device_state(self):
+        if self._dev is None:
+            import torch
+            dev = _hip.require_gpu()
+            keys = itertools.chain(self.user_pos_train.keys(), self.user_pos_test.keys())
+            n_rows = max(int(u) for u in keys) + 1
+            tr_ptr, tr_items = _dict_to_csr(self.user_pos_train, n_rows)
+            te_ptr, te_items = _dict_to_csr(self.user_pos_test, n_rows)
+            self._dev = dict(
+                dev=dev, n_rows=n_rows, max_train=int(np.diff(tr_ptr).max()) if n_rows else 0,
+                tr_ptr=torch.from_numpy(tr_ptr).to(dev), tr_items=torch.from_numpy(tr_items).to(dev),
+                te_ptr=torch.from_numpy(te_ptr).to(dev), te_items=torch.from_numpy(te_items).to(dev))
+        return self._dev
+
+    # ---- evaluation ------------------------------------------------------------------------------
+    def evaluate(self, model, test_users: Optional[Iterable[int]] = None) -> MetricReport:
+        assert hasattr(model, "predict"), "the model must have attribute 'predict'."
+        if test_users is not None:
+            test_users = [u for u in test_users if u in self.user_pos_test]
+        else:
+            test_users = list(self.user_pos_test.keys())
+        assert isinstance(test_users, Iterable), "'test_user' must be iterable."
+        rows, sums, n = self.per_user_rows(model, test_users)
+        if rows is not None:
+            final = np.mean(rows, axis=0)                      # float32, as evaluator.py:208
+        else:
+            final = (sums / max(n, 1)).astype(np.float32)
+        final = final.reshape(self.metrics_num, self.max_top)[:, self.top_show - 1].reshape(-1)
+        return MetricReport(self.metrics_list, final)
+
+    def per_user_rows(self, model, test_users):
+        """-> (rows float32 [n, n_metric*max_top] on the host or None, fp64 column sums, n)."""
+        import torch
+        st = self._device_state()
+        dev, K, nm = st["dev"], self.max_top, self.metrics_num
+        users = np.asarray(list(test_users), dtype=np.int32)
+        n = len(users)
+        d_sums = torch.zeros(nm * K, dtype=torch.float64, device=dev)
+        keep_rows = n <= _HOST_MEAN_MAX
+        host_rows = []
+        margs = _hip.metric_array(self.metrics)
+        factors = model.predict_factors() if hasattr(model, "predict_factors") else None
+        if factors is not None:
+            ut, it, bias = factors
+            n_items = int(it.shape[0])
+            fused_ok = (it.shape[1] == 64 and ut.shape[1] == 64 and n_items - st["max_train"] >= K)
+        if factors is not None and fused_ok:
+            d_users = torch.from_numpy(users).to(dev)
+            work = torch.empty(int(_hip.lib().skr_eval_fused_workspace(min(n, _FUSED_CHUNK), K)), dtype=torch.uint8,
+                               device=dev)
+            for s in range(0, n, _FUSED_CHUNK):
+                b = min(_FUSED_CHUNK, n - s)
+                du = d_users[s:s + b]
+                ids = torch.empty((b, K), dtype=torch.int32, device=dev)
+                rows = torch.empty((b, nm * K), dtype=torch.float32, device=dev)
+                _hip.check(_hip.lib().skr_eval_fused_topk(
+                    _hip.ptr(ut), _hip.ptr(du), b, _hip.ptr(it), _hip.ptr(bias), n_items, 64, _hip.ptr(st["tr_ptr"]),
+                    _hip.ptr(st["tr_items"]), K, _hip.ptr(ids), None, _hip.ptr(work), work.numel(), _hip.stream()))
+                _hip.check(_hip.lib().skr_rank_metrics(
+                    _hip.ptr(ids), b, K, _hip.ptr(du), _hip.ptr(st["te_ptr"]), _hip.ptr(st["te_items"]), margs, nm,
+                    _hip.ptr(rows), _hip.ptr(d_sums), _hip.stream()))
+                if keep_rows:
+                    host_rows.append(rows.cpu().numpy())
+        else:
+            # generic contract of the reference: predict() returns a dense [B, I] ndarray
+            bs = max(int(self.batch_size), 1)
+            for s in range(0, n, bs):
+                bu = users[s:s + bs]
+                score = model.predict(list(bu))
+                assert isinstance(score, np.ndarray), "'ranking_score' must be an np.ndarray"
+                d_sc = torch.from_numpy(np.ascontiguousarray(score, np.float32)).to(dev)
+                du = torch.from_numpy(bu).to(dev)
+                b, n_items = d_sc.shape
+                _hip.check(_hip.lib().skr_mask_train(_hip.ptr(d_sc), b, n_items, n_items, _hip.ptr(du),
+                                                     _hip.ptr(st["tr_ptr"]), _hip.ptr(st["tr_items"]), _hip.stream()))
+                # gather the truth rows of this batch into a compact CSR so that row b <-> user bu[b]
+                rows = torch.empty((b, nm * K), dtype=torch.float32, device=dev)
+                te_ptr, te_items = _batch_truth(st, du)
+                _hip.check(_hip.lib().skr_eval_scores(_hip.ptr(d_sc), b, n_items, n_items, _hip.ptr(te_ptr),
+                                                      _hip.ptr(te_items), margs, nm, K, _hip.ptr(rows), None,
+                                                      _hip.ptr(d_sums), _hip.stream()))
+                if keep_rows:
+                    host_rows.append(rows.cpu().numpy())
+        sums = d_sums.cpu().numpy()
+        rows = np.concatenate(host_rows, axis=0) if keep_rows and host_rows else None
+        return rows, sums, n
+
+
+def _batch_truth(st, d_users):
+    """compact test CSR for the users of one batch (device tensors)"""
+    import torch
+    ptr, items = st["te_ptr"], st["te_items"]
+    u = d_users.long()
+    beg, end = ptr[u], ptr[u + 1]
+    lens = end - beg
+    out_ptr = torch.zeros(len(u) + 1, dtype=torch.int64, device=ptr.device)
+    out_ptr[1:] = torch.cumsum(lens, 0)
+    total = int(out_ptr[-1])
+    if total == 0:
+        return out_ptr, torch.zeros(1, dtype=torch.int32, device=ptr.device)
+    row_of = torch.repeat_interleave(torch.arange(len(u), device=ptr.device), lens)
+    offs = torch.arange(total, device=ptr.device) - out_ptr[row_of]
+    return out_ptr, items[beg[row_of] + offs].contiguous()
+
+
+class EarlyStopping(object):
+    """Stop when the monitored metric has not improved for ``patience`` evaluations
+    (patience <= 0: never) -- reference: evaluator.py:217-246."""
+
+    def __init__(self, metric: str = "NDCG@10", patience: int = 100):
+        self._metric = metric
+        self._patience = patience
+        self._best_score = None
+        self._counter = 0
+
+    def __call__(self, val_result: MetricReport):
+        if self._best_score is None:
+            self._best_score = val_result
+        elif val_result[self.key_metric] <= self._best_score[self.key_metric]:
+            self._counter += 1
+            if self._counter >= self._patience > 0:
+                return True
+        else:
+            self._best_score = val_result
+            self._counter = 0
+        return False
+
+    @property
+    def key_metric(self) -> str:
+        return self._metric
+
+    @property
+    def best_result(self) -> MetricReport:
+        if self._best_score is not None:
+            return self._best_score
+        return MetricReport(["None"], [0])

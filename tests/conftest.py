@@ -1,0 +1,39 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "scikit-recommender_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return load
+
+
+@pytest.fixture()
+def tiny_dir(tmp_path, golden):
+    """the tiny dataset of the golden fixtures, written in the reference's TSV format"""
+    d = golden("tiny_dataset")
+    root = tmp_path / "tiny"
+    root.mkdir()
+    for split in ("train", "test"):
+        rows = d[split]
+        with open(root / f"tiny.{split}", "w") as f:
+            for u, i, t in rows:
+                f.write(f"{int(u)}\t{int(i)}\t1.0\t{int(t)}\n")
+    return str(root)

@@ -1,0 +1,173 @@
+"""GPU parity, E rows: skr_eval_scores (drop-in for cpp_evaluate_matrix), skr_rank_metrics,
+skr_eval_fused_topk and the RankingEvaluator host mirror, against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from helpers import lists_from_csr, random_csr
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+ALL = [1, 2, 3, 4, 5]
+
+
+def test_eval_scores_golden_cases(golden):
+    """the reference's own eval_score_matrix outputs, bit for bit (tie-free rows; -inf masked columns)"""
+    from gpu_utils import eval_scores
+    e = golden("golden_eval")
+    for c in range(int(e["n_cases"])):
+        tests = lists_from_csr(e[f"c{c}_test_rowptr"], e[f"c{c}_test_items"])
+        K = int(e[f"c{c}_K"])
+        rows, ids, sums = eval_scores(e[f"c{c}_scores"], tests, e[f"c{c}_mids"], K)
+        assert np.array_equal(rows.view(np.uint32), e[f"c{c}_rows"].view(np.uint32)), c
+        np.testing.assert_allclose(sums, e[f"c{c}_rows"].astype(np.float64).sum(0), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("B,I,K", [(3, 5, 5), (4, 1000, 1), (5, 1024, 10), (2, 4097, 128), (7, 20000, 50),
+                                    (64, 100000, 10), (1, 2048, 100)])
+def test_eval_scores_vs_oracle(B, I, K):
+    from gpu_utils import eval_scores
+    rng = np.random.default_rng(B * 1000 + I + K)
+    sc = np.stack([rng.permutation(I).astype(np.float32) for _ in range(B)]) * np.float32(0.37) - np.float32(11)
+    for b in range(B):  # masked (train) columns
+        sc[b, rng.choice(I, min(I - K, int(rng.integers(0, 60))), replace=False)] = -np.inf
+    tests = [rng.choice(I, int(rng.integers(0, min(I, 12) + 1)), replace=False) for _ in range(B)]
+    want, want_ids = O.eval_score_matrix(sc, tests, ALL, K, return_ids=True)
+    rows, ids, _ = eval_scores(sc, tests, ALL, K)
+    assert np.array_equal(ids, want_ids)
+    assert np.array_equal(rows.view(np.uint32), want.view(np.uint32))
+
+
+def test_eval_scores_tie_rule_and_errors():
+    """exact ties rank by ascending item id (documented deviation from the heap order)"""
+    from gpu_utils import eval_scores
+    from skrec import _hip
+    rng = np.random.default_rng(3)
+    sc = np.round(rng.standard_normal((6, 3000)).astype(np.float32) * 4) / 4
+    sc[0, :] = 1.0  # an all-equal row
+    _, ids, _ = eval_scores(sc, [[] for _ in range(6)], [2], 25)
+    for b in range(6):
+        assert np.array_equal(ids[b], O.topk_ids_lowid(sc[b], 25))
+    assert list(ids[0]) == list(range(25))
+    with pytest.raises(ValueError):
+        eval_scores(sc, [[] for _ in range(6)], [6], 5)        # unknown metric id
+    with pytest.raises(ValueError):
+        eval_scores(sc[:, :4], [[] for _ in range(6)], [1], 5)  # top_k > n_items
+    with pytest.raises(ValueError):
+        eval_scores(sc, [[] for _ in range(6)], [1], 129)
+
+
+def test_rank_metrics_vs_oracle():
+    import torch
+    from gpu_utils import to_dev, dev
+    from skrec import _hip
+    rng = np.random.default_rng(8)
+    B, I, K = 500, 300, 37
+    ids = np.stack([rng.permutation(I)[:K] for _ in range(B)]).astype(np.int32)
+    rowptr, items = random_csr(rng, B, I, 0, 50)
+    # reference semantics through the oracle: a score row whose descending order is `ids`
+    sc = np.full((B, I), -1e9, np.float32)
+    for b in range(B):
+        sc[b, ids[b]] = np.arange(K, 0, -1, dtype=np.float32)
+    want = O.eval_score_matrix(sc, lists_from_csr(rowptr, items), ALL, K)
+    rows = torch.zeros((B, 5 * K), dtype=torch.float32, device=dev())
+    sums = torch.zeros(5 * K, dtype=torch.float64, device=dev())
+    d_ids, d_ptr, d_items = to_dev(ids), to_dev(rowptr), to_dev(items)
+    _hip.check(_hip.lib().skr_rank_metrics(_hip.ptr(d_ids), B, K, None, _hip.ptr(d_ptr), _hip.ptr(d_items),
+                                           _hip.metric_array(ALL), 5, _hip.ptr(rows), _hip.ptr(sums), _hip.stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(rows.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    np.testing.assert_allclose(sums.cpu().numpy(), want.astype(np.float64).sum(0), rtol=1e-12)
+
+
+def _fused_reference(Ut, users, It, bias, rowptr, items, K):
+    """fp64 scores + a 'safe' mask: rows whose K-th and (K+1)-th scores are closer than fp32 summation
+    noise cannot be compared id-for-id (top-K ties)"""
+    sc = Ut[users].astype(np.float64) @ It.astype(np.float64).T
+    if bias is not None:
+        sc = sc + bias.astype(np.float64)
+    for r, u in enumerate(users):
+        sc[r, items[rowptr[u]:rowptr[u + 1]]] = -np.inf
+    order = np.argsort(-sc, axis=1, kind="stable")[:, :K + 1]
+    top = np.take_along_axis(sc, order, 1)
+    gaps = -np.diff(top, axis=1)                    # gaps between consecutive ranks 1..K+1
+    scale = np.abs(top[:, :1]) + 1.0
+    safe = gaps.min(axis=1) > 64 * 2.0 ** -24 * scale[:, 0] * 8
+    return order[:, :K], top[:, :K], safe
+
+
+@pytest.mark.parametrize("B,I,K,with_bias,with_mask", [(1, 40, 5, True, True), (64, 32, 10, False, True),
+                                                       (65, 1000, 20, True, True), (200, 5000, 50, True, False),
+                                                       (130, 33, 3, False, True), (300, 20011, 128, True, True),
+                                                       (1000, 3000, 10, False, True)])
+def test_fused_topk_vs_fp64(B, I, K, with_bias, with_mask):
+    from gpu_utils import fused_topk
+    rng = np.random.default_rng(B + I + K)
+    nU = B + 17
+    Ut = (rng.standard_normal((nU, 64)) * 0.3).astype(np.float32)
+    It = (rng.standard_normal((I, 64)) * 0.3).astype(np.float32)
+    bias = (rng.standard_normal(I) * 0.1).astype(np.float32) if with_bias else None
+    users = rng.permutation(nU)[:B].astype(np.int32)
+    max_tr = max(0, min(I - K, 120))
+    rowptr, items = random_csr(rng, nU, I, 0, max_tr) if with_mask else (None, np.zeros(0, np.int32))
+    ids, sc = fused_topk(Ut, users, It, bias, rowptr, items, K)
+    rp = rowptr if with_mask else np.zeros(nU + 1, np.int64)
+    want_ids, want_sc, safe = _fused_reference(Ut, users, It, bias, rp, items, K)
+    assert safe.mean() > 0.5
+    assert np.array_equal(ids[safe], want_ids[safe]), np.flatnonzero((ids != want_ids).any(1) & safe)[:5]
+    np.testing.assert_allclose(sc[safe], want_sc[safe], rtol=2e-5, atol=2e-6)
+    # every row, safe or not: a valid ranking of unmasked items, sorted, and the same SET up to near-ties
+    for r in range(B):
+        assert len(set(ids[r])) == K and ids[r].min() >= 0 and ids[r].max() < I
+        assert np.all(np.diff(sc[r]) <= 0)
+        if with_mask:
+            u = users[r]
+            assert not np.isin(ids[r], items[rp[u]:rp[u + 1]]).any()
+
+
+def test_fused_exact_on_integer_scores():
+    """integer-valued factors make every fp32 dot product exact, so ids AND scores must match the
+    oracle's ranking bit for bit, ties included (lower id first)"""
+    from gpu_utils import fused_topk
+    rng = np.random.default_rng(4)
+    B, I, K = 96, 777, 12
+    Ut = rng.integers(-3, 4, (B, 64)).astype(np.float32)
+    It = rng.integers(-3, 4, (I, 64)).astype(np.float32)
+    bias = rng.integers(-5, 6, I).astype(np.float32)
+    rowptr, items = random_csr(rng, B, I, 0, 100)
+    ids, sc = fused_topk(Ut, np.arange(B, dtype=np.int32), It, bias, rowptr, items, K)
+    full = Ut @ It.T + bias
+    for r in range(B):
+        full[r, items[rowptr[r]:rowptr[r + 1]]] = -np.inf
+        want = O.topk_ids_lowid(full[r], K)
+        assert np.array_equal(ids[r], want)
+        assert np.array_equal(sc[r], full[r, want])
+
+
+def test_ranking_evaluator_end_to_end(golden):
+    """RankingEvaluator (generic predict() contract) == the reference's MetricReport values"""
+    from skrec.utils.py import RankingEvaluator
+    e = golden("golden_eval")
+    d = golden("tiny_dataset")
+    trd, ted = {}, {}
+    for u, i, _ in d["train"]:
+        trd.setdefault(int(u), []).append(int(i))
+    for u, i, _ in d["test"]:
+        ted.setdefault(int(u), []).append(int(i))
+    trd = {u: np.int32(v) for u, v in sorted(trd.items())}
+    ted = {u: np.int32(v) for u, v in sorted(ted.items())}
+    table = e["e2e_table"]
+
+    class Fixed:
+        def predict(self, users):
+            return table[np.asarray(users)].copy()
+    for tag, metric, top_k, bs in (("a", None, (5, 10, 20), 16), ("b", ["Recall", "NDCG"], 7, 64), ("c", "MRR", [3], 5)):
+        ev = RankingEvaluator(trd, ted, metric=metric, top_k=top_k, batch_size=bs, num_thread=2)
+        rep = ev.evaluate(Fixed())
+        assert list(rep.metrics()) == list(e[f"e2e_{tag}_names"])
+        got = np.array(list(rep.values()), np.float32)
+        assert np.array_equal(got.view(np.uint32), e[f"e2e_{tag}_values"].view(np.uint32)), tag
+        rep2 = ev.evaluate(Fixed(), test_users=list(e["e2e_sub_users"]))
+        got2 = np.array(list(rep2.values()), np.float32)
+        assert np.array_equal(got2.view(np.uint32), e[f"e2e_{tag}_sub_values"].view(np.uint32))
+    with pytest.raises(AssertionError):
+        ev.evaluate(object())

@@ -1,0 +1,127 @@
+"""GPU parity, end to end: the three in-scope recommenders, constructed and fitted through the
+reference's own API (RunConfig + model dict + fit()), replay the reference's recorded trajectories:
+identical initial weights, per-step losses within 1e-5 relative, per-epoch MetricReports equal to
+the reference's (bit-equal ranking rows => bit-equal float32 means, up to rare near-tie flips that
+the 1e-5 tolerance absorbs), final weights within fp32 noise."""
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+SEED = 2021
+
+
+def _seed():
+    import random
+    import torch
+    np.random.seed(SEED)
+    random.seed(SEED)
+    torch.manual_seed(SEED)
+
+
+def _run_config(tiny_dir, name):
+    from skrec import RunConfig
+    return RunConfig(recommender=name, data_dir=tiny_dir, file_column="UIRT", sep="\t", hyperopt=False, gpu_id=0,
+                     metric=("Precision", "Recall", "MAP", "NDCG", "MRR"), top_k=(5, 10, 20), test_batch_size=16,
+                     test_thread=2, seed=SEED)
+
+
+def _fit_and_record(model):
+    reports, losses = [], []
+    ev, te = model.evaluate, model.train_epoch
+
+    def evaluate(test_users=None):
+        r = ev(test_users)
+        reports.append(np.array(list(r.values()), np.float32))
+        return r
+
+    def train_epoch(it):
+        te(it)
+        losses.append(model.step_losses.cpu().numpy().copy())
+    model.evaluate, model.train_epoch = evaluate, train_epoch
+    best = model.fit()
+    return np.stack(reports), np.concatenate(losses, 0), np.array(list(best.values()), np.float32)
+
+
+def _check_reports(got, want, names):
+    assert got.shape == want.shape
+    # per-user rows are bit-exact unless fp32 summation order flips a near-tie at the K boundary
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-4, err_msg=str(names))
+
+
+def test_bprmf_replays_reference(golden, tiny_dir, monkeypatch, tmp_path):
+    from skrec.recommender.BPRMF import BPRMF
+    from skrec.utils.py.random import reset_global_sampler
+    monkeypatch.chdir(tmp_path)
+    g = golden("golden_bprmf")
+    reset_global_sampler(2020)
+    _seed()
+    m = BPRMF(_run_config(tiny_dir, "BPRMF"), dict(lr=1e-3, reg=1e-3, n_dim=64, batch_size=256, epochs=3))
+    assert np.array_equal(m.user_embeddings.cpu().numpy(), g["U0"])      # same init under the same seed
+    assert np.array_equal(m.item_embeddings.cpu().numpy(), g["V0"])
+    assert list(m.evaluator.metrics_list) == list(g["names"])
+    reports, losses, best = _fit_and_record(m)
+    np.testing.assert_allclose(losses[:, 0], g["bpr_sum"], rtol=1e-5)
+    np.testing.assert_allclose(losses[:, 1], g["l2"], rtol=1e-5)
+    _check_reports(reports, g["reports"], g["names"])
+    _check_reports(best[None], g["best"][None], g["names"])
+    np.testing.assert_allclose(m.user_embeddings.cpu().numpy(), g["U1"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(m.item_embeddings.cpu().numpy(), g["V1"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(m.item_biases.cpu().numpy(), g["b1"].reshape(-1), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(m.predict(list(g["pred_users"])), g["pred"], rtol=1e-4, atol=1e-6)
+
+
+def test_lightgcn_replays_reference(golden, tiny_dir, monkeypatch, tmp_path):
+    from skrec.recommender.LightGCN import LightGCN
+    from skrec.utils.py.random import reset_global_sampler
+    monkeypatch.chdir(tmp_path)
+    g = golden("golden_lightgcn")
+    reset_global_sampler(2020)
+    _seed()
+    m = LightGCN(_run_config(tiny_dir, "LightGCN"),
+                 dict(lr=1e-3, reg=1e-3, embed_size=64, n_layers=3, adj_type="pre", batch_size=256, epochs=2))
+    assert np.array_equal(m.user_embeddings.cpu().numpy(), g["U0"])
+    # adjacency: same sparsity pattern and values as the reference's coalesced COO tensor
+    rp, col, val = (t.cpu().numpy() for t in (m.adj.rowptr, m.adj.col, m.adj.val))
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    assert np.array_equal(rows, g["adj_idx"][0]) and np.array_equal(col, g["adj_idx"][1])
+    np.testing.assert_allclose(val, g["adj_val"], rtol=1e-6)
+    for t in ("plain", "norm", "gcmc"):
+        a = m._create_adj_mat(t).tocoo()
+        order = np.lexsort((a.col, a.row))
+        assert np.array_equal(np.stack([a.row[order], a.col[order]]), g[f"adj_{t}_idx"])
+        np.testing.assert_allclose(a.data[order], g[f"adj_{t}_val"], rtol=1e-6)
+    reports, losses, best = _fit_and_record(m)
+    np.testing.assert_allclose(losses[:, 0], g["bpr_mean"], rtol=1e-5)
+    np.testing.assert_allclose(losses[:, 1], g["l2"], rtol=1e-5)
+    _check_reports(reports, g["reports"], g["names"])
+    np.testing.assert_allclose(m.user_embeddings.cpu().numpy(), g["U1"], rtol=0, atol=3e-6)
+    m.eval()
+    uf, vf, _ = m.predict_factors()
+    np.testing.assert_allclose(uf.cpu().numpy(), g["Uf"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(vf.cpu().numpy(), g["Vf"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(m.predict(list(g["pred_users"])), g["pred"], rtol=1e-4, atol=2e-6)
+
+
+def test_layergcn_replays_reference(golden, tiny_dir, monkeypatch, tmp_path):
+    from skrec.recommender.LayerGCN import LayerGCN
+    from skrec.utils.py.random import reset_global_sampler
+    monkeypatch.chdir(tmp_path)
+    g = golden("golden_layergcn")
+    reset_global_sampler(2020)
+    _seed()
+    m = LayerGCN(_run_config(tiny_dir, "LayerGCN"),
+                 dict(lr=1e-3, reg=1e-2, embed_dim=64, n_layers=4, dropout=0.0, batch_size=256, epochs=2))
+    assert np.array_equal(m.user_embeddings.cpu().numpy(), g["U0"])
+    rp, col, val = (t.cpu().numpy() for t in (m.adj.rowptr, m.adj.col, m.adj.val))
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    assert np.array_equal(rows, g["adj_idx"][0]) and np.array_equal(col, g["adj_idx"][1])
+    np.testing.assert_allclose(val, g["adj_val"], rtol=1e-6)
+    reports, losses, best = _fit_and_record(m)
+    total = losses[:, 0] + np.float32(1e-2) * losses[:, 1]
+    np.testing.assert_allclose(total, g["loss"], rtol=1e-5)
+    _check_reports(reports, g["reports"], g["names"])
+    np.testing.assert_allclose(m.user_embeddings.cpu().numpy(), g["U1"], rtol=0, atol=3e-6)
+    m.forward()
+    np.testing.assert_allclose(m.out[:m.num_users].cpu().numpy(), g["Uf"], rtol=0, atol=6e-6)
+    with pytest.raises(NotImplementedError):
+        LayerGCN(_run_config(tiny_dir, "LayerGCN"), dict(dropout=0.1))

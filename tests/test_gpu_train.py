@@ -1,0 +1,155 @@
+"""GPU parity, T rows: skr_bpr_step, skr_adam_step, skr_csr_spmm, skr_layer_refine_* against the
+oracle's explicit-gradient maths (itself pinned to the reference trajectories) and torch-CPU fp32."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as O
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+
+def _close(a, b, rtol=1e-5, atol=1e-6):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("n,with_bias,split", [(1, True, False), (257, True, False), (1024, False, True), (3000, True, True)])
+def test_bpr_step_vs_oracle(n, with_bias, split):
+    import torch
+    from gpu_utils import to_dev, dev
+    from skrec import _hip
+    rng = np.random.default_rng(n)
+    nU, nI = 300, 200
+    P = (rng.standard_normal((nU, 64)) * 0.3).astype(np.float32)
+    Q = (rng.standard_normal((nI, 64)) * 0.3).astype(np.float32)
+    bias = (rng.standard_normal(nI) * 0.2).astype(np.float32) if with_bias else None
+    RP = (rng.standard_normal((nU, 64)) * 0.3).astype(np.float32) if split else P
+    RQ = (rng.standard_normal((nI, 64)) * 0.3).astype(np.float32) if split else Q
+    u = rng.integers(0, nU, n).astype(np.int32)
+    i = rng.integers(0, nI, n).astype(np.int32)
+    j = rng.integers(0, nI, n).astype(np.int32)
+    ls, reg, rs = (1.0 / n, 1e-3, 1.0 / 1024) if split else (1.0, 1e-3, 1.0)
+    loss, l2, gP, gQ, gb, gRP, gRQ = O.bpr_batch(P, Q, bias, RP, RQ, u, i, j, ls, reg, rs)
+    dP, dQ, dRP, dRQ = to_dev(P), to_dev(Q), to_dev(RP), to_dev(RQ)
+    db = to_dev(bias) if with_bias else None
+    z = lambda a: torch.zeros_like(to_dev(a))  # noqa: E731
+    ggP, ggQ = z(P), z(Q)
+    ggRP, ggRQ = (z(RP), z(RQ)) if split else (ggP, ggQ)
+    ggb = z(bias) if with_bias else None
+    dl = torch.zeros(2, dtype=torch.float32, device=dev())
+    _hip.check(_hip.lib().skr_bpr_step(_hip.ptr(dP), _hip.ptr(dQ), _hip.ptr(db), _hip.ptr(dRP if split else dP),
+                                       _hip.ptr(dRQ if split else dQ), _hip.ptr(to_dev(u)), _hip.ptr(to_dev(i)),
+                                       _hip.ptr(to_dev(j)), n, ls, reg, rs, _hip.ptr(ggP), _hip.ptr(ggQ), _hip.ptr(ggb),
+                                       _hip.ptr(ggRP), _hip.ptr(ggRQ), _hip.ptr(dl), _hip.stream()))
+    torch.cuda.synchronize()
+    got = dl.cpu().numpy()
+    assert abs(got[0] - loss) <= 1e-5 * abs(loss) and abs(got[1] - l2) <= 1e-5 * abs(l2)
+    _close(ggP.cpu().numpy(), gP)
+    _close(ggQ.cpu().numpy(), gQ)
+    if split:
+        _close(ggRP.cpu().numpy(), gRP)
+        _close(ggRQ.cpu().numpy(), gRQ)
+    if with_bias:
+        _close(ggb.cpu().numpy(), gb)
+
+
+def test_adam_matches_torch_cpu():
+    import torch
+    from gpu_utils import to_dev
+    from skrec import _hip
+    rng = np.random.default_rng(0)
+    n = 64 * 1000 + 3
+    p0 = rng.standard_normal(n).astype(np.float32)
+    pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([pt], lr=1e-3)
+    dp, dm, dv = to_dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for t in range(1, 6):
+        g = (rng.standard_normal(n) * (rng.random(n) < 0.3)).astype(np.float32)  # mostly-zero grads, dense update
+        pt.grad = torch.from_numpy(g.copy())
+        opt.step()
+        dg = to_dev(g)
+        _hip.check(_hip.lib().skr_adam_step(_hip.ptr(dp), _hip.ptr(dg), _hip.ptr(dm), _hip.ptr(dv), n, 1e-3, 0.9, 0.999,
+                                            1e-8, t, 1, _hip.stream()))
+        torch.cuda.synchronize()
+        assert float(dg.abs().max()) == 0.0  # zero_grad fused
+        _close(dp.cpu().numpy(), pt.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_rows,density,heavy", [(50, 0.2, 0), (3000, 0.004, 2), (20000, 0.0005, 3)])
+def test_csr_spmm_vs_scipy(n_rows, density, heavy):
+    import torch
+    from gpu_utils import dev
+    from skrec.recommender.LightGCN import DeviceCSR
+    rng = np.random.default_rng(n_rows)
+    A = sp.random(n_rows, n_rows, density=density, format="lil", random_state=rng, dtype=np.float32)
+    for h in range(heavy):  # rows far longer than one 512-nnz chunk -> split rows + atomics
+        cols = rng.choice(n_rows, min(n_rows, 2000 + 700 * h), replace=False)
+        A[h * 7, cols] = rng.standard_normal(len(cols)).astype(np.float32)
+    A = sp.csr_matrix(A)
+    A[n_rows // 2, :] = 0  # an empty row
+    A.eliminate_zeros()
+    X = rng.standard_normal((n_rows, 64)).astype(np.float32)
+    add = rng.standard_normal((n_rows, 64)).astype(np.float32)
+    acc0 = rng.standard_normal((n_rows, 64)).astype(np.float32)
+    csr = DeviceCSR(A, dev())
+    dX, dadd, dacc = (torch.from_numpy(a).to(dev()) for a in (X, add, acc0.copy()))
+    Y = torch.full((n_rows, 64), 7.0, device=dev())
+    csr.spmm(dX, Y)
+    torch.cuda.synchronize()
+    want = (A @ X).astype(np.float32)
+    _close(Y.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+    csr.spmm(dX, Y, addend=dadd, accum=dacc, accum_scale=0.25)
+    torch.cuda.synchronize()
+    _close(Y.cpu().numpy(), want + add, rtol=2e-5, atol=2e-5)
+    _close(dacc.cpu().numpy(), acc0 + 0.25 * (want + add), rtol=2e-5, atol=2e-5)
+
+
+def test_layer_refine_fwd_bwd_vs_torch_autograd():
+    import torch
+    from gpu_utils import to_dev, dev
+    from skrec import _hip
+    rng = np.random.default_rng(1)
+    n = 777
+    Y = rng.standard_normal((n, 64)).astype(np.float32)
+    E = rng.standard_normal((n, 64)).astype(np.float32)
+    Y[5] = 0.0  # zero-degree node: propagated row is exactly zero
+    dZ = rng.standard_normal((n, 64)).astype(np.float32)
+    ty, te = torch.tensor(Y, requires_grad=True), torch.tensor(E, requires_grad=True)
+    w = torch.nn.functional.cosine_similarity(ty, te, dim=-1)
+    z = torch.einsum("a,ab->ab", w, ty)
+    z.backward(torch.from_numpy(dZ))
+    dY_, dE_, dZ_ = to_dev(Y), to_dev(E), to_dev(dZ)
+    Z = torch.zeros((n, 64), device=dev())
+    W = torch.zeros(n, device=dev())
+    acc = torch.ones((n, 64), device=dev())
+    L, st = _hip.lib(), _hip.stream()
+    _hip.check(L.skr_layer_refine_fwd(_hip.ptr(dY_), _hip.ptr(dE_), n, 64, _hip.ptr(Z), _hip.ptr(W), _hip.ptr(acc), st))
+    gY = torch.zeros((n, 64), device=dev())
+    gE = torch.full((n, 64), 2.0, device=dev())
+    _hip.check(L.skr_layer_refine_bwd(_hip.ptr(dY_), _hip.ptr(dE_), _hip.ptr(W), _hip.ptr(dZ_), n, 64, _hip.ptr(gY),
+                                      _hip.ptr(gE), st))
+    torch.cuda.synchronize()
+    _close(W.cpu().numpy(), w.detach().numpy(), rtol=1e-5, atol=1e-6)
+    _close(Z.cpu().numpy(), z.detach().numpy(), rtol=1e-5, atol=1e-6)
+    _close(acc.cpu().numpy(), 1.0 + z.detach().numpy(), rtol=1e-5, atol=1e-6)
+    _close(gY.cpu().numpy(), ty.grad.numpy(), rtol=2e-5, atol=2e-6)
+    _close(gE.cpu().numpy(), 2.0 + te.grad.numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_gather_axpy_scale():
+    import torch
+    from gpu_utils import to_dev, dev
+    from skrec import _hip
+    rng = np.random.default_rng(2)
+    T = rng.standard_normal((100, 64)).astype(np.float32)
+    idx = rng.integers(0, 100, 333).astype(np.int32)
+    out = torch.zeros((333, 64), device=dev())
+    L, st = _hip.lib(), _hip.stream()
+    dT = to_dev(T)
+    _hip.check(L.skr_gather_rows(_hip.ptr(dT), _hip.ptr(to_dev(idx)), 333, 64, _hip.ptr(out), st))
+    y = to_dev(T.copy())
+    _hip.check(L.skr_axpy(0.5, _hip.ptr(dT), _hip.ptr(y), T.size, st))
+    _hip.check(L.skr_scale(3.0, _hip.ptr(y), T.size, st))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), T[idx])
+    _close(y.cpu().numpy(), (T + np.float32(0.5) * T) * np.float32(3.0), rtol=1e-6)

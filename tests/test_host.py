@@ -1,0 +1,127 @@
+"""CPU suite, part 3: host-side mirror of the reference interface (no GPU): configs, registry,
+dataset views, batch iterator contracts, evaluator bookkeeping."""
+import sys
+
+import numpy as np
+import pytest
+
+import skrec
+from skrec import RunConfig, ModelRegistry, merge_config_with_cmd_args
+from skrec.io import RSDataset
+from skrec.utils.py import BatchIterator, MetricReport, EarlyStopping, RankingEvaluator
+from helpers import tiny_arrays
+
+
+def test_public_api_surface():
+    for name in ("RunConfig", "ModelRegistry", "merge_config_with_cmd_args", "PairwiseIterator", "PointwiseIterator",
+                 "RankingEvaluator", "MetricReport", "EarlyStopping", "randint_choice", "batch_randint_choice",
+                 "BatchIterator", "RSDataset", "ImplicitFeedback", "Config", "ModelConfig"):
+        assert hasattr(skrec, name), name
+    from skrec.io import PairwiseSampler, PointwiseSampler, PairwiseIterator, PointwiseIterator
+    assert PairwiseSampler is PairwiseIterator and PointwiseSampler is PointwiseIterator
+    from skrec.utils.hyperopt import HyperOpt  # noqa: F401  (importable without the hyperopt package)
+
+
+def test_run_config_defaults_and_validation():
+    rc = RunConfig()
+    assert rc.test_batch_size == 64 and rc.test_thread == 4 and rc.seed == 2021 and rc.top_k[-1] == 100
+    assert list(dict(rc.items()))[:3] == ["recommender", "data_dir", "file_column"]
+    with pytest.raises(AssertionError):
+        RunConfig(test_batch_size=0)
+    assert RunConfig(foo=1).recommender == "BPRMF"  # unknown keys are swallowed like the reference
+
+
+def test_cmd_arg_merge(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["x", "--lr", "1e-2", "--top_k", "[10,20]", "--recommender", "LightGCN",
+                                      "--hyperopt", "false", "--data_dir", "dataset/a_b"])
+    d = merge_config_with_cmd_args({"lr": 1e-3})
+    assert d == {"lr": 0.01, "top_k": [10, 20], "recommender": "LightGCN", "hyperopt": False, "data_dir": "dataset/a_b"}
+    monkeypatch.setattr(sys, "argv", ["x", "--lr"])
+    with pytest.raises(SyntaxError):
+        merge_config_with_cmd_args({})
+    monkeypatch.setattr(sys, "argv", ["x", "lr", "1"])
+    with pytest.raises(SyntaxError):
+        merge_config_with_cmd_args({})
+
+
+def test_registry_and_model_configs():
+    reg = ModelRegistry()
+    for name in ("BPRMF", "LightGCN", "LayerGCN"):
+        assert reg.load_skrec_model(name)
+        model, cfg = reg.get_model(name)
+        assert model.__name__ == name and cfg.__name__ == name + "Config"
+    assert not reg.load_skrec_model("NoSuchModel")
+    from skrec.recommender.BPRMF import BPRMFConfig
+    from skrec.recommender.LightGCN import LightGCNConfig
+    from skrec.recommender.LayerGCN import LayerGCNConfig
+    b, l, y = BPRMFConfig(), LightGCNConfig(), LayerGCNConfig()
+    assert (b.lr, b.reg, b.n_dim, b.batch_size, b.epochs, b.early_stop) == (1e-3, 1e-3, 64, 1024, 1000, 200)
+    assert (l.n_layers, l.adj_type, l.early_stop) == (3, "pre", 100)
+    assert (y.reg, y.n_layers, y.batch_size, y.dropout) == (1e-2, 4, 2048, 0.0)
+    assert BPRMFConfig.num_combos() == 20
+    with pytest.raises(AssertionError):
+        LightGCNConfig(adj_type="bogus")
+
+
+def test_dataset_views(tiny_dir, golden):
+    ds = RSDataset(tiny_dir, "\t", "UIRT")
+    U, I, rowptr, pos, srt, uary = tiny_arrays(golden)
+    assert (ds.num_users, ds.num_items) == (U, I) and ds.data_name == "tiny"
+    rp, fo, so = ds.train_data.to_csr_arrays()
+    assert np.array_equal(rp, rowptr) and np.array_equal(fo, pos) and np.array_equal(so, srt)
+    ud = ds.train_data.to_user_dict()
+    assert list(ud) == sorted(ud) and 63 not in ud and all(v.dtype == np.int32 for v in ud.values())
+    assert np.array_equal(np.concatenate(list(ud.values())), pos)
+    pairs = ds.train_data.to_user_item_pairs()
+    assert pairs.dtype == np.int32 and pairs.shape == (len(pos), 2)
+    assert ds.train_data.to_coo_matrix().shape == (U, I)
+    assert 5 not in ds.test_data.to_user_dict() and 63 in ds.test_data.to_user_dict()
+    with pytest.raises(FileNotFoundError):
+        RSDataset(tiny_dir + "_missing", "\t", "UIRT").num_users
+
+
+def test_batch_iterator_contract():
+    users, items = list(range(10)), list(range(10, 20))
+    out = list(BatchIterator(users, items, batch_size=4, shuffle=False))
+    assert [len(b[0]) for b in out] == [4, 4, 2] and out[2][1] == [18, 19]
+    assert len(BatchIterator(users, batch_size=4, drop_last=True)) == 2
+    np.random.seed(3)
+    shuffled = [x for b in BatchIterator(users, batch_size=3, shuffle=True) for x in b]
+    np.random.seed(3)
+    assert shuffled == np.random.permutation(10).tolist()
+    with pytest.raises(ValueError):
+        BatchIterator([1, 2], [1], batch_size=1)
+
+
+def test_metric_report_and_early_stopping():
+    r1 = MetricReport(["NDCG@10", "Recall@10"], np.float32([0.2, 0.1]))
+    assert r1.values_str.split("\t")[0].strip() == "0.20000000"
+    with pytest.raises(KeyError):
+        r1["HR@10"]
+    es = EarlyStopping("NDCG@10", patience=2)
+    assert not es(r1)
+    worse = MetricReport(["NDCG@10", "Recall@10"], np.float32([0.1, 0.3]))
+    assert not es(worse) and es(worse) and es.best_result is r1
+    never = EarlyStopping("NDCG@10", patience=0)
+    assert not any(never(worse) for _ in range(5))
+
+
+def test_evaluator_bookkeeping():
+    ev = RankingEvaluator({0: np.int32([1])}, {0: np.int32([2])}, metric=["Recall", "NDCG"], top_k=[20, 10])
+    assert ev.metrics_list == ["Recall@10", "Recall@20", "NDCG@10", "NDCG@20"] and ev.max_top == 20
+    assert RankingEvaluator(None, {0: [1]}, metric="MRR", top_k=3).metrics_list == ["MRR@1", "MRR@2", "MRR@3"]
+    with pytest.raises(AssertionError):
+        RankingEvaluator(None, {0: [1]}, metric=["HR"])
+    with pytest.raises(AssertionError):
+        RankingEvaluator(None, {})
+    with pytest.raises(NotImplementedError):
+        RankingEvaluator(None, {0: [1]}, top_k=500)
+
+
+def test_hot_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from skrec import _hip
+    with pytest.raises(_hip.HipError):
+        skrec.randint_choice(10, 3)
