@@ -80,8 +80,9 @@ def test_rank_metrics_vs_oracle():
 
 
 def _fused_reference(Ut, users, It, bias, rowptr, items, K):
-    """fp64 scores + a 'safe' mask: rows whose K-th and (K+1)-th scores are closer than fp32 summation
-    noise cannot be compared id-for-id (top-K ties)"""
+    """fp64 scores, ranks 1..K+1 and the gaps between consecutive ranks.  fp32 summation order may
+    swap two items whose fp64 scores are closer than the fp32 dot-product noise, so ids are compared
+    only where the neighbouring gaps are clear of it (top-K ties)."""
     sc = Ut[users].astype(np.float64) @ It.astype(np.float64).T
     if bias is not None:
         sc = sc + bias.astype(np.float64)
@@ -89,10 +90,11 @@ def _fused_reference(Ut, users, It, bias, rowptr, items, K):
         sc[r, items[rowptr[u]:rowptr[u + 1]]] = -np.inf
     order = np.argsort(-sc, axis=1, kind="stable")[:, :K + 1]
     top = np.take_along_axis(sc, order, 1)
-    gaps = -np.diff(top, axis=1)                    # gaps between consecutive ranks 1..K+1
-    scale = np.abs(top[:, :1]) + 1.0
-    safe = gaps.min(axis=1) > 64 * 2.0 ** -24 * scale[:, 0] * 8
-    return order[:, :K], top[:, :K], safe
+    gaps = -np.diff(top, axis=1)                    # gaps[:, p] = score(rank p) - score(rank p+1)
+    return order[:, :K], top[:, :K], gaps
+
+
+NOISE = 2e-5  # >> 64 * 2^-24 * sum|a*b| for the factor scales used here
 
 
 @pytest.mark.parametrize("B,I,K,with_bias,with_mask", [(1, 40, 5, True, True), (64, 32, 10, False, True),
@@ -111,11 +113,19 @@ def test_fused_topk_vs_fp64(B, I, K, with_bias, with_mask):
     rowptr, items = random_csr(rng, nU, I, 0, max_tr) if with_mask else (None, np.zeros(0, np.int32))
     ids, sc = fused_topk(Ut, users, It, bias, rowptr, items, K)
     rp = rowptr if with_mask else np.zeros(nU + 1, np.int64)
-    want_ids, want_sc, safe = _fused_reference(Ut, users, It, bias, rp, items, K)
-    assert safe.mean() > 0.5
-    assert np.array_equal(ids[safe], want_ids[safe]), np.flatnonzero((ids != want_ids).any(1) & safe)[:5]
-    np.testing.assert_allclose(sc[safe], want_sc[safe], rtol=2e-5, atol=2e-6)
-    # every row, safe or not: a valid ranking of unmasked items, sorted, and the same SET up to near-ties
+    want_ids, want_sc, gaps = _fused_reference(Ut, users, It, bias, rp, items, K)
+    clear = gaps > NOISE
+    # rank p is comparable id-for-id when the gaps above and below it are clear
+    pos_ok = clear[:, 1:] if K == 1 else np.concatenate([clear[:, :1], clear[:, :-1] & clear[:, 1:]], axis=1)[:, :K]
+    pos_ok[:, 0] = clear[:, 0]
+    assert pos_ok.mean() > 0.6
+    assert np.array_equal(ids[pos_ok], want_ids[pos_ok])
+    set_ok = clear[:, K - 1]                        # the K / K+1 boundary decides the id SET
+    assert set_ok.mean() > 0.6
+    for r in np.flatnonzero(set_ok):
+        assert set(ids[r]) == set(want_ids[r]), r
+    np.testing.assert_allclose(np.sort(sc, axis=1), np.sort(want_sc, axis=1), rtol=2e-5, atol=2e-5)
+    # every row: a valid ranking of distinct unmasked items, scores descending
     for r in range(B):
         assert len(set(ids[r])) == K and ids[r].min() >= 0 and ids[r].max() < I
         assert np.all(np.diff(sc[r]) <= 0)
