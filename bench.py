@@ -1,0 +1,299 @@
+"""bench.py -- the hot path of BASELINE.json configs[1] on N MI355X:
+
+    BPRMF d=64, synthetic MovieLens-shaped 1M users / 100K items / ~50M interactions,
+    exact-stream negative sampling + fused BPR step + dense Adam (train), fused MFMA top-K (eval).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one mini-batch of 1024 interactions per rank through the whole training path: its share
+of the epoch's negative sampling (the sampler call that produces exactly the negatives these K steps
+consume sits INSIDE the timed region), skr_bpr_step, the item-gradient all-reduce (N > 1), and
+ONE skr_adam_step over every parameter of the flat [U|V|b] buffer (the reference's dense-Adam semantics).  Users are
+sharded u % N; the item table and bias are replicated and kept identical by one RCCL all-reduce of
+their gradients per step.  The dataset is fixed (strong scaling); the global batch is 1024*N.
+Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "scikit-recommender_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak (spec)
+D = 64
+
+
+def synth_dataset(n_users, n_items, n_inter, seed, dev):
+    """MovieLens-shaped implicit feedback, generated on the device: Zipf(0.9) item popularity over a
+    random item permutation, log-normal user activity clipped to [20, I/2], items without replacement
+    per user, one held-out item per user (leave-one-out => Recall@K == HR@K)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    act = torch.exp(torch.randn(n_users, generator=g, device=dev) * 0.6)
+    act = act / act.sum() * (n_inter + n_users) * 1.04     # ~4 % is lost to de-duplication below
+    act = act.clamp(20, n_items // 2).round().long()
+    pop = 1.0 / torch.arange(1, n_items + 1, device=dev, dtype=torch.float32) ** 0.9
+    pop = pop[torch.randperm(n_items, generator=g, device=dev)]
+    total = int(act.sum())
+    owner = torch.repeat_interleave(torch.arange(n_users, device=dev), act)
+    items = torch.empty(total, dtype=torch.long, device=dev)
+    chunk = 1 << 24
+    for s in range(0, total, chunk):
+        items[s:s + chunk] = torch.multinomial(pop, min(chunk, total - s), replacement=True, generator=g)
+    key = torch.unique(owner * n_items + items)            # sorted by (user, item), duplicates dropped
+    del owner, items
+    u = key // n_items
+    it = (key % n_items).int()
+    counts = torch.bincount(u, minlength=n_users)
+    rowptr = torch.zeros(n_users + 1, dtype=torch.long, device=dev)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    # hold one interaction per user out (position hashed from the user id)
+    pick = rowptr[:-1] + (torch.arange(n_users, device=dev) * 2654435761 % counts.clamp(min=1))
+    test_item = it[pick].clone()
+    keep = torch.ones(len(it), dtype=torch.bool, device=dev)
+    keep[pick] = False
+    u, it = u[keep].int(), it[keep]
+    counts = counts - 1
+    rowptr = torch.zeros(n_users + 1, dtype=torch.long, device=dev)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return dict(rowptr=rowptr, users=u.contiguous(), items=it.contiguous(), test_item=test_item.contiguous())
+
+
+def shard(ds, rank, world, dev):
+    """users u % world == rank, re-indexed 0..U_local-1 (their global id is local*world + rank)"""
+    if world == 1:
+        return ds, torch.arange(len(ds["rowptr"]) - 1, device=dev, dtype=torch.int32)
+    n_users = len(ds["rowptr"]) - 1
+    mine = torch.arange(rank, n_users, world, device=dev)
+    lens = (ds["rowptr"][1:] - ds["rowptr"][:-1])[mine]
+    rowptr = torch.zeros(len(mine) + 1, dtype=torch.long, device=dev)
+    rowptr[1:] = torch.cumsum(lens, 0)
+    sel = (ds["users"].long() % world) == rank
+    return dict(rowptr=rowptr, users=(ds["users"][sel] // world).int().contiguous(), items=ds["items"][sel].contiguous(),
+                test_item=ds["test_item"][mine].contiguous()), mine.int()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--items", type=int, default=100_000)
+    ap.add_argument("--interactions", type=int, default=50_000_000)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--eval-users", type=int, default=65536)
+    ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from skrec import _hip
+    from skrec.utils.py.random import DeviceSampler
+    L = _hip.lib()
+    st = _hip.stream
+
+    full = synth_dataset(args.users, args.items, args.interactions, 20260101, dev)
+    n_inter_total = int(full["rowptr"][-1])
+    ds, _ = shard(full, rank, world, dev)
+    if world > 1:
+        del full
+    nU, nI = len(ds["rowptr"]) - 1, args.items
+    b, K, W = args.batch, args.steps, args.warmup
+
+    # ---- model state: the reference's BPRMF tables + dense Adam ----------------------------------
+    # one flat buffer [U | V | b] (tables are views) => ONE adam launch per step, as in skrec.recommender.BPRMF
+    n_par = nU * D + nI * D + nI
+    flat = torch.zeros(n_par, device=dev)
+    U, V, bias = flat[:nU * D].view(nU, D), flat[nU * D:(nU + nI) * D].view(nI, D), flat[(nU + nI) * D:]
+    U.copy_(torch.randn(nU, D, generator=torch.Generator().manual_seed(2021 + rank)) * 0.01)
+    V.copy_(torch.randn(nI, D, generator=torch.Generator().manual_seed(7)) * 0.01)   # identical on every rank
+    grad, m1, m2 = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
+    gU, gV, gb = grad[:nU * D].view(nU, D), grad[nU * D:(nU + nI) * D].view(nI, D), grad[(nU + nI) * D:]
+    g_item = grad[nU * D:]                                  # [V | b] gradients: the all-reduced part
+    touch = torch.zeros((n_par + 63) // 64, dtype=torch.uint8, device=dev)
+    if world > 1:
+        touch[nU:] = 2                                      # all-reduced item gradients are read every step
+    loss = torch.zeros(2, device=dev)
+
+    # ---- the slice of the epoch these W+K steps consume: a user prefix of the local shard ---------
+    def prefix(n_need, start_user):
+        lo = int(ds["rowptr"][start_user])
+        end_user = int(torch.searchsorted(ds["rowptr"], torch.tensor(lo + n_need, device=dev))) + 1
+        end_user = min(end_user, nU)
+        hi = int(ds["rowptr"][end_user])
+        rp = (ds["rowptr"][start_user:end_user + 1] - lo).contiguous()
+        return dict(rowptr=rp, users=ds["users"][lo:hi], items=ds["items"][lo:hi], n_users=end_user - start_user,
+                    nnz=hi - lo, end_user=end_user)
+    warm = prefix(W * b, 0) if W > 0 else None
+    timed = prefix(K * b, warm["end_user"] if warm else 0)
+    assert timed["nnz"] >= K * b, "dataset too small for --steps"
+    sampler = DeviceSampler(2020)
+    gperm = torch.Generator(device=dev).manual_seed(11 + rank)
+
+    def run_slice(sl, n_steps, events=None):
+        neg = torch.empty(sl["nnz"], dtype=torch.int32, device=dev)
+        sampler.sample_epoch_exact(nI, sl["n_users"], sl["rowptr"], sl["items"], sl["nnz"], 1, neg)
+        perm = torch.randperm(sl["nnz"], generator=gperm, device=dev)[:n_steps * b]
+        uu = sl["users"].index_select(0, perm).contiguous()
+        ii = sl["items"].index_select(0, perm).contiguous()
+        jj = neg.index_select(0, perm).contiguous()
+        for s in range(n_steps):
+            u, i, j = uu[s * b:(s + 1) * b], ii[s * b:(s + 1) * b], jj[s * b:(s + 1) * b]
+            _hip.check(L.skr_bpr_step(_hip.ptr(U), _hip.ptr(V), _hip.ptr(bias), _hip.ptr(U), _hip.ptr(V), _hip.ptr(u),
+                                      _hip.ptr(i), _hip.ptr(j), b, 1.0, 1e-3, 1.0, _hip.ptr(gU), _hip.ptr(gV),
+                                      _hip.ptr(gb), _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(loss), _hip.ptr(touch),
+                                      _hip.ptr(grad), st()))
+            if world > 1:   # the path's one exchange step: replicated item table => sum its gradients
+                dist.all_reduce(g_item)
+            run_slice.t += 1
+            if events is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _hip.check(L.skr_adam_step(_hip.ptr(flat), _hip.ptr(grad), _hip.ptr(m1), _hip.ptr(m2), n_par, 1e-3, 0.9, 0.999,
+                                       1e-8, run_slice.t, 1, _hip.ptr(touch), st()))
+            if events is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                events.append((e0, e1))
+    run_slice.t = 0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # size the sampler's scratch for the timed slice outside the timed region (consumes stream words)
+    _scratch = torch.empty(timed["nnz"], dtype=torch.int32, device=dev)
+    sampler.sample_epoch_exact(nI, timed["n_users"], timed["rowptr"], timed["items"], timed["nnz"], 1, _scratch)
+    del _scratch
+    if W > 0:
+        run_slice(warm, W)
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    run_slice(timed, K, events)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    adam_ms = float(np.mean([a.elapsed_time(z) for a, z in events]))
+    value = K * b * world / dt
+
+    out = {
+        "metric": "train interactions/sec + eval users/sec (HR@10/NDCG@10) at 1/2/4/8 MI355X",
+        "value": value, "unit": "train interactions/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: BPRMF d=64, synthetic 1M-user/100K-item/50M-interaction, "
+                               "exact-stream sampler + fused BPR step + dense Adam; eval = fused MFMA top-10",
+                   "users": args.users, "items": args.items, "train_interactions": n_inter_total,
+                   "batch_per_gpu": b, "global_batch": b * world, "sharding": f"users u%{world}, item table replicated"
+                   + (" + RCCL all-reduce of item grads per step" if world > 1 else "")},
+    }
+    # ---- roofline of the dominant kernel (adam_kernel over the user table) -------------------------
+    adam_bytes = float(n_par) * 28.0           # 7 fp32 per parameter per step (p,g,m,v in; p,m,v out)
+    ach = adam_bytes / (adam_ms * 1e-3) / 1e9
+    out["roofline"] = {"kernel": "adam_kernel<true> (dense Adam over the flat [U|V|b] buffer, one launch per step)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": adam_ms,
+                       "algorithmic_bytes_per_launch": adam_bytes}
+
+    # ---- eval leg: fused GEMM(MFMA)+mask+top-K over a block of this rank's users -------------------
+    if not args.no_eval:
+        ne = min(args.eval_users, nU)
+        users_e = torch.arange(ne, dtype=torch.int32, device=dev)
+        ids = torch.empty((ne, args.top_k), dtype=torch.int32, device=dev)
+        rows = torch.empty((ne, 2 * args.top_k), dtype=torch.float32, device=dev)
+        sums = torch.zeros(2 * args.top_k, dtype=torch.float64, device=dev)
+        ws = int(L.skr_eval_fused_workspace(ne, args.top_k))
+        work = torch.empty(ws, dtype=torch.uint8, device=dev)
+        test_ptr = torch.arange(nU + 1, dtype=torch.long, device=dev)   # one held-out item per user
+        margs = _hip.metric_array([2, 4])                               # Recall (= HR on leave-one-out), NDCG
+
+        def eval_once():
+            _hip.check(L.skr_eval_fused_topk(_hip.ptr(U), _hip.ptr(users_e), ne, _hip.ptr(V), _hip.ptr(bias), nI, D,
+                                             _hip.ptr(ds["rowptr"]), _hip.ptr(ds["items"]), args.top_k, _hip.ptr(ids), None,
+                                             _hip.ptr(work), ws, st()))
+            _hip.check(L.skr_rank_metrics(_hip.ptr(ids), ne, args.top_k, _hip.ptr(users_e), _hip.ptr(test_ptr),
+                                          _hip.ptr(ds["test_item"]), margs, 2, _hip.ptr(rows), _hip.ptr(sums), st()))
+        wu = min(ne, 4096)   # short warm-up launch
+        _hip.check(L.skr_eval_fused_topk(_hip.ptr(U), _hip.ptr(users_e), wu, _hip.ptr(V), _hip.ptr(bias), nI, D,
+                                         _hip.ptr(ds["rowptr"]), _hip.ptr(ds["items"]), args.top_k, _hip.ptr(ids), None,
+                                         _hip.ptr(work), ws, st()))
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        eval_once()
+        e1.record()
+        barrier()
+        te = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([te], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            te = float(tmax)
+        flops = 2.0 * ne * nI * D
+        k_ms = e0.elapsed_time(e1)
+        tf = flops / (k_ms * 1e-3) / 1e12
+        hr = (sums.cpu().numpy() / ne).reshape(2, args.top_k)[:, -1]
+        out["eval"] = {"users_per_sec": ne * world / te, "users": ne * world, "top_k": args.top_k, "seconds": te,
+                       f"HR@{args.top_k}": float(hr[0]), f"NDCG@{args.top_k}": float(hr[1])}
+        out["roofline_eval"] = {"kernel": "fused_topk_kernel (FP32 MFMA GEMM + mask + top-K)", "bound": "mfma",
+                                "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                                "traffic": None, "avg_launch_ms": k_ms, "algorithmic_flop_per_launch": flops}
+
+    # ---- CPU baseline (rank 0, N = 1 only): the reference's way on this box's host cores -----------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_baseline as CB
+        rp = ds["rowptr"].cpu().numpy()
+        it = ds["items"].cpu().numpy()
+        us = ds["users"].cpu().numpy()
+        rate_s, kind_s, sample_s = CB.time_sampler(nI, rp, it)
+        nb = 16
+        rng = np.random.default_rng(3)
+        idx = rng.integers(0, len(it), nb * b)
+        neg = rng.integers(0, nI, nb * b).astype(np.int32)
+        t_step, cores = CB.time_bprmf_steps(nU, nI, D, us[idx], it[idx], neg, b, steps=nb - 2, warmup=2)
+        cpu_value = b / (t_step + b / rate_s)
+        out["cpu_baseline"] = {"value": cpu_value, "unit": "train interactions/s", "cores": cores,
+                               "kind": "port", "sample": f"{nb - 2} BPRMF steps of {b} at full table size with the "
+                               f"reference's torch-CPU op sequence ({t_step * 1e3:.1f} ms/step) + sampler share at "
+                               f"{rate_s / 1e6:.2f} M negatives/s ({kind_s}: {sample_s})"}
+        if not args.no_eval:
+            ev_rate, ev_kind = CB.time_eval_batches(U.cpu().numpy(), V.cpu().numpy(), bias.cpu().numpy(), rp, it,
+                                                    ds["test_item"].cpu().numpy(), np.arange(256, dtype=np.int32),
+                                                    K=args.top_k)
+            out["cpu_baseline"]["eval_users_per_sec"] = ev_rate
+            out["cpu_baseline"]["eval_kind"] = ev_kind
+            out["cpu_baseline"]["eval_sample"] = "4 batches of 64 users: torch-CPU matmul + numpy masking + native top-K (4 threads)"
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

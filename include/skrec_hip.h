@@ -171,22 +171,28 @@ int skr_rank_metrics(const int32_t* d_topk_ids, int B, int top_k, const int32_t*
  *   reg * reg_scale * row goes to d_gRP/d_gRQ (+ d_gb for the bias), computed from d_RP/d_RQ --
  *   for BPRMF these are the same tables (BPRMF.py:118-124); for LightGCN/LayerGCN the scores use
  *   the propagated tables and the regulariser the ego tables (LightGCN.py:192-196).
- *   d_bias / d_gb may be NULL (no item bias). */
+ *   d_bias / d_gb may be NULL (no item bias).
+ *   d_touch (may be NULL): one byte per 64-float block of the gradient allocation that starts at
+ *   d_touch_base; every block this call adds into gets its byte set to 1, so that skr_adam_step
+ *   can skip reading (and re-zeroing) the gradient of blocks nobody touched. */
 int skr_bpr_step(const float* d_P, const float* d_Q, const float* d_bias,
                  const float* d_RP, const float* d_RQ,
                  const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n,
                  float loss_scale, float reg, float reg_scale,
                  float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ,
-                 float* d_loss, void* stream);
+                 float* d_loss, uint8_t* d_touch, const float* d_touch_base, void* stream);
 
 /* torch.optim.Adam.step for one dense parameter (single-tensor path): for every element
  *   m = m + (g-m)*(1-b1);  v = v*b2 + (1-b2)*g*g;
  *   p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * step_t is the 1-based step count.  If zero_grad != 0 the gradient buffer is zeroed in the same
- * pass (the next step's optimizer.zero_grad(), BPRMF.py:125). */
+ * pass (the next step's optimizer.zero_grad(), BPRMF.py:125).
+ * d_touch (may be NULL): one byte per 64-float block of d_g.  0 = the block's gradient is known to
+ * be all zero (it is neither read nor written: 24 instead of 32 bytes of traffic per parameter,
+ * same result bit for bit); 1 = read it, then clear the byte; 2 = always read, never cleared. */
 int skr_adam_step(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n,
                   float lr, float beta1, float beta2, float eps, int64_t step_t, int zero_grad,
-                  void* stream);
+                  uint8_t* d_touch, void* stream);
 
 /* Y = A * X for a CSR matrix with fp32 values and dim == 64 (torch.sparse.mm, LightGCN.py:94);
  *   optional fused epilogues:  Y += d_addend (same shape, may be NULL);

@@ -27,8 +27,14 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
     const float* __restrict__ RP, const float* __restrict__ RQ, const int32_t* __restrict__ u_ids,
     const int32_t* __restrict__ i_ids, const int32_t* __restrict__ j_ids, int n, float loss_scale, float reg,
     float reg_scale, float* __restrict__ gP, float* __restrict__ gQ, float* __restrict__ gb, float* __restrict__ gRP,
-    float* __restrict__ gRQ, float* __restrict__ loss) {
+    float* __restrict__ gRQ, float* __restrict__ loss, uint8_t* __restrict__ touch, const float* touch_base) {
     __shared__ float s_loss[BPR_WAVES], s_l2[BPR_WAVES];
+    // mark the 64-float gradient block that starts at `a` as touched (one lane per row is enough)
+    // (a byte that is already non-zero -- 1, or the sticky 2 -- is left alone)
+    auto mark = [&](const float* a) {
+        uint8_t* t = &touch[(a - touch_base) >> 6];
+        if (*t == 0) *t = 1;
+    };
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float acc_loss = 0.0f, acc_l2 = 0.0f;
     const float rs = reg * reg_scale;
@@ -70,6 +76,11 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
                 atomicAdd(&gb[j], -c + rs * bj);
             }
         }
+        if (touch && lane == 0) {
+            mark(&gP[u * D]); mark(&gQ[i * D]); mark(&gQ[j * D]);
+            if (rs != 0.0f) { mark(&gRP[u * D]); mark(&gRQ[i * D]); mark(&gRQ[j * D]); }
+            if (bias && gb) { mark(&gb[i]); mark(&gb[j]); }
+        }
         acc_loss += l;
         acc_l2 += 0.5f * sq;
     }
@@ -103,8 +114,10 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p = p + (a.neg_step_size * m) / denom;      // addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+template <bool TOUCH>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, AdamArgs a, int zero_grad) {
+                                                   float* __restrict__ v, int64_t n, AdamArgs a, int zero_grad,
+                                                   uint8_t* __restrict__ touch) {
     const int64_t n4 = n >> 2;
     float4* p4 = reinterpret_cast<float4*>(p);
     float4* g4 = reinterpret_cast<float4*>(g);
@@ -112,7 +125,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     float4* v4 = reinterpret_cast<float4*>(v);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4; i += stride) {
-        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+        // 16 consecutive lanes share one 64-float block and its byte; they all read it in this
+        // instruction, before the lane with (i & 15) == 0 clears it further down
+        const uint8_t flag = TOUCH ? touch[i >> 4] : 2;
+        if (flag) gg = g4[i];
         adam_elem(pp.x, gg.x, mm.x, vv.x, a);
         adam_elem(pp.y, gg.y, mm.y, vv.y, a);
         adam_elem(pp.z, gg.z, mm.z, vv.z, a);
@@ -120,9 +138,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         p4[i] = pp;
         m4[i] = mm;
         v4[i] = vv;
-        if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (flag) {
+            if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TOUCH && flag == 1 && (i & 15) == 0) touch[i >> 4] = 0;
+        }
     }
-    // tail (n not a multiple of 4)
+    // tail (n not a multiple of 4): always read
     for (int64_t i = (n4 << 2) + blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
         float pp = p[i], mm = m[i], vv = v[i];
         adam_elem(pp, g[i], mm, vv, a);
@@ -130,6 +151,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         m[i] = mm;
         v[i] = vv;
         if (zero_grad) g[i] = 0.f;
+        if (TOUCH && touch[i >> 6] == 1) touch[i >> 6] = 0;
     }
 }
 
@@ -302,21 +324,23 @@ extern "C" {
 int skr_bpr_step(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
                  const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n, float loss_scale, float reg,
                  float reg_scale, float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ, float* d_loss,
-                 void* stream) {
+                 uint8_t* d_touch, const float* d_touch_base, void* stream) {
     SKR_REQUIRE(d_P && d_Q && d_RP && d_RQ && d_u && d_i && d_j && d_gP && d_gQ && d_gRP && d_gRQ && d_loss,
                 "skr_bpr_step: NULL argument");
     SKR_REQUIRE(n >= 0, "skr_bpr_step: negative batch size");
+    SKR_REQUIRE(!d_touch || d_touch_base, "skr_bpr_step: d_touch needs d_touch_base");
     if (n == 0) return SKR_OK;
     int blocks = (n + BPR_WAVES - 1) / BPR_WAVES;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bpr_step_kernel, dim3(blocks), dim3(BPR_WAVES * 64), 0, skr::as_stream(stream), d_P, d_Q, d_bias,
-                       d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP, d_gRQ, d_loss);
+                       d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP, d_gRQ, d_loss,
+                       d_touch, d_touch_base);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
 
 int skr_adam_step(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, int64_t step_t, int zero_grad, void* stream) {
+                  float eps, int64_t step_t, int zero_grad, uint8_t* d_touch, void* stream) {
     SKR_REQUIRE(d_p && d_g && d_m && d_v, "skr_adam_step: NULL argument");
     SKR_REQUIRE(n >= 0 && step_t >= 1, "skr_adam_step: n must be >= 0 and step_t >= 1");
     SKR_REQUIRE(((reinterpret_cast<uintptr_t>(d_p) | reinterpret_cast<uintptr_t>(d_g) | reinterpret_cast<uintptr_t>(d_m) |
@@ -336,8 +360,12 @@ int skr_adam_step(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, flo
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream), d_p, d_g,
-                       d_m, d_v, n, a, zero_grad);
+    if (d_touch)
+        hipLaunchKernelGGL(adam_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream),
+                           d_p, d_g, d_m, d_v, n, a, zero_grad, d_touch);
+    else
+        hipLaunchKernelGGL(adam_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream),
+                           d_p, d_g, d_m, d_v, n, a, zero_grad, d_touch);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

@@ -5,7 +5,8 @@ Same config, same initialisation (weights are drawn on the CPU with torch's gene
 reference's order, so a given ``--seed`` yields the reference's initial tables), same loss
 (sum over the batch of -log sigmoid(x_ui - x_uj) + reg * 0.5 * sum of squares of the gathered rows,
 BPRMF.py:117-124) and the same dense Adam.  One training step is two kinds of launches:
-``skr_bpr_step`` (gather + score + loss + gradient scatter fused) and ``skr_adam_step`` per table.
+``skr_bpr_step`` (gather + score + loss + gradient scatter fused) and ONE ``skr_adam_step`` over the
+flat [U | V | b] parameter buffer.
 """
 from typing import Dict
 
@@ -65,21 +66,27 @@ class BPRMF(AbstractRecommender):
             raise NotImplementedError("the MI355X kernels are specialised for n_dim=64 (one row per wavefront)")
         self.device = _hip.require_gpu()
         U, V, b = _init_tables(self.num_users, self.num_items, self.config.n_dim)
-        self.user_embeddings = U.to(self.device).contiguous()
-        self.item_embeddings = V.to(self.device).contiguous()
-        self.item_biases = b.to(self.device).contiguous()
-        self.optimizer = DenseAdam([self.user_embeddings, self.item_embeddings, self.item_biases], lr=self.config.lr)
+        # one flat buffer [U | V | b] => one Adam launch per step; the tables are views into it
+        nu, ni, d = self.num_users, self.num_items, self.config.n_dim
+        self._flat = torch.cat([U.reshape(-1), V.reshape(-1), b.reshape(-1)]).to(self.device).contiguous()
+        self.user_embeddings = self._flat[:nu * d].view(nu, d)
+        self.item_embeddings = self._flat[nu * d:(nu + ni) * d].view(ni, d)
+        self.item_biases = self._flat[(nu + ni) * d:]
+        self.optimizer = DenseAdam(self._flat, lr=self.config.lr, track_touch=True)
+        self._grads = (self.optimizer.grad_view(0, (nu, d)), self.optimizer.grad_view(nu * d, (ni, d)),
+                       self.optimizer.grad_view((nu + ni) * d, (ni,)))
         self.step_losses = None  # device [n_steps, 2]: (bpr sum, l2) per step of the last epoch
         self.sampler_mode = getattr(run_config, "sampler_mode", None)
 
     def train_step(self, users, pos, neg, loss_slot):
         """one mini-batch; ``users/pos/neg`` are int32 device tensors"""
-        gU, gV, gb = self.optimizer.grads
+        gU, gV, gb = self._grads
         _hip.check(_hip.lib().skr_bpr_step(
             _hip.ptr(self.user_embeddings), _hip.ptr(self.item_embeddings), _hip.ptr(self.item_biases),
             _hip.ptr(self.user_embeddings), _hip.ptr(self.item_embeddings),
             _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), 1.0, self.config.reg, 1.0,
-            _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(gb), _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(loss_slot), _hip.stream()))
+            _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(gb), _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(loss_slot),
+            _hip.ptr(self.optimizer.touch), _hip.ptr(self.optimizer.grad), _hip.stream()))
         self.optimizer.step()
 
     def train_epoch(self, data_iter):

@@ -76,7 +76,8 @@ class LayerGCN(AbstractRecommender):
         self.adj = DeviceCSR(build_layergcn_adjacency(inter, self.num_users, self.num_items), self.device)
         N = self.num_users + self.num_items
         self.ego = torch.cat([ue, ie], dim=0).to(self.device).contiguous()
-        self.optimizer = DenseAdam([self.ego], lr=cfg.lr)
+        self.optimizer = DenseAdam(self.ego.view(-1), lr=cfg.lr)
+        self._g_ego = self.optimizer.grad.view(N, 64)
         z = lambda: torch.zeros((N, 64), dtype=torch.float32, device=self.device)  # noqa: E731
         K = cfg.n_layers
         self.out = z()                                   # sum of refined layers
@@ -114,12 +115,13 @@ class LayerGCN(AbstractRecommender):
         L, st = _hip.lib(), _hip.stream()
         N = self.ego.shape[0]
         self.forward()
-        gO, (gE,) = self._g_out, self.optimizer.grads
+        gO, gE = self._g_out, self._g_ego
         gO.zero_()
         _hip.check(L.skr_bpr_step(
             _hip.ptr(self.out[:nu]), _hip.ptr(self.out[nu:]), None, _hip.ptr(self.ego[:nu]), _hip.ptr(self.ego[nu:]),
             _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), 1.0, cfg.reg, 1.0,
-            _hip.ptr(gO[:nu]), _hip.ptr(gO[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot), st))
+            _hip.ptr(gO[:nu]), _hip.ptr(gO[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot),
+            None, None, st))
         # backward: dZ_K = gO ; dY_k, dE0 += refine_bwd(dZ_k) ; dZ_{k-1} = gO + A dY_k ; dE0 += A dY_1
         dz = gO
         dy, tmp = self._t

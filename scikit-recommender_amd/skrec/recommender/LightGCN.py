@@ -115,7 +115,8 @@ class LightGCN(AbstractRecommender):
         get_initializer("xavier_uniform")(ie.weight)
         N = self.num_users + self.num_items
         self.ego = torch.cat([ue.weight.detach(), ie.weight.detach()], dim=0).to(self.device).contiguous()  # E0
-        self.optimizer = DenseAdam([self.ego], lr=cfg.lr)
+        self.optimizer = DenseAdam(self.ego.view(-1), lr=cfg.lr)
+        self._g_ego = self.optimizer.grad.view(N, 64)
         z = lambda: torch.zeros((N, 64), dtype=torch.float32, device=self.device)  # noqa: E731
         self.final = z()          # layer mean, E-bar
         self._x = [z(), z()]      # propagation ping-pong
@@ -168,13 +169,13 @@ class LightGCN(AbstractRecommender):
         n = users.numel()
         self.propagate()
         self._final_is_current = False
-        gF, (gE,) = self._g_final, self.optimizer.grads
+        gF, gE = self._g_final, self._g_ego
         gF.zero_()
         _hip.check(_hip.lib().skr_bpr_step(
             _hip.ptr(self.final[:nu]), _hip.ptr(self.final[nu:]), None, _hip.ptr(self.ego[:nu]), _hip.ptr(self.ego[nu:]),
             _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), n, 1.0 / n, cfg.reg, 1.0 / cfg.batch_size,
             _hip.ptr(gF[:nu]), _hip.ptr(gF[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot),
-            _hip.stream()))
+            None, None, _hip.stream()))
         # backward through the mean and the K propagations: dL/dE0 += sum_k (A^T)^k H, H = gF/(K+1)
         _hip.check(_hip.lib().skr_scale(1.0 / (K + 1), _hip.ptr(gF), gF.numel(), _hip.stream()))
         x = gF

@@ -57,22 +57,32 @@ class AbstractRecommender(object):
 
 
 class DenseAdam(object):
-    """State of ``torch.optim.Adam(params, lr)`` for dense fp32 tensors, stepped by ``skr_adam_step``
-    (betas 0.9/0.999, eps 1e-8, no weight decay: the reference's defaults, BPRMF.py:99)."""
+    """State of ``torch.optim.Adam(params, lr)`` for ONE flat fp32 buffer holding every parameter of the
+    model, stepped by a single ``skr_adam_step`` launch per training step (betas 0.9/0.999, eps 1e-8,
+    no weight decay: the reference's defaults, BPRMF.py:99).  Every element is updated every step,
+    like the reference's dense Adam; with ``track_touch`` a byte per 64-float block lets the kernel
+    skip READING gradients that are known to be zero (same result, 24 instead of 32 B/param)."""
 
-    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8, track_touch=False):
         import torch
-        self.params = list(params)
-        self.grads = [torch.zeros_like(p) for p in self.params]
-        self.m = [torch.zeros_like(p) for p in self.params]
-        self.v = [torch.zeros_like(p) for p in self.params]
+        assert flat.dim() == 1 and flat.is_contiguous()
+        self.flat = flat
+        self.grad = torch.zeros_like(flat)
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.touch = torch.zeros((flat.numel() + 63) // 64, dtype=torch.uint8, device=flat.device) if track_touch else None
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         self.t = 0
+
+    def grad_view(self, start, shape):
+        n = 1
+        for d in shape:
+            n *= d
+        return self.grad[start:start + n].view(*shape)
 
     def step(self):
         from .. import _hip
         self.t += 1
-        L, st = _hip.lib(), _hip.stream()
-        for p, g, m, v in zip(self.params, self.grads, self.m, self.v):
-            _hip.check(L.skr_adam_step(_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), p.numel(), self.lr,
-                                       self.betas[0], self.betas[1], self.eps, self.t, 1, st))
+        _hip.check(_hip.lib().skr_adam_step(_hip.ptr(self.flat), _hip.ptr(self.grad), _hip.ptr(self.m), _hip.ptr(self.v),
+                                            self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t, 1,
+                                            _hip.ptr(self.touch), _hip.stream()))

@@ -38,7 +38,7 @@ def test_binding_loads_and_reports_errors_without_gpu():
     rc = L.skr_eval_scores(None, 1, 10, 10, None, None, None, 0, 5, None, None, None, None)
     assert rc == -1 and b"NULL" in L.skr_last_error()
     with pytest.raises(ValueError):
-        _hip.check(L.skr_adam_step(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 1, 0, None))
+        _hip.check(L.skr_adam_step(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 1, 0, None, None))
     assert L.skr_eval_fused_workspace(100, 10) == 128 * 256 * 8
 
 

@@ -41,7 +41,7 @@ def test_bpr_step_vs_oracle(n, with_bias, split):
     _hip.check(_hip.lib().skr_bpr_step(_hip.ptr(dP), _hip.ptr(dQ), _hip.ptr(db), _hip.ptr(dRP if split else dP),
                                        _hip.ptr(dRQ if split else dQ), _hip.ptr(du), _hip.ptr(di),
                                        _hip.ptr(dj), n, ls, reg, rs, _hip.ptr(ggP), _hip.ptr(ggQ), _hip.ptr(ggb),
-                                       _hip.ptr(ggRP), _hip.ptr(ggRQ), _hip.ptr(dl), _hip.stream()))
+                                       _hip.ptr(ggRP), _hip.ptr(ggRQ), _hip.ptr(dl), None, None, _hip.stream()))
     torch.cuda.synchronize()
     got = dl.cpu().numpy()
     assert abs(got[0] - loss) <= 1e-5 * abs(loss) and abs(got[1] - l2) <= 1e-5 * abs(l2)
@@ -54,7 +54,10 @@ def test_bpr_step_vs_oracle(n, with_bias, split):
         _close(ggb.cpu().numpy(), gb)
 
 
-def test_adam_matches_torch_cpu():
+@pytest.mark.parametrize("use_touch", [False, True])
+def test_adam_matches_torch_cpu(use_touch):
+    """dense torch.optim.Adam on the CPU vs skr_adam_step; with touch bytes the kernel must skip only
+    gradient blocks that really are zero and give the same numbers"""
     import torch
     from gpu_utils import to_dev
     from skrec import _hip
@@ -64,16 +67,47 @@ def test_adam_matches_torch_cpu():
     pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
     opt = torch.optim.Adam([pt], lr=1e-3)
     dp, dm, dv = to_dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    nb = (n + 63) // 64
     for t in range(1, 6):
-        g = (rng.standard_normal(n) * (rng.random(n) < 0.3)).astype(np.float32)  # mostly-zero grads, dense update
+        blocks = rng.random(nb) < 0.3                     # gradient lives in ~30 % of the 64-float blocks
+        g = (rng.standard_normal(n) * np.repeat(blocks, 64)[:n]).astype(np.float32)
         pt.grad = torch.from_numpy(g.copy())
         opt.step()
         dg = to_dev(g)
+        touch = to_dev(np.where(blocks, 1 + (np.arange(nb) % 2), 0).astype(np.uint8)) if use_touch else None
         _hip.check(_hip.lib().skr_adam_step(_hip.ptr(dp), _hip.ptr(dg), _hip.ptr(dm), _hip.ptr(dv), n, 1e-3, 0.9, 0.999,
-                                            1e-8, t, 1, _hip.stream()))
+                                            1e-8, t, 1, _hip.ptr(touch), _hip.stream()))
         torch.cuda.synchronize()
         assert float(dg.abs().max()) == 0.0  # zero_grad fused
+        if use_touch:  # 1 -> cleared, 2 -> sticky, 0 stays
+            want = np.where(blocks, np.where(np.arange(nb) % 2 == 1, 2, 0), 0)
+            assert np.array_equal(touch.cpu().numpy(), want)
         _close(dp.cpu().numpy(), pt.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_bpr_step_marks_touched_blocks():
+    import torch
+    from gpu_utils import to_dev, dev
+    from skrec import _hip
+    rng = np.random.default_rng(9)
+    nU, nI, n = 50, 40, 30
+    flat = torch.zeros(nU * 64 + nI * 64 + nI, device=dev())
+    g = torch.zeros_like(flat)
+    touch = torch.zeros((flat.numel() + 63) // 64, dtype=torch.uint8, device=dev())
+    P, Q, b = flat[:nU * 64].view(nU, 64), flat[nU * 64:(nU + nI) * 64].view(nI, 64), flat[(nU + nI) * 64:]
+    flat.normal_()
+    gP, gQ, gb = g[:nU * 64].view(nU, 64), g[nU * 64:(nU + nI) * 64].view(nI, 64), g[(nU + nI) * 64:]
+    u, i, j = (rng.integers(0, m, n).astype(np.int32) for m in (nU, nI, nI))
+    du, di, dj = to_dev(u), to_dev(i), to_dev(j)
+    loss = torch.zeros(2, device=dev())
+    _hip.check(_hip.lib().skr_bpr_step(_hip.ptr(P), _hip.ptr(Q), _hip.ptr(b), _hip.ptr(P), _hip.ptr(Q), _hip.ptr(du),
+                                       _hip.ptr(di), _hip.ptr(dj), n, 1.0, 1e-3, 1.0, _hip.ptr(gP), _hip.ptr(gQ), _hip.ptr(gb),
+                                       _hip.ptr(gP), _hip.ptr(gQ), _hip.ptr(loss), _hip.ptr(touch), _hip.ptr(g), _hip.stream()))
+    torch.cuda.synchronize()
+    nz = (g.cpu().numpy() != 0)
+    nz = np.pad(nz, (0, (-len(nz)) % 64)).reshape(-1, 64).any(1)
+    t = touch.cpu().numpy().astype(bool)
+    assert np.all(t[nz]) and t.sum() <= len(set(u)) + 2 * len(set(i) | set(j)) + 2
 
 
 @pytest.mark.parametrize("n_rows,density,heavy", [(50, 0.2, 0), (3000, 0.004, 2), (20000, 0.0005, 3)])
