@@ -23,6 +23,8 @@
 // Bound: MFMA (2*B*I*64 flop); the 25.6 MB item table streams from L2 / Infinity Cache.
 #include "eval_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -283,6 +285,172 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel(FusedArgs 
     }
 }
 
+
+// ================================================================================================
+// v2: same mapping, re-scheduled for one/two waves per SIMD.
+//   * item tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write,
+//     and the data's latency is covered by a whole 64-MFMA chain (the wait sits at the END of the
+//     iteration; in v1 hipcc hoisted the ds_writes -- and with them the vmcnt waits -- into the chain,
+//     which parked the wave for ~1950 cycles per tile: profiles/r01_eval_pmc.txt);
+//   * two accumulator sets: while tile t is multiplied, the any-score-above-threshold test of tile
+//     t-1 (64 v_cmp + scalar ORs, straight-line) sits in the same basic block and is interleaved
+//     with the MFMAs by the scheduler; the candidate path is entered only when some lane passed;
+//   * the item bias rides along through LDS (one 4-byte LDS-DMA per tile) and seeds the accumulators.
+// ================================================================================================
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+struct WaveCtx {
+    int lane, c, h;
+    int64_t ubase;
+    int* cnt;
+    uint64_t* my_cand;
+};
+
+// candidate path for one finished tile: append every score above the user's threshold, then compact
+// the lists that came within one tile of their capacity
+__device__ __forceinline__ void tile_candidates(const FusedArgs& a, const WaveCtx& w, const f32x16& acc0,
+                                                const f32x16& acc1, int tile_base, float (&thr)[2], const int (&uid)[2]) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const f32x16& acc = f ? acc1 : acc0;
+        const int ul = 32 * f + w.c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int item = tile_base + (r & 3) + 8 * (r >> 2) + 4 * w.h;
+            if (acc[r] > thr[f] && item < a.n_items) {
+                const int p = atomicAdd(&w.cnt[ul], 1);  // < FE_CAP by the compaction rule
+                w.my_cand[static_cast<int64_t>(ul) * FE_CAP + p] = skr::rank_key(acc[r], item);
+            }
+        }
+    }
+    uint64_t need = __ballot(w.cnt[w.lane] > FE_CAP - FE_TI);
+    while (need) {
+        const int ul = __ffsll(static_cast<long long>(need)) - 1;
+        need &= need - 1;
+        const int f = ul >> 5;
+        const int u_id = __shfl(f ? uid[1] : uid[0], ul & 31, 64);
+        const float nt = compact_user(a, w.lane, w.my_cand + static_cast<int64_t>(ul) * FE_CAP, &w.cnt[ul], u_id, -1);
+        if (w.c == (ul & 31)) {
+            if (f) thr[1] = nt; else thr[0] = nt;
+        }
+    }
+}
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v2(FusedArgs a) {
+    __shared__ float4 s_tile[FE_WAVES][2][FE_TI * FE_D / 4];  // wave-private double buffer: 2 x 8 KB
+    __shared__ float4 s_bias[FE_WAVES][2][16];                // 64 floats per buffer (32 used twice)
+    __shared__ int s_cnt[FE_WAVES][FE_UW];
+    WaveCtx w;
+    w.lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    w.c = w.lane & 31;
+    w.h = w.lane >> 5;
+    const int lane = w.lane, c = w.c, h = w.h;
+    w.ubase = (static_cast<int64_t>(blockIdx.x) * FE_WAVES + wv) * FE_UW;
+    if (w.ubase >= a.B) return;
+    w.cnt = s_cnt[wv];
+    w.cnt[lane] = 0;
+    w.my_cand = a.cand + w.ubase * FE_CAP;
+
+    float bf[2][32];
+    float thr[2];
+    int uid[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int64_t row = w.ubase + 32 * f + c;
+        const bool ok = row < a.B;
+        uid[f] = a.users[ok ? row : (a.B - 1)];
+        thr[f] = ok ? -INFINITY : INFINITY;
+        const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid[f]) * FE_D + 32 * h);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = up[q];
+            bf[f][4 * q + 0] = v.x; bf[f][4 * q + 1] = v.y; bf[f][4 * q + 2] = v.z; bf[f][4 * q + 3] = v.w;
+        }
+    }
+    const int n_tiles = (a.n_items + FE_TI - 1) / FE_TI;
+
+    // LDS-DMA of tile T into buffer BUF: instruction j writes LDS bytes [j*1024, (j+1)*1024) = rows
+    // 4j..4j+3; lane l supplies the 16-byte piece ((l&15) ^ (row&15)) of row 4j + (l>>4).
+#define FE2_ISSUE(T, BUF)                                                                                    \
+    {                                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
+            const int rl_ = 4 * j + (lane >> 4);                                                             \
+            int item_ = (T) * FE_TI + rl_;                                                                   \
+            item_ = item_ < a.n_items ? item_ : a.n_items - 1;                                               \
+            const int piece_ = (lane & 15) ^ (rl_ & 15);                                                     \
+            __builtin_amdgcn_global_load_lds(                                                                \
+                (gbl_ptr_t)(a.item_table + static_cast<int64_t>(item_) * FE_D + 4 * piece_),                 \
+                (lds_ptr_t)(&s_tile[wv][BUF][j * 64]), 16, 0, 0);                                            \
+        }                                                                                                    \
+        if (HAS_BIAS) {                                                                                      \
+            int bi_ = (T) * FE_TI + (lane & 31);                                                             \
+            bi_ = bi_ < a.n_items ? bi_ : a.n_items - 1;                                                     \
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a.item_bias + bi_), (lds_ptr_t)(&s_bias[wv][BUF][0]), 4, 0, 0); \
+        }                                                                                                    \
+    }
+#define FE2_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+    // one tile: CUR accumulators <- tile T; fast test of the PREVious tile's accumulators meanwhile
+#define FE2_STEP(C0, C1, P0, P1, T)                                                                          \
+    {                                                                                                        \
+        const int t_ = (T);                                                                                  \
+        const int bc_ = t_ & 1;                                                                              \
+        if (t_ + 1 < n_tiles) FE2_ISSUE(t_ + 1, bc_ ^ 1)                                                     \
+        float av_[32];                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                      \
+            const float4 v_ = s_tile[wv][bc_][c * 16 + ((8 * h + q) ^ (c & 15))];                            \
+            av_[4 * q + 0] = v_.x; av_[4 * q + 1] = v_.y; av_[4 * q + 2] = v_.z; av_[4 * q + 3] = v_.w;      \
+        }                                                                                                    \
+        if (HAS_BIAS) {                                                                                      \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                  \
+                const float4 b4_ = s_bias[wv][bc_][2 * g + h];                                               \
+                C0[4 * g + 0] = b4_.x; C0[4 * g + 1] = b4_.y; C0[4 * g + 2] = b4_.z; C0[4 * g + 3] = b4_.w;  \
+            }                                                                                                \
+        } else {                                                                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) C0[r] = 0.0f;                                     \
+        }                                                                                                    \
+        C1 = C0;                                                                                             \
+        bool any_ = false;                                                                                   \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) any_ |= (P0[r] > thr[0]) | (P1[r] > thr[1]);          \
+        _Pragma("unroll") for (int s = 0; s < 32; ++s) {                                                     \
+            C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[s], bf[0][s], C0, 0, 0, 0);                        \
+            C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[s], bf[1][s], C1, 0, 0, 0);                        \
+        }                                                                                                    \
+        if (__any(any_)) tile_candidates(a, w, P0, P1, (t_ - 1) * FE_TI, thr, uid);                          \
+        FE2_WAIT();                                                                                          \
+    }
+
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB[r] = -INFINITY;  // "tile -1": nothing passes
+    f32x16 accA1 = accB, accB1 = accB;
+    FE2_ISSUE(0, 0)
+    FE2_WAIT();
+    int t = 0;
+    for (; t + 1 < n_tiles; t += 2) {
+        FE2_STEP(accA, accA1, accB, accB1, t)
+        FE2_STEP(accB, accB1, accA, accA1, t + 1)
+    }
+    if (t < n_tiles) {  // odd tile count: the last tile lands in A
+        FE2_STEP(accA, accA1, accB, accB1, t)
+        tile_candidates(a, w, accA, accA1, t * FE_TI, thr, uid);
+    } else {
+        tile_candidates(a, w, accB, accB1, (n_tiles - 1) * FE_TI, thr, uid);
+    }
+#undef FE2_STEP
+#undef FE2_WAIT
+#undef FE2_ISSUE
+    for (int ul = 0; ul < FE_UW; ++ul) {
+        const int64_t row = w.ubase + ul;
+        if (row >= a.B) break;
+        const int u_id = __shfl((ul >> 5) ? uid[1] : uid[0], ul & 31, 64);
+        compact_user(a, lane, w.my_cand + static_cast<int64_t>(ul) * FE_CAP, &w.cnt[ul], u_id, row);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -314,10 +482,18 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     const int64_t waves = (static_cast<int64_t>(B) + FE_UW - 1) / FE_UW;
     const unsigned blocks = static_cast<unsigned>((waves + FE_WAVES - 1) / FE_WAVES);
     hipStream_t st = skr::as_stream(stream);
-    if (d_item_bias)
-        hipLaunchKernelGGL(fused_topk_kernel<true>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
-    else
-        hipLaunchKernelGGL(fused_topk_kernel<false>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
+    static const int version = [] { const char* e = getenv("SKR_FUSED_V"); return e ? atoi(e) : 2; }();
+    if (version == 1) {
+        if (d_item_bias)
+            hipLaunchKernelGGL(fused_topk_kernel<true>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
+        else
+            hipLaunchKernelGGL(fused_topk_kernel<false>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
+    } else {
+        if (d_item_bias)
+            hipLaunchKernelGGL(fused_topk_kernel_v2<true>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
+        else
+            hipLaunchKernelGGL(fused_topk_kernel_v2<false>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
+    }
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

@@ -12,6 +12,7 @@
 #include "skr_common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -114,7 +115,7 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p = p + (a.neg_step_size * m) / denom;      // addcdiv_(exp_avg, denom, value=-step_size)
 }
 
-template <bool TOUCH>
+template <bool TOUCH, int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, AdamArgs a, int zero_grad,
                                                    uint8_t* __restrict__ touch) {
@@ -124,23 +125,58 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4; i += stride) {
-        float4 pp = p4[i], mm = m4[i], vv = v4[i];
-        float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
-        // 16 consecutive lanes share one 64-float block and its byte; they all read it in this
-        // instruction, before the lane with (i & 15) == 0 clears it further down
-        const uint8_t flag = TOUCH ? touch[i >> 4] : 2;
-        if (flag) gg = g4[i];
-        adam_elem(pp.x, gg.x, mm.x, vv.x, a);
-        adam_elem(pp.y, gg.y, mm.y, vv.y, a);
-        adam_elem(pp.z, gg.z, mm.z, vv.z, a);
-        adam_elem(pp.w, gg.w, mm.w, vv.w, a);
-        p4[i] = pp;
-        m4[i] = mm;
-        v4[i] = vv;
-        if (flag) {
-            if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (TOUCH && flag == 1 && (i & 15) == 0) touch[i >> 4] = 0;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [](const float4* q) -> float4 {
+        if (NT) {
+            float4 r;
+            r.x = __builtin_nontemporal_load(&q->x); r.y = __builtin_nontemporal_load(&q->y);
+            r.z = __builtin_nontemporal_load(&q->z); r.w = __builtin_nontemporal_load(&q->w);
+            return r;
+        }
+        return *q;
+    };
+    auto stv = [](float4* q, const float4& r) {
+        if (NT) {
+            __builtin_nontemporal_store(r.x, &q->x); __builtin_nontemporal_store(r.y, &q->y);
+            __builtin_nontemporal_store(r.z, &q->z); __builtin_nontemporal_store(r.w, &q->w);
+        } else {
+            *q = r;
+        }
+    };
+    for (int64_t i0 = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i0 < n4; i0 += stride * UNROLL) {
+        float4 pp[UNROLL], mm[UNROLL], vv[UNROLL], gg[UNROLL];
+        uint8_t flag[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {   // issue every load of this trip before the first use
+            const int64_t i = i0 + k * stride;
+            gg[k] = zero4;
+            flag[k] = 0;
+            if (i < n4) {
+                pp[k] = ld(&p4[i]);
+                mm[k] = ld(&m4[i]);
+                vv[k] = ld(&v4[i]);
+                // 16 consecutive lanes share one 64-float block and its byte; they all read it in this
+                // instruction, before the lane with (i & 15) == 0 clears it further down
+                flag[k] = TOUCH ? touch[i >> 4] : 2;
+                if (flag[k]) gg[k] = g4[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            const int64_t i = i0 + k * stride;
+            if (i < n4) {
+                adam_elem(pp[k].x, gg[k].x, mm[k].x, vv[k].x, a);
+                adam_elem(pp[k].y, gg[k].y, mm[k].y, vv[k].y, a);
+                adam_elem(pp[k].z, gg[k].z, mm[k].z, vv[k].z, a);
+                adam_elem(pp[k].w, gg[k].w, mm[k].w, vv[k].w, a);
+                stv(&p4[i], pp[k]);
+                stv(&m4[i], mm[k]);
+                stv(&v4[i], vv[k]);
+                if (flag[k]) {
+                    if (zero_grad) g4[i] = zero4;
+                    if (TOUCH && flag[k] == 1 && (i & 15) == 0) touch[i >> 4] = 0;
+                }
+            }
         }
     }
     // tail (n not a multiple of 4): always read
@@ -357,15 +393,35 @@ int skr_adam_step(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, flo
     a.neg_step_size = static_cast<float>(-(static_cast<double>(lr) / bc1));
     a.bc2_sqrt = static_cast<float>(std::sqrt(bc2));
     a.eps = eps;
+    // Launch shape measured on MI355X (tools/tune_adam.sh, profiles/r01_adam_tuning.txt): 2 workgroups
+    // per CU, 4 float4 per lane in flight, non-temporal accesses.  SKR_ADAM_CFG="<blocks_per_cu>,
+    // <unroll>,<nt>" overrides it for tuning runs.
+    static int cfg_bpc = 2, cfg_unroll = 4, cfg_nt = 1;
+    static bool cfg_read = false;
+    if (!cfg_read) {
+        cfg_read = true;
+        if (const char* e = getenv("SKR_ADAM_CFG")) sscanf(e, "%d,%d,%d", &cfg_bpc, &cfg_unroll, &cfg_nt);
+    }
     int64_t blocks = ((n >> 2) + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks > 256 * cfg_bpc) blocks = 256 * cfg_bpc;
     if (blocks < 1) blocks = 1;
-    if (d_touch)
-        hipLaunchKernelGGL(adam_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream),
-                           d_p, d_g, d_m, d_v, n, a, zero_grad, d_touch);
-    else
-        hipLaunchKernelGGL(adam_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream),
-                           d_p, d_g, d_m, d_v, n, a, zero_grad, d_touch);
+    const dim3 grid(static_cast<unsigned>(blocks)), blk(256);
+    hipStream_t st = skr::as_stream(stream);
+#define SKR_ADAM_LAUNCH(T, U_, N_) \
+    hipLaunchKernelGGL((adam_kernel<T, U_, N_>), grid, blk, 0, st, d_p, d_g, d_m, d_v, n, a, zero_grad, d_touch)
+#define SKR_ADAM_PICK(T)                                                        \
+    if (cfg_nt) {                                                               \
+        if (cfg_unroll == 4) SKR_ADAM_LAUNCH(T, 4, true);                       \
+        else if (cfg_unroll == 2) SKR_ADAM_LAUNCH(T, 2, true);                  \
+        else SKR_ADAM_LAUNCH(T, 1, true);                                       \
+    } else {                                                                    \
+        if (cfg_unroll == 4) SKR_ADAM_LAUNCH(T, 4, false);                      \
+        else if (cfg_unroll == 2) SKR_ADAM_LAUNCH(T, 2, false);                 \
+        else SKR_ADAM_LAUNCH(T, 1, false);                                      \
+    }
+    if (d_touch) { SKR_ADAM_PICK(true) } else { SKR_ADAM_PICK(false) }
+#undef SKR_ADAM_PICK
+#undef SKR_ADAM_LAUNCH
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
