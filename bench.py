@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--items", type=int, default=100_000)
     ap.add_argument("--interactions", type=int, default=50_000_000)
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--eval-users", type=int, default=131072)
+    ap.add_argument("--eval-users", type=int, default=262144)
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")

@@ -10,13 +10,14 @@
 //     whole catalogue in tiles of 32 items; a 32x32 MFMA tile has the ITEM on the row and the USER
 //     on the column, so every lane holds 16 scores of ONE user -> the running top-K threshold of
 //     that user is a single register compare per score;
-//   * item tiles (32 x 256 B) are fetched with full-line coalesced 16-byte loads (prefetched one
-//     tile ahead in registers), transposed through a wave-private, XOR-swizzled LDS image into the
-//     A-fragment layout (conflict-free ds_read_b128); waves share nothing, so there are no barriers
-//     and a wave that stops to compact its candidate lists never stalls its neighbours;
+//   * item tiles (32 x 256 B) go global -> LDS by LDS-DMA (global_load_lds_dwordx4, full 256-byte
+//     lines, one tile ahead) into a wave-private, XOR-swizzled image that the A fragments are read
+//     from with conflict-free ds_read_b128; waves share nothing, so there are no barriers and a
+//     wave that stops to compact its candidate lists never stalls its neighbours;
 //   * scores above the user's threshold (rare once it has warmed up) are appended to a per-user
-//     candidate list in HBM scratch (LDS counters); when a list nears capacity the wave sorts it
-//     (register bitonic, 256 keys), drops train items, keeps the K best and raises the threshold;
+//     candidate list in HBM scratch (LDS counters, one atomic per lane and tile); once a list holds
+//     more than top_k + 32 entries the wave sorts it (register bitonic over 64/128/256 keys), drops
+//     train items (binary search in the CSR), keeps the K best and raises the threshold;
 //   * k order inside a dot product: the chain starts from the item bias (if any) and adds dims
 //     {t, 32+t} at MFMA step t, a fixed order (results are deterministic run to run, and differ from
 //     a CPU sgemm + bias add only in summation order).
@@ -41,16 +42,18 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
     return (static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo);
 }
 
-// Descending sort of 256 keys held 4 per lane; element index = e*64 + lane.
-__device__ __forceinline__ void wave_sort256_desc(uint64_t (&k)[4], int lane) {
+// Descending sort of 64*NR keys held NR per lane; element index = e*64 + lane.
+template <int NR>
+__device__ __forceinline__ void wave_sort_desc(uint64_t (&k)[NR], int lane) {
+    constexpr int N = 64 * NR;
 #pragma unroll
-    for (int kk = 2; kk <= 256; kk <<= 1) {
+    for (int kk = 2; kk <= N; kk <<= 1) {
 #pragma unroll
         for (int j = kk >> 1; j > 0; j >>= 1) {
             if (j >= 64) {
                 const int de = j >> 6;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < NR; ++e) {
                     if ((e & de) == 0) {
                         const int e2 = e | de;
                         const bool desc = (((e * 64) & kk) == 0);
@@ -62,7 +65,7 @@ __device__ __forceinline__ void wave_sort256_desc(uint64_t (&k)[4], int lane) {
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < NR; ++e) {
                     const bool desc = (((e * 64 + lane) & kk) == 0);
                     const bool low = ((lane & j) == 0);
                     const uint64_t a = k[e];
@@ -88,35 +91,36 @@ struct FusedArgs {
     uint64_t* cand;  // [ceil(B/64)*64][FE_CAP]
     int32_t* out_ids;
     float* out_scores;
+    int ablate;      // timing experiments only (SKR_FUSED_ABLATE): 1 = thresholds +inf (pure GEMM sweep)
+    int trigger;     // a list is compacted once it holds more than this many candidates (K <= trigger <= CAP-32)
 };
 
-// Sort user `ul`'s candidate list, drop train items, keep the best top_k at the front.
-// Returns the new threshold (score of the K-th best, or -inf while fewer than K are known).
-// If out_row >= 0 the final top_k ids / scores are also written to the outputs.
-__device__ __forceinline__ float compact_user(const FusedArgs& a, int lane, uint64_t* __restrict__ list, int* cnt_p,
-                                              int uid, int64_t out_row) {
-    __threadfence_block();  // this wave's earlier appends must have landed before they are re-read
-    const int n = *cnt_p;
-    uint64_t k[4];
+// Sort user `ul`'s candidate list (at most 64*NR entries), drop train items, keep the best top_k at
+// the front.  Returns the new threshold (score of the K-th best, or -inf while fewer than K are
+// known).  If out_row >= 0 the final top_k ids / scores are also written to the outputs.
+template <int NR>
+__device__ __forceinline__ float compact_user_n(const FusedArgs& a, int lane, uint64_t* __restrict__ list, int* cnt_p,
+                                                int n, int uid, int64_t out_row) {
+    uint64_t k[NR];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NR; ++e) {
         const int idx = e * 64 + lane;
         k[e] = (idx < n) ? list[idx] : SKR_KEY_MIN;
     }
     if (a.train_rowptr) {
         const int64_t rb = a.train_rowptr[uid], re = a.train_rowptr[uid + 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < NR; ++e)
             if (k[e] != SKR_KEY_MIN && skr::contains_sorted(a.train_items, rb, re, skr::key_id(k[e]))) k[e] = SKR_KEY_MIN;
     }
-    wave_sort256_desc(k, lane);
+    wave_sort_desc<NR>(k, lane);
     int valid = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) valid += __popcll(__ballot(k[e] != SKR_KEY_MIN));
+    for (int e = 0; e < NR; ++e) valid += __popcll(__ballot(k[e] != SKR_KEY_MIN));
     const int K = a.top_k;
     const int keep = valid < K ? valid : K;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {  // top_k <= 128: the survivors live in elements 0..127
+    for (int e = 0; e < 2 && e < NR; ++e) {  // top_k <= 128: the survivors live in elements 0..127
         const int idx = e * 64 + lane;
         if (idx < keep) {
             list[idx] = k[e];
@@ -130,175 +134,49 @@ __device__ __forceinline__ float compact_user(const FusedArgs& a, int lane, uint
     float thr = -INFINITY;
     if (keep == K) {
         const int src = (K - 1) & 63;
-        const uint64_t ke = ((K - 1) >> 6) ? k[1] : k[0];
+        const uint64_t ke = (NR > 1 && ((K - 1) >> 6)) ? k[NR > 1 ? 1 : 0] : k[0];
         const int lo = __shfl(static_cast<int>(static_cast<uint32_t>(ke)), src, 64);
         const int hi = __shfl(static_cast<int>(static_cast<uint32_t>(ke >> 32)), src, 64);
         thr = skr::key_score((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo));
     }
+    return thr;
+}
+
+__device__ __forceinline__ float compact_user(const FusedArgs& a, int lane, uint64_t* __restrict__ list, int* cnt_p,
+                                              int uid, int64_t out_row) {
+    __threadfence_block();  // this wave's earlier appends must have landed before they are re-read
+    const int n = *cnt_p;   // wave-uniform
+    float thr;
+    if (n <= 64 && a.top_k <= 64) thr = compact_user_n<1>(a, lane, list, cnt_p, n, uid, out_row);
+    else if (n <= 128) thr = compact_user_n<2>(a, lane, list, cnt_p, n, uid, out_row);
+    else thr = compact_user_n<4>(a, lane, list, cnt_p, n, uid, out_row);
     __threadfence_block();
     return thr;
 }
 
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel(FusedArgs a) {
-    __shared__ float4 s_tile[FE_WAVES][2][FE_TI * FE_D / 4];  // wave-private double buffer: 2 x 8 KB
-    __shared__ int s_cnt[FE_WAVES][FE_UW];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const int64_t wave_id = static_cast<int64_t>(blockIdx.x) * FE_WAVES + wv;
-    const int64_t ubase = wave_id * FE_UW;
-    if (ubase >= a.B) return;  // whole wave idle (no barriers are used anywhere in this kernel)
-    float4* tile0 = s_tile[wv][0];
-    float4* tile1 = s_tile[wv][1];
-    int* cnt = s_cnt[wv];
-    cnt[lane] = 0;
-
-    // ---- B fragments: user (32f + c), dims [32h, 32h+32) -> bf[f][t] = dim 32h + t -----------------
-    float bf[2][32];
-    float thr[2];
-    int uid[2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int64_t row = ubase + 32 * f + c;
-        const bool ok = row < a.B;
-        uid[f] = a.users[ok ? row : (a.B - 1)];
-        thr[f] = ok ? -INFINITY : INFINITY;  // padding columns never pass
-        const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid[f]) * FE_D + 32 * h);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 v = up[q];
-            bf[f][4 * q + 0] = v.x; bf[f][4 * q + 1] = v.y; bf[f][4 * q + 2] = v.z; bf[f][4 * q + 3] = v.w;
-        }
-    }
-    uint64_t* my_cand = a.cand + ubase * FE_CAP;
-
-    const int n_tiles = (a.n_items + FE_TI - 1) / FE_TI;
-    // global -> register prefetch of one tile: instruction j covers rows 4j..4j+3, lane l reads the
-    // 16-byte piece ((l&15) ^ (row&15)) of row 4j + (l>>4): full 256-byte lines, XOR-swizzled image.
-    // (macros, not lambdas: the 8 x float4 staging registers must stay in VGPRs)
-    float4 pf0, pf1, pf2, pf3, pf4, pf5, pf6, pf7;  // named scalars: an indexed array ends up in scratch
-#define FE_FETCH1(T, J, DST)                                                                              \
-    {                                                                                                      \
-        const int rl_ = 4 * (J) + (lane >> 4);                                                             \
-        int item_ = (T) * FE_TI + rl_;                                                                     \
-        item_ = item_ < a.n_items ? item_ : a.n_items - 1; /* clamp (masked in the epilogue) */            \
-        const int piece_ = (lane & 15) ^ (rl_ & 15);                                                       \
-        DST = *reinterpret_cast<const float4*>(a.item_table + static_cast<int64_t>(item_) * FE_D + 4 * piece_); \
-    }
-#define FE_FETCH(T)                                                                                    \
-    FE_FETCH1(T, 0, pf0) FE_FETCH1(T, 1, pf1) FE_FETCH1(T, 2, pf2) FE_FETCH1(T, 3, pf3) FE_FETCH1(T, 4, pf4) \
-        FE_FETCH1(T, 5, pf5) FE_FETCH1(T, 6, pf6) FE_FETCH1(T, 7, pf7)
-#define FE_STASH(TILE) /* linear image: row 4j+(l>>4), slot l&15 */                                     \
-    (TILE)[0 * 64 + lane] = pf0; (TILE)[1 * 64 + lane] = pf1; (TILE)[2 * 64 + lane] = pf2;               \
-    (TILE)[3 * 64 + lane] = pf3; (TILE)[4 * 64 + lane] = pf4; (TILE)[5 * 64 + lane] = pf5;               \
-    (TILE)[6 * 64 + lane] = pf6; (TILE)[7 * 64 + lane] = pf7;
-
-    FE_FETCH(0)
-    FE_STASH(tile0)
-
-    for (int t = 0; t < n_tiles; ++t) {
-        float4* cur = (t & 1) ? tile1 : tile0;
-        float4* nxt = (t & 1) ? tile0 : tile1;
-        const int tn = (t + 1 < n_tiles) ? t + 1 : t;  // the last iteration re-fetches its own tile (unused)
-        FE_FETCH(tn)
-        // ---- A fragment: item c, dims [32h, 32h+32): piece g = 8h+q sits in slot g ^ (c&15) ----------
-        float av[32];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 v = cur[c * 16 + ((8 * h + q) ^ (c & 15))];
-            av[4 * q + 0] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
-        }
-        // ---- accumulators start from the item bias (the fma chain's seed), so that the epilogue is a
-        //      bare compare: acc[r] = score(item tile_base + (r&3) + 8*(r>>2) + 4h, user 32f + c) -------
-        const int tile_base = t * FE_TI;
-        const bool full = (tile_base + FE_TI <= a.n_items);
-        f32x16 acc0 = {0};
-        if (HAS_BIAS) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int i0 = tile_base + 8 * g + 4 * h;
-                if (full) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(a.item_bias + i0);
-                    acc0[4 * g + 0] = b4.x; acc0[4 * g + 1] = b4.y; acc0[4 * g + 2] = b4.z; acc0[4 * g + 3] = b4.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc0[4 * g + e] = (i0 + e < a.n_items) ? a.item_bias[i0 + e] : 0.0f;
-                }
-            }
-        }
-        f32x16 acc1 = acc0;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bf[0][s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bf[1][s], acc1, 0, 0, 0);
-        }
-        bool appended = false;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const f32x16& acc = f ? acc1 : acc0;
-            uint32_t m = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m |= (acc[r] > thr[f]) ? (1u << r) : 0u;
-            if (!full) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (tile_base + (r & 3) + 8 * (r >> 2) + 4 * h >= a.n_items) m &= ~(1u << r);
-            }
-            if (m) {  // rare once the thresholds have warmed up
-                appended = true;
-                const int ul = 32 * f + c;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (m & (1u << r)) {
-                        const int item = tile_base + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const int p = atomicAdd(&cnt[ul], 1);  // < FE_CAP: see the compaction rule below
-                        my_cand[static_cast<int64_t>(ul) * FE_CAP + p] = skr::rank_key(acc[r], item);
-                    }
-                }
-            }
-        }
-        // ---- a list may take at most 32 new entries per tile: compact every list above CAP-32 -------
-        if (__any(appended)) {
-            uint64_t need = __ballot(cnt[lane] > FE_CAP - FE_TI);
-            while (need) {
-                const int ul = __ffsll(static_cast<long long>(need)) - 1;
-                need &= need - 1;
-                const int f = ul >> 5;
-                const int u_id = __shfl(f ? uid[1] : uid[0], ul & 31, 64);
-                const float nt = compact_user(a, lane, my_cand + static_cast<int64_t>(ul) * FE_CAP, &cnt[ul], u_id, -1);
-                if (c == (ul & 31)) {
-                    if (f) thr[1] = nt; else thr[0] = nt;
-                }
-            }
-        }
-        FE_STASH(nxt)
-    }
-#undef FE_FETCH
-#undef FE_FETCH1
-#undef FE_STASH
-    // ---- final ranking of every user of this wave ---------------------------------------------------
-    for (int ul = 0; ul < FE_UW; ++ul) {
-        const int64_t row = ubase + ul;
-        if (row >= a.B) break;
-        const int u_id = __shfl((ul >> 5) ? uid[1] : uid[0], ul & 31, 64);
-        compact_user(a, lane, my_cand + static_cast<int64_t>(ul) * FE_CAP, &cnt[ul], u_id, row);
-    }
-}
-
-
-// ================================================================================================
-// v2: same mapping, re-scheduled for one/two waves per SIMD.
-//   * item tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write,
-//     and the data's latency is covered by a whole 64-MFMA chain (the wait sits at the END of the
-//     iteration; in v1 hipcc hoisted the ds_writes -- and with them the vmcnt waits -- into the chain,
-//     which parked the wave for ~1950 cycles per tile: profiles/r01_eval_pmc.txt);
-//   * two accumulator sets: while tile t is multiplied, the any-score-above-threshold test of tile
-//     t-1 (64 v_cmp + scalar ORs, straight-line) sits in the same basic block and is interleaved
-//     with the MFMAs by the scheduler; the candidate path is entered only when some lane passed;
-//   * the item bias rides along through LDS (one 4-byte LDS-DMA per tile) and seeds the accumulators.
-// ================================================================================================
+// ------------------------------------------------------------------------------------------------
+// Building blocks of the sweep kernel
+// ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// LDS-DMA issued from inline asm: the compiler's waitcnt pass must not see it, otherwise it treats every
+// later ds_read as a possible reader of the DMA's destination and drains vmcnt(0) in front of it
+// (measured: the wave waited for the tile it had just requested, ~2000 cycles per tile).  The wait for
+// the DMA is placed by hand (FE2_WAIT) half a tile later.  M0 carries the wave-uniform LDS address;
+// the hardware adds lane * size.
+__device__ __forceinline__ void glds_b128(const void* gptr, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ void glds_b32(const void* gptr, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_addr)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(reinterpret_cast<uintptr_t>((lds_ptr_t)p))));
+}
 
 struct WaveCtx {
     int lane, c, h;
@@ -311,20 +189,45 @@ struct WaveCtx {
 // the lists that came within one tile of their capacity
 __device__ __forceinline__ void tile_candidates(const FusedArgs& a, const WaveCtx& w, const f32x16& acc0,
                                                 const f32x16& acc1, int tile_base, float (&thr)[2], const int (&uid)[2]) {
+    // which of this lane's 16 rows are real items (only the last, partial tile has holes)
+    uint32_t valid = 0xffffu;
+    if (tile_base + FE_TI > a.n_items) {
+        valid = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (tile_base + (r & 3) + 8 * (r >> 2) + 4 * w.h < a.n_items) valid |= 1u << r;
+    }
+    // one LDS atomic per lane and fragment reserves the slots of all its passing scores at once
+    uint32_t m[2];
+    int base[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const f32x16& acc = f ? acc1 : acc0;
-        const int ul = 32 * f + w.c;
+        uint32_t mm = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int item = tile_base + (r & 3) + 8 * (r >> 2) + 4 * w.h;
-            if (acc[r] > thr[f] && item < a.n_items) {
-                const int p = atomicAdd(&w.cnt[ul], 1);  // < FE_CAP by the compaction rule
-                w.my_cand[static_cast<int64_t>(ul) * FE_CAP + p] = skr::rank_key(acc[r], item);
+        for (int r = 0; r < 16; ++r) mm |= (acc[r] > thr[f]) ? (1u << r) : 0u;
+        m[f] = mm & valid;
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int n = __popc(m[f]);
+        base[f] = n ? atomicAdd(&w.cnt[32 * f + w.c], n) : 0;  // < FE_CAP by the compaction rule
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const f32x16& acc = f ? acc1 : acc0;
+        uint64_t* list = w.my_cand + static_cast<int64_t>(32 * f + w.c) * FE_CAP + base[f];
+        if (m[f]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (m[f] & (1u << r)) {
+                    const int item = tile_base + (r & 3) + 8 * (r >> 2) + 4 * w.h;
+                    list[__popc(m[f] & ((1u << r) - 1u))] = skr::rank_key(acc[r], item);
+                }
             }
         }
     }
-    uint64_t need = __ballot(w.cnt[w.lane] > FE_CAP - FE_TI);
+    uint64_t need = __ballot(w.cnt[w.lane] > a.trigger);
     while (need) {
         const int ul = __ffsll(static_cast<long long>(need)) - 1;
         need &= need - 1;
@@ -337,10 +240,40 @@ __device__ __forceinline__ void tile_candidates(const FusedArgs& a, const WaveCt
     }
 }
 
+// ================================================================================================
+// The sweep kernel.  History (profiles/r01_eval_history.txt): v1 staged tiles through registers
+// (50 % of FP32-MFMA peak: hipcc hoisted the ds_writes and their vmcnt waits into the MFMA chain);
+// v2 switched to LDS-DMA and a second accumulator set; this version pins every auxiliary instruction
+// into an MFMA gap.
+//   One tile = two chains of 16 "slots"; a slot is the two MFMAs (one per user fragment) of one k-step
+//   and owns a few independent instructions that issue while the matrix pipe is busy:
+//     chain 1 (k 0..15, operands avLo):  slot j < 8: LDS-DMA j of tile t+1 (scalar base + per-lane constant
+//                                        offset: no address arithmetic), slot 8: bias DMA, every slot: the
+//                                        threshold test of one accumulator row of tile t-1;
+//     chain 2 (k 16..31, operands avHi): slot 11: wait for the DMA, read avLo of tile t+1.
+//   avHi of tile t is read at the top of the step; the bias seeds the accumulators as the C operand of the
+//   first MFMA pair.  Only tiles whose successor is a full tile take this path; the last one or two tiles
+//   of a sweep (and catalogues smaller than 64 items) go through the generic step below.
+// ================================================================================================
+__device__ __forceinline__ void glds_b128_s(uint32_t voff, const void* sbase, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ void glds_b32_s(uint32_t voff, const void* sbase, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory", "m0");
+}
+
+#define FE2_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define FE3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0)
+#define FE3_PIN() __builtin_amdgcn_sched_barrier(0)
+
 template <bool HAS_BIAS>
-__global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v2(FusedArgs a) {
-    __shared__ float4 s_tile[FE_WAVES][2][FE_TI * FE_D / 4];  // wave-private double buffer: 2 x 8 KB
-    __shared__ float4 s_bias[FE_WAVES][2][16];                // 64 floats per buffer (32 used twice)
+__global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v3(FusedArgs a) {
+    __shared__ float4 s_tile0[FE_WAVES][FE_TI * FE_D / 4];  // wave-private, 8 KB per wave and buffer
+    __shared__ float4 s_tile1[FE_WAVES][FE_TI * FE_D / 4];
+    __shared__ float4 s_bias0[FE_WAVES][16];
+    __shared__ float4 s_bias1[FE_WAVES][16];
     __shared__ int s_cnt[FE_WAVES][FE_UW];
     WaveCtx w;
     w.lane = threadIdx.x & 63;
@@ -362,7 +295,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v2(FusedAr
         const int64_t row = w.ubase + 32 * f + c;
         const bool ok = row < a.B;
         uid[f] = a.users[ok ? row : (a.B - 1)];
-        thr[f] = ok ? -INFINITY : INFINITY;
+        thr[f] = (ok && a.ablate != 1) ? -INFINITY : INFINITY;
         const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid[f]) * FE_D + 32 * h);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -370,79 +303,140 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v2(FusedAr
             bf[f][4 * q + 0] = v.x; bf[f][4 * q + 1] = v.y; bf[f][4 * q + 2] = v.z; bf[f][4 * q + 3] = v.w;
         }
     }
+    // The B-fragment loads must be retired HERE: hipcc cannot see the hand-issued LDS-DMA below, so any
+    // counted `s_waitcnt vmcnt(N)` it would otherwise place inside the loop for these loads ends up
+    // waiting on the DMA instead (measured in the ISA: vmcnt(6..0) in the middle of the chains).
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int q = 0; q < 32; ++q) asm volatile("" : "+v"(bf[f][q]));
     const int n_tiles = (a.n_items + FE_TI - 1) / FE_TI;
+    const int n_full = a.n_items / FE_TI;
 
-    // LDS-DMA of tile T into buffer BUF: instruction j writes LDS bytes [j*1024, (j+1)*1024) = rows
-    // 4j..4j+3; lane l supplies the 16-byte piece ((l&15) ^ (row&15)) of row 4j + (l>>4).
-#define FE2_ISSUE(T, BUF)                                                                                    \
-    {                                                                                                        \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
-            const int rl_ = 4 * j + (lane >> 4);                                                             \
-            int item_ = (T) * FE_TI + rl_;                                                                   \
-            item_ = item_ < a.n_items ? item_ : a.n_items - 1;                                               \
-            const int piece_ = (lane & 15) ^ (rl_ & 15);                                                     \
-            __builtin_amdgcn_global_load_lds(                                                                \
-                (gbl_ptr_t)(a.item_table + static_cast<int64_t>(item_) * FE_D + 4 * piece_),                 \
-                (lds_ptr_t)(&s_tile[wv][BUF][j * 64]), 16, 0, 0);                                            \
-        }                                                                                                    \
-        if (HAS_BIAS) {                                                                                      \
-            int bi_ = (T) * FE_TI + (lane & 31);                                                             \
-            bi_ = bi_ < a.n_items ? bi_ : a.n_items - 1;                                                     \
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a.item_bias + bi_), (lds_ptr_t)(&s_bias[wv][BUF][0]), 4, 0, 0); \
-        }                                                                                                    \
+    // per-lane byte offset of DMA instruction j inside a tile (constant over the sweep) and LDS targets
+    uint32_t doff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int rl = 4 * j + (lane >> 4);
+        doff[j] = static_cast<uint32_t>((rl * FE_D + 4 * ((lane & 15) ^ (rl & 15))) * 4);
     }
-#define FE2_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+    const uint32_t boff = static_cast<uint32_t>((lane & 31) * 4);
+    const uint32_t lt0 = lds_addr_of(&s_tile0[wv][0]), lt1 = lds_addr_of(&s_tile1[wv][0]);
+    const uint32_t lb0 = lds_addr_of(&s_bias0[wv][0]), lb1 = lds_addr_of(&s_bias1[wv][0]);
 
-    // one tile: CUR accumulators <- tile T; fast test of the PREVious tile's accumulators meanwhile
-#define FE2_STEP(C0, C1, P0, P1, T)                                                                          \
-    {                                                                                                        \
-        const int t_ = (T);                                                                                  \
-        const int bc_ = t_ & 1;                                                                              \
-        if (t_ + 1 < n_tiles) FE2_ISSUE(t_ + 1, bc_ ^ 1)                                                     \
-        float av_[32];                                                                                       \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                      \
-            const float4 v_ = s_tile[wv][bc_][c * 16 + ((8 * h + q) ^ (c & 15))];                            \
-            av_[4 * q + 0] = v_.x; av_[4 * q + 1] = v_.y; av_[4 * q + 2] = v_.z; av_[4 * q + 3] = v_.w;      \
-        }                                                                                                    \
-        if (HAS_BIAS) {                                                                                      \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                  \
-                const float4 b4_ = s_bias[wv][bc_][2 * g + h];                                               \
-                C0[4 * g + 0] = b4_.x; C0[4 * g + 1] = b4_.y; C0[4 * g + 2] = b4_.z; C0[4 * g + 3] = b4_.w;  \
-            }                                                                                                \
-        } else {                                                                                             \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) C0[r] = 0.0f;                                     \
-        }                                                                                                    \
-        C1 = C0;                                                                                             \
-        bool any_ = false;                                                                                   \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) any_ |= (P0[r] > thr[0]) | (P1[r] > thr[1]);          \
-        _Pragma("unroll") for (int s = 0; s < 32; ++s) {                                                     \
-            C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[s], bf[0][s], C0, 0, 0, 0);                        \
-            C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[s], bf[1][s], C1, 0, 0, 0);                        \
-        }                                                                                                    \
-        if (__any(any_)) tile_candidates(a, w, P0, P1, (t_ - 1) * FE_TI, thr, uid);                          \
-        FE2_WAIT();                                                                                          \
+    // generic (clamped, per-lane pointer) DMA of tile T into LDS addresses LT / LB
+    auto issue_generic = [&](int T, uint32_t LT, uint32_t LB) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rl = 4 * j + (lane >> 4);
+            int item = T * FE_TI + rl;
+            item = item < a.n_items ? item : a.n_items - 1;
+            const int piece = (lane & 15) ^ (rl & 15);
+            glds_b128(a.item_table + static_cast<int64_t>(item) * FE_D + 4 * piece, LT + j * 1024);
+        }
+        if (HAS_BIAS) {
+            int bi = T * FE_TI + (lane & 31);
+            bi = bi < a.n_items ? bi : a.n_items - 1;
+            glds_b32(a.item_bias + bi, LB);
+        }
+    };
+#define FE3_READ_HALF(DST, TILEPTR, HALF)                                                       \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+        const float4 v_ = (TILEPTR)[c * 16 + ((8 * h + 4 * (HALF) + q) ^ (c & 15))];            \
+        DST[4 * q + 0] = v_.x; DST[4 * q + 1] = v_.y; DST[4 * q + 2] = v_.z; DST[4 * q + 3] = v_.w; \
+    }
+#define FE3_SEED(SEED, BIASPTR)                                                                 \
+    if (HAS_BIAS) {                                                                             \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                         \
+            const float4 b4_ = (BIASPTR)[2 * g + h];                                            \
+            SEED[4 * g + 0] = b4_.x; SEED[4 * g + 1] = b4_.y; SEED[4 * g + 2] = b4_.z; SEED[4 * g + 3] = b4_.w; \
+        }                                                                                       \
+    } else {                                                                                    \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) SEED[r] = 0.0f;                          \
+    }
+
+    // fast step: tile T (operands in CT/CB, avLo preloaded), successor T+1 is a FULL tile -> NT/NB
+#define FE3_FAST_STEP(C0, C1, P0, P1, T, CT, CB, NT, NB, LNT, LNB)                                       \
+    {                                                                                                    \
+        const int t_ = (T);                                                                              \
+        const char* nb_ = reinterpret_cast<const char*>(a.item_table) + static_cast<int64_t>(t_ + 1) * (FE_TI * FE_D * 4); \
+        const char* nbb_ = reinterpret_cast<const char*>(a.item_bias) + static_cast<int64_t>(t_ + 1) * (FE_TI * 4); \
+        f32x16 seed_;                                                                                    \
+        FE3_SEED(seed_, CB[wv])                                                                          \
+        FE3_READ_HALF(avHi, CT[wv], 1)                                                                   \
+        bool any_ = false;                                                                               \
+        FE3_PIN();                                                                                       \
+        _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) {                                              \
+            if (s_ == 0) {                                                                               \
+                C0 = FE3_MFMA(avLo[0], bf[0][0], seed_);                                                 \
+                C1 = FE3_MFMA(avLo[0], bf[1][0], seed_);                                                 \
+            } else {                                                                                     \
+                C0 = FE3_MFMA(avLo[s_], bf[0][s_], C0);                                                  \
+                C1 = FE3_MFMA(avLo[s_], bf[1][s_], C1);                                                  \
+            }                                                                                            \
+            if (s_ < 8) glds_b128_s(doff[s_], nb_, (LNT) + s_ * 1024);                                   \
+            if (HAS_BIAS && s_ == 8) glds_b32_s(boff, nbb_, (LNB));                                      \
+            any_ |= (P0[s_] > thr[0]) | (P1[s_] > thr[1]);                                               \
+            FE3_PIN();                                                                                   \
+        }                                                                                                \
+        _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) {                                              \
+            C0 = FE3_MFMA(avHi[s_], bf[0][16 + s_], C0);                                                 \
+            C1 = FE3_MFMA(avHi[s_], bf[1][16 + s_], C1);                                                 \
+            if (s_ == 11) {                                                                              \
+                FE2_WAIT();                                                                              \
+                FE3_READ_HALF(avLo, NT[wv], 0)                                                           \
+            }                                                                                            \
+            FE3_PIN();                                                                                   \
+        }                                                                                                \
+        if (__any(any_)) tile_candidates(a, w, P0, P1, (t_ - 1) * FE_TI, thr, uid);                      \
     }
 
     f32x16 accA, accB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accB[r] = -INFINITY;  // "tile -1": nothing passes
     f32x16 accA1 = accB, accB1 = accB;
-    FE2_ISSUE(0, 0)
+    float avLo[16], avHi[16];
+    issue_generic(0, lt0, lb0);
     FE2_WAIT();
     int t = 0;
-    for (; t + 1 < n_tiles; t += 2) {
-        FE2_STEP(accA, accA1, accB, accB1, t)
-        FE2_STEP(accB, accB1, accA, accA1, t + 1)
+    const int n_fast = n_full - 1;  // tiles 0 .. n_fast-1 have a full successor
+    if (n_fast >= 2) {
+        FE3_READ_HALF(avLo, s_tile0[wv], 0)
+        for (; t + 2 <= n_fast; t += 2) {  // even tiles: s_tile0 / accA, odd tiles: s_tile1 / accB
+            FE3_FAST_STEP(accA, accA1, accB, accB1, t, s_tile0, s_bias0, s_tile1, s_bias1, lt1, lb1)
+            FE3_FAST_STEP(accB, accB1, accA, accA1, t + 1, s_tile1, s_bias1, s_tile0, s_bias0, lt0, lb0)
+        }
     }
-    if (t < n_tiles) {  // odd tile count: the last tile lands in A
-        FE2_STEP(accA, accA1, accB, accB1, t)
-        tile_candidates(a, w, accA, accA1, t * FE_TI, thr, uid);
-    } else {
-        tile_candidates(a, w, accB, accB1, (n_tiles - 1) * FE_TI, thr, uid);
+    // generic tail (t is even here; tile t sits in buffer t & 1; previous tile's scores are in accB)
+    for (; t < n_tiles; ++t) {
+        const float4* ct = (t & 1) ? s_tile1[wv] : s_tile0[wv];
+        const float4* cb = (t & 1) ? s_bias1[wv] : s_bias0[wv];
+        if (t + 1 < n_tiles) issue_generic(t + 1, (t & 1) ? lt0 : lt1, (t & 1) ? lb0 : lb1);
+        f32x16 seed;
+        FE3_SEED(seed, cb)
+        FE3_READ_HALF(avLo, ct, 0)
+        FE3_READ_HALF(avHi, ct, 1)
+        accA = seed;
+        accA1 = seed;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            accA = FE3_MFMA(avLo[s], bf[0][s], accA);
+            accA1 = FE3_MFMA(avLo[s], bf[1][s], accA1);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            accA = FE3_MFMA(avHi[s], bf[0][16 + s], accA);
+            accA1 = FE3_MFMA(avHi[s], bf[1][16 + s], accA1);
+        }
+        if (t > 0) tile_candidates(a, w, accB, accB1, (t - 1) * FE_TI, thr, uid);
+        FE2_WAIT();
+        accB = accA;
+        accB1 = accA1;
     }
-#undef FE2_STEP
-#undef FE2_WAIT
-#undef FE2_ISSUE
+    tile_candidates(a, w, accB, accB1, (n_tiles - 1) * FE_TI, thr, uid);
+#undef FE3_FAST_STEP
+#undef FE3_SEED
+#undef FE3_READ_HALF
     for (int ul = 0; ul < FE_UW; ++ul) {
         const int64_t row = w.ubase + ul;
         if (row >= a.B) break;
@@ -478,22 +472,22 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     if (work_bytes < skr_eval_fused_workspace(B, top_k) || !d_work)
         return skr::fail(SKR_ENOMEM, "workspace too small: need %zu bytes", skr_eval_fused_workspace(B, top_k));
     FusedArgs a{d_user_table, d_users, B, d_item_table, d_item_bias, n_items, d_train_rowptr, d_train_items,
-                top_k, static_cast<uint64_t*>(d_work), d_topk_ids, d_topk_scores};
+                top_k, static_cast<uint64_t*>(d_work), d_topk_ids, d_topk_scores, 0, 0};
+    // compaction trigger: small lists keep the thresholds fresh (fewer candidate events per tile);
+    // a tile adds at most 32 entries per user, so trigger + 32 <= FE_CAP must hold
+    static const int trig_env = [] { const char* e = getenv("SKR_FUSED_TRIGGER"); return e ? atoi(e) : 0; }();
+    a.trigger = trig_env > 0 ? trig_env : top_k + 32;
+    if (a.trigger < top_k) a.trigger = top_k;
+    if (a.trigger > FE_CAP - FE_TI) a.trigger = FE_CAP - FE_TI;
+    static const int ablate = [] { const char* e = getenv("SKR_FUSED_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = ablate;
     const int64_t waves = (static_cast<int64_t>(B) + FE_UW - 1) / FE_UW;
     const unsigned blocks = static_cast<unsigned>((waves + FE_WAVES - 1) / FE_WAVES);
     hipStream_t st = skr::as_stream(stream);
-    static const int version = [] { const char* e = getenv("SKR_FUSED_V"); return e ? atoi(e) : 2; }();
-    if (version == 1) {
-        if (d_item_bias)
-            hipLaunchKernelGGL(fused_topk_kernel<true>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
-        else
-            hipLaunchKernelGGL(fused_topk_kernel<false>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
-    } else {
-        if (d_item_bias)
-            hipLaunchKernelGGL(fused_topk_kernel_v2<true>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
-        else
-            hipLaunchKernelGGL(fused_topk_kernel_v2<false>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
-    }
+    if (d_item_bias)
+        hipLaunchKernelGGL(fused_topk_kernel_v3<true>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
+    else
+        hipLaunchKernelGGL(fused_topk_kernel_v3<false>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

@@ -26,7 +26,7 @@ from ... import _hip
 __all__ = ["MetricReport", "RankingEvaluator", "EarlyStopping"]
 
 _HOST_MEAN_MAX = 1 << 18
-_FUSED_CHUNK = 1 << 17     # users per fused launch: 2 waves per SIMD on 256 CUs (256 MB of candidate scratch)
+_FUSED_CHUNK = 1 << 18     # users per fused launch (512 MB of candidate scratch): 4 workgroups per CU
 
 
 class MetricReport(object):
