@@ -214,11 +214,27 @@ def main():
                    "batch_per_gpu": b, "global_batch": b * world, "sharding": f"users u%{world}, item table replicated"
                    + (" + RCCL all-reduce of item grads per step" if world > 1 else "")},
     }
-    # ---- roofline of the dominant kernel (adam_kernel over the user table) -------------------------
+    # HBM traffic per launch comes from the rocprofv3 PMC passes of this same command (separate runs:
+    # tools/profile_bench.sh -> tools/summarize_profiles.py -> profiles/<round>_pmc_summary.json)
+    pmc = {}
+    try:
+        import glob
+        latest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")))[-1]
+        pmc = json.load(open(latest)).get("kernels", {})
+    except Exception:
+        pmc = {}
+
+    def pmc_traffic(prefix):
+        for name, ent in pmc.items():
+            if name.startswith(prefix) and "hbm_bytes_per_launch" in ent:
+                return ent["hbm_bytes_per_launch"]
+        return None
+    # ---- roofline of the dominant kernel (adam_kernel over the flat parameter buffer) ---------------
     adam_bytes = float(n_par) * 28.0           # 7 fp32 per parameter per step (p,g,m,v in; p,m,v out)
     ach = adam_bytes / (adam_ms * 1e-3) / 1e9
     out["roofline"] = {"kernel": "adam_kernel<true> (dense Adam over the flat [U|V|b] buffer, one launch per step)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": adam_ms,
+                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("adam_kernel") if world == 1 and args.users == 1_000_000 else None,
+                       "avg_launch_ms": adam_ms,
                        "algorithmic_bytes_per_launch": adam_bytes}
 
     # ---- eval leg: fused GEMM(MFMA)+mask+top-K over a block of this rank's users -------------------
@@ -261,7 +277,7 @@ def main():
         hr = (sums.cpu().numpy() / ne).reshape(2, args.top_k)[:, -1]
         out["eval"] = {"users_per_sec": ne * world / te, "users": ne * world, "top_k": args.top_k, "seconds": te,
                        f"HR@{args.top_k}": float(hr[0]), f"NDCG@{args.top_k}": float(hr[1])}
-        out["roofline_eval"] = {"kernel": "fused_topk_kernel (FP32 MFMA GEMM + mask + top-K)", "bound": "mfma",
+        out["roofline_eval"] = {"kernel": "fused_topk_kernel_v3 (FP32 MFMA GEMM + mask + top-K)", "bound": "mfma",
                                 "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                                 "traffic": None, "avg_launch_ms": k_ms, "algorithmic_flop_per_launch": flops}
 

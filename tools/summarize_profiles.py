@@ -1,0 +1,68 @@
+"""Condense the rocprofv3 CSVs that tools/profile_bench.sh / profile_eval.sh left under
+gpurun_out/prof_<tag>/ into the small, tracked files under profiles/."""
+import collections
+import csv
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0][:70]
+
+
+# 1. --kernel-trace --stats summary (top kernels)
+rows = list(csv.DictReader(open(f"{src}/stats_kernel_stats.csv")))
+with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline (MI355X)\n")
+    f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+    for r in rows[:25]:
+        f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+stats = {short(r["Name"]): r for r in rows}
+
+# 2. PMC passes: FETCH_SIZE / WRITE_SIZE per launch (KB), gfx950 correction: FETCH_SIZE x2 for wide
+#    coalesced streaming reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact for 16-B stores.
+pmc = {}
+for name in ("fetch", "write"):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f"{src}/{name}_counter_collection.csv")):
+        agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    pmc[name] = agg
+summary = {"tag": tag, "command": "python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline", "kernels": {}}
+for k in ("adam_kernel<true, 4, true>", "fused_topk_kernel_v3<true>", "bpr_step_kernel", "exact_assign_kernel",
+          "mt_generate_kernel"):
+    if k not in stats:
+        continue
+    fe, wr = pmc["fetch"].get(k, []), pmc["write"].get(k, [])
+    ent = {"calls": int(stats[k]["Calls"]), "avg_ns": float(stats[k]["AverageNs"])}
+    if fe and wr:
+        # for multi-size kernels (the eval kernel has a short warm-up launch) take the largest launch
+        fkb, wkb = (max(fe), max(wr)) if "fused" in k else (sum(fe) / len(fe), sum(wr) / len(wr))
+        ent.update(FETCH_SIZE_KB=fkb, WRITE_SIZE_KB=wkb, hbm_read_bytes=fkb * 1024 * 2, hbm_write_bytes=wkb * 1024,
+                   hbm_bytes_per_launch=fkb * 1024 * 2 + wkb * 1024,
+                   note="FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read stream)")
+    summary["kernels"][k] = ent
+
+# 3. eval kernel PMC (MFMA utilisation, clock)
+p = f"{src}/evalpmc_counter_collection.csv"
+if os.path.exists(p):
+    agg = collections.defaultdict(dict)
+    for r in csv.DictReader(open(p)):
+        if "fused_topk" in r["Kernel_Name"]:
+            d = agg[r["Dispatch_Id"]]
+            d[r["Counter_Name"]] = float(r["Counter_Value"])
+            d["dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            d["grid_threads"] = int(r["Grid_Size"])
+    big = max(agg.values(), key=lambda d: d["grid_threads"])
+    clk = big["GRBM_GUI_ACTIVE"] / 8 / (big["dur_us"] * 1e-6)
+    simd_cycles = big["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024
+    big["effective_clock_GHz"] = clk / 1e9
+    big["mfma_busy_fraction_at_effective_clock"] = simd_cycles / (big["GRBM_GUI_ACTIVE"] / 8)
+    summary["eval_pmc_largest_launch"] = big
+json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+print(json.dumps(summary, indent=1)[:3000])
