@@ -1,0 +1,97 @@
+"""CPU suite, part 4: the N > 1 path of bench.py on two gloo ranks -- user sharding u % N, the
+re-indexing of the shard's CSR, and the one exchange step (all-reduce of the replicated item
+table's gradient) reproduce the single-process gradients.  Kernels are replaced by the oracle's
+explicit-gradient maths here (no GPU); the collective and the sharding code are the real ones."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import bench
+from oracle import oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _toy(seed=0, nU=40, nI=30):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, 9, nU)
+    rowptr = np.zeros(nU + 1, np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    items = np.concatenate([np.sort(rng.choice(nI, l, replace=False)) for l in lens]).astype(np.int32)
+    users = np.repeat(np.arange(nU, dtype=np.int32), lens)
+    return dict(rowptr=torch.from_numpy(rowptr), users=torch.from_numpy(users), items=torch.from_numpy(items),
+                test_item=torch.arange(nU, dtype=torch.int32)), nU, nI
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full, nU, nI = _toy()
+    ds, mine = bench.shard(full, rank, world, torch.device("cpu"))
+    # shard bookkeeping: local row r is global user r*world + rank, rows keep their items
+    assert torch.equal(mine.long(), torch.arange(rank, nU, world))
+    g_rowptr, g_items = full["rowptr"].numpy(), full["items"].numpy()
+    l_rowptr, l_items, l_users = ds["rowptr"].numpy(), ds["items"].numpy(), ds["users"].numpy()
+    for r, u in enumerate(mine.tolist()):
+        assert np.array_equal(l_items[l_rowptr[r]:l_rowptr[r + 1]], g_items[g_rowptr[u]:g_rowptr[u + 1]])
+    assert np.array_equal(np.repeat(np.arange(len(mine)), np.diff(l_rowptr)), l_users)
+    # one data-parallel step: local BPR gradients, all-reduce of the item part only
+    rng = np.random.default_rng(1)
+    U = (rng.standard_normal((nU, 64)) * 0.1).astype(np.float32)       # same on both ranks
+    V = (rng.standard_normal((nI, 64)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(nI) * 0.1).astype(np.float32)
+    Ul = U[mine.numpy()]
+    neg = ((l_items + 7 + l_users) % nI).astype(np.int32)
+    _, _, gU, gV, gb, _, _ = O.bpr_batch(Ul, V, b, Ul, V, l_users, l_items, neg, 1.0, 1e-3, 1.0)
+    g_item = torch.from_numpy(np.concatenate([gV.reshape(-1), gb]))
+    dist.all_reduce(g_item)                                             # the path's one exchange step
+    out[rank] = (mine.numpy(), gU, g_item.numpy(), l_users, l_items, neg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        res = {k: out[k] for k in range(world)}
+    full, nU, nI = _toy()
+    rng = np.random.default_rng(1)
+    U = (rng.standard_normal((nU, 64)) * 0.1).astype(np.float32)
+    V = (rng.standard_normal((nI, 64)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(nI) * 0.1).astype(np.float32)
+    # the union of the two local batches, in global user ids
+    gu = np.concatenate([res[r][0][res[r][3]] for r in range(world)]).astype(np.int32)
+    gi = np.concatenate([res[r][4] for r in range(world)])
+    gj = np.concatenate([res[r][5] for r in range(world)])
+    _, _, gU, gV, gb, _, _ = O.bpr_batch(U, V, b, U, V, gu, gi, gj, 1.0, 1e-3, 1.0)
+    want_item = np.concatenate([gV.reshape(-1), gb])
+    for r in range(world):
+        np.testing.assert_allclose(res[r][2], want_item, rtol=1e-5, atol=1e-7)      # replicas agree
+        np.testing.assert_allclose(res[r][1], gU[res[r][0]], rtol=1e-5, atol=1e-7)  # user rows are local
+    assert np.array_equal(res[0][2], res[1][2])                                       # bit-identical replicas
+
+
+def test_fast_sampler_twin_is_shard_invariant():
+    """the slot-keyed sampler gives every (user, slot) the same negative however users are split"""
+    from fast_sampler_twin import sample_fast
+    from helpers import random_csr
+    rng = np.random.default_rng(4)
+    rowptr, pos = random_csr(rng, 60, 25, 0, 8)
+    whole = sample_fast(9, 2, 0, 25, rowptr, pos, 2)
+    cut_u = 23
+    cut = int(rowptr[cut_u])
+    lo = sample_fast(9, 2, 0, 25, rowptr[:cut_u + 1].copy(), pos[:cut].copy(), 2)
+    hi = sample_fast(9, 2, cut * 2, 25, (rowptr[cut_u:] - cut).copy(), pos[cut:].copy(), 2)
+    assert np.array_equal(np.concatenate([lo, hi]), whole)
