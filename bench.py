@@ -103,11 +103,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = max(torch.cuda.device_count(), 1)
+    local_dev = local_rank % n_dev           # one process per GPU; the modulo only matters for rehearsals on one card
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" is RCCL on ROCm.  SKR_DIST_BACKEND=gloo rehearses the N > 1 code path on a single-GPU box.
+        backend = os.environ.get("SKR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from skrec import _hip
     from skrec.utils.py.random import DeviceSampler
@@ -208,8 +215,9 @@ def main():
         "value": value, "unit": "train interactions/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: BPRMF d=64, synthetic 1M-user/100K-item/50M-interaction, "
-                               "exact-stream sampler + fused BPR step + dense Adam; eval = fused MFMA top-10",
+        "config": {"workload": f"BASELINE configs[1]: BPRMF d=64, synthetic {args.users}-user/{args.items}-item/"
+                               f"{args.interactions}-interaction (MovieLens-shaped), exact-stream sampler + fused BPR "
+                               f"step + dense Adam; eval = fused MFMA top-{args.top_k}",
                    "users": args.users, "items": args.items, "train_interactions": n_inter_total,
                    "batch_per_gpu": b, "global_batch": b * world, "sharding": f"users u%{world}, item table replicated"
                    + (" + RCCL all-reduce of item grads per step" if world > 1 else "")},

@@ -139,3 +139,19 @@ def test_layergcn_replays_reference(golden, tiny_dir, monkeypatch, tmp_path):
     np.testing.assert_allclose(m.out[:m.num_users].cpu().numpy(), g["Uf"], rtol=0, atol=6e-6)
     with pytest.raises(NotImplementedError):
         LayerGCN(_run_config(tiny_dir, "LayerGCN"), dict(dropout=0.1))
+
+
+def test_run_skrec_cli_drop_in(tiny_dir, tmp_path):
+    """the reference's command line (run_skrec.py --key value ...) drives a full fit() on the GPU"""
+    import subprocess
+    import sys
+    from conftest import REPO
+    import os
+    script = os.path.join(REPO, "scikit-recommender_amd", "run_skrec.py")
+    r = subprocess.run([sys.executable, script, "--recommender", "BPRMF", "--data_dir", tiny_dir, "--epochs", "2",
+                        "--batch_size", "256", "--top_k", "[5,10]", "--metric", "['Recall','NDCG']", "--seed", "7"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "epoch 1:" in r.stdout and "best:" in r.stdout and "Recall@5" in r.stdout
+    logs = list((tmp_path / "log").rglob("*.log"))
+    assert len(logs) == 1 and "NDCG@10" in logs[0].read_text()
