@@ -141,6 +141,13 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
                         int top_k, int32_t* d_topk_ids, float* d_topk_scores,
                         void* d_work, size_t work_bytes, void* stream);
 
+/* Dense score matrix of the predict() API surface (_MF.predict, BPRMF.py:84-88; _LightGCN.predict,
+ * LightGCN.py:102-107): d_scores[b, i] = <user_table[d_users[b]], item_table[i]> (+ d_item_bias[i]),
+ * fp32 fma chain in ascending k, bias added last.  The evaluator does not use it (it never needs
+ * the matrix); it exists so that predict() has no torch kernel behind it.  dim == 64. */
+int skr_score_matrix(const float* d_user_table, const int32_t* d_users, int B, const float* d_item_table,
+                     const float* d_item_bias, int n_items, int dim, float* d_scores, int64_t ld, void* stream);
+
 /* evaluator.py:197-200 on the device: d_scores[b, i] = -inf for every train item i of user
  * d_users[b] (generic path, when a foreign model hands over a dense [B, n_items] score matrix). */
 int skr_mask_train(float* d_scores, int B, int n_items, int64_t ld, const int32_t* d_users,

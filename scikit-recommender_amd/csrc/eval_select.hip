@@ -147,6 +147,35 @@ __global__ void mask_train_kernel(float* __restrict__ scores, int B, int n_items
     }
 }
 
+// dense scores[b, i] = <user_table[users[b]], item_table[i]> (+ bias[i]) for the predict() API surface
+// (BPRMF.py:84-88).  One wavefront per (user, 64-item strip): the user row is broadcast from LDS, every
+// lane owns one item row (64 sequential fp32 fmas, k ascending, bias added last like the reference).
+__global__ __launch_bounds__(256) void score_matrix_kernel(const float* __restrict__ user_table,
+                                                           const int32_t* __restrict__ users, int B,
+                                                           const float* __restrict__ item_table,
+                                                           const float* __restrict__ bias, int n_items,
+                                                           float* __restrict__ scores, int64_t ld) {
+    __shared__ float s_u[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y * 4 + wv;
+    const int item = blockIdx.x * 64 + lane;
+    if (b < B) s_u[wv][lane] = user_table[static_cast<int64_t>(users[b]) * 64 + lane];
+    __syncthreads();
+    if (b >= B || item >= n_items) return;
+    const float4* row = reinterpret_cast<const float4*>(item_table + static_cast<int64_t>(item) * 64);
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float4 v = row[q];
+        acc = fmaf(s_u[wv][4 * q + 0], v.x, acc);
+        acc = fmaf(s_u[wv][4 * q + 1], v.y, acc);
+        acc = fmaf(s_u[wv][4 * q + 2], v.z, acc);
+        acc = fmaf(s_u[wv][4 * q + 3], v.w, acc);
+    }
+    if (bias) acc += bias[item];
+    scores[static_cast<int64_t>(b) * ld + item] = acc;
+}
+
 int make_metric_args(const int* metric, int n_metric, skr::MetricArgs* out) {
     SKR_REQUIRE(metric && n_metric >= 1 && n_metric <= 8, "n_metric must be in [1, 8]");
     out->n_metric = n_metric;
@@ -193,6 +222,20 @@ int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
                        d_test_items, margs, skr::inv_log2_table(), top_k, o);
     SKR_LAUNCH_CHECK();
     if (d_sums) return skr::launch_colsum(d_rows, n_users, margs.n_metric * top_k, d_sums, st);
+    return SKR_OK;
+}
+
+int skr_score_matrix(const float* d_user_table, const int32_t* d_users, int B, const float* d_item_table,
+                     const float* d_item_bias, int n_items, int dim, float* d_scores, int64_t ld, void* stream) {
+    SKR_REQUIRE(d_user_table && d_users && d_item_table && d_scores, "skr_score_matrix: NULL argument");
+    SKR_REQUIRE(dim == 64, "skr_score_matrix: dim must be 64 (got %d)", dim);
+    SKR_REQUIRE(B >= 0 && n_items > 0 && ld >= n_items, "skr_score_matrix: bad shape");
+    if (B == 0) return SKR_OK;
+    dim3 grid(static_cast<unsigned>((n_items + 63) / 64), static_cast<unsigned>((B + 3) / 4));
+    SKR_REQUIRE(grid.y <= 65535, "skr_score_matrix: at most 262140 users per call");
+    hipLaunchKernelGGL(score_matrix_kernel, grid, dim3(256), 0, skr::as_stream(stream), d_user_table, d_users, B,
+                       d_item_table, d_item_bias, n_items, d_scores, ld);
+    SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
 

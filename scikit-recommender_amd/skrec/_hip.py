@@ -35,6 +35,7 @@ SIGNATURES = {
     "skr_eval_fused_workspace": (sz, [i32, i32]),
     "skr_eval_fused_topk": (i32, [vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, sz, vp]),
     "skr_mask_train": (i32, [vp, i32, i32, i64, vp, vp, vp, vp]),
+    "skr_score_matrix": (i32, [vp, vp, i32, vp, vp, i32, i32, vp, i64, vp]),
     "skr_rank_metrics": (i32, [vp, i32, i32, vp, vp, vp, C.POINTER(i32), i32, vp, vp, vp]),
     "skr_bpr_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "skr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, vp]),
@@ -105,6 +106,18 @@ def ptr(t):
         return t.ctypes.data
     assert t.is_contiguous(), "tensor must be contiguous"
     return t.data_ptr()
+
+
+def score_matrix(user_table, users, item_table, bias):
+    """predict() helper: dense [len(users), n_items] fp32 scores on the device (skr_score_matrix)"""
+    import torch
+    dev = user_table.device
+    du = torch.as_tensor(np.asarray(users, dtype=np.int32)).to(dev)
+    n_items = int(item_table.shape[0])
+    out = torch.empty((du.numel(), n_items), dtype=torch.float32, device=dev)
+    check(lib().skr_score_matrix(ptr(user_table), ptr(du), du.numel(), ptr(item_table), ptr(bias), n_items, 64, ptr(out),
+                                 n_items, stream()))
+    return out
 
 
 def metric_array(ids):

@@ -118,7 +118,4 @@ class BPRMF(AbstractRecommender):
     def predict(self, users) -> np.ndarray:
         """dense [len(users), num_items] scores (API surface of BPRMF.py:145-147; the evaluator uses
         the fused kernel through ``predict_factors`` instead)"""
-        users = torch.from_numpy(np.asarray(users)).long().to(self.device)
-        ratings = torch.matmul(self.user_embeddings[users], self.item_embeddings.T)
-        ratings += self.item_biases
-        return ratings.cpu().numpy()
+        return _hip.score_matrix(self.user_embeddings, users, self.item_embeddings, self.item_biases).cpu().numpy()

@@ -164,5 +164,4 @@ class LayerGCN(AbstractRecommender):
 
     def predict(self, users):
         self.forward()
-        users = torch.from_numpy(np.asarray(users)).long().to(self.device)
-        return torch.matmul(self.out[:self.num_users][users], self.out[self.num_users:].T).cpu().numpy()
+        return _hip.score_matrix(self.out[:self.num_users], users, self.out[self.num_users:], None).cpu().numpy()

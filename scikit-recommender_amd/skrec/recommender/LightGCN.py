@@ -222,5 +222,4 @@ class LightGCN(AbstractRecommender):
 
     def predict(self, users):
         uf, vf, _ = self.predict_factors()
-        users = torch.from_numpy(np.asarray(users)).long().to(self.device)
-        return torch.matmul(uf[users], vf.T).cpu().numpy()
+        return _hip.score_matrix(uf, users, vf, None).cpu().numpy()
