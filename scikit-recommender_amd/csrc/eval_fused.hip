@@ -476,7 +476,8 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     // compaction trigger: small lists keep the thresholds fresh (fewer candidate events per tile);
     // a tile adds at most 32 entries per user, so trigger + 32 <= FE_CAP must hold
     static const int trig_env = [] { const char* e = getenv("SKR_FUSED_TRIGGER"); return e ? atoi(e) : 0; }();
-    a.trigger = trig_env > 0 ? trig_env : top_k + 32;
+    // measured on MI355X (profiles/r01_eval_history.txt): K=10 is best around K+48, K>=50 at the cap
+    a.trigger = trig_env > 0 ? trig_env : 30 + 3 * top_k;
     if (a.trigger < top_k) a.trigger = top_k;
     if (a.trigger > FE_CAP - FE_TI) a.trigger = FE_CAP - FE_TI;
     static const int ablate = [] { const char* e = getenv("SKR_FUSED_ABLATE"); return e ? atoi(e) : 0; }();

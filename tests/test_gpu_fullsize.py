@@ -1,0 +1,107 @@
+"""GPU parity at BASELINE.json's full size (1 M users / 100 k items / ~48 M interactions) through
+size-independent properties and cross-checks between independent paths."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+U, I = 1_000_000, 100_000
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+    import bench
+    return bench.synth_dataset(U, I, 50_000_000, 20260101, torch.device("cuda", 0))
+
+
+def test_exact_epoch_full_size(big):
+    """(1) the prefix of the epoch equals the reference stream bit for bit (the stream is sequential,
+    so the first users' negatives do not depend on the rest); (2) no negative is a train positive of
+    its user, all in range; (3) words consumed = slots + rejections >= slots; (4) a second epoch
+    continues the stream (differs from the first)."""
+    import torch
+    from skrec.utils.py.random import DeviceSampler
+    rowptr, items = big["rowptr"], big["items"]
+    nnz = int(rowptr[-1])
+    s = DeviceSampler(2020)
+    neg = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    s.sample_epoch_exact(I, U, rowptr, items, nnz, 1, neg)
+    draws1 = s.draws
+    n_pref = 5000
+    rp = rowptr[:n_pref + 1].cpu().numpy()
+    want = O.Sampler(2020).sample_epoch(I, rp, items[:int(rp[-1])].cpu().numpy(), 1)
+    assert np.array_equal(neg[:len(want)].cpu().numpy(), want)
+    assert int(neg.min()) >= 0 and int(neg.max()) < I
+    key_pos = big["users"].long() * I + items.long()            # sorted by construction
+    key_neg = big["users"].long() * I + neg.long()
+    idx = torch.searchsorted(key_pos, key_neg).clamp(max=nnz - 1)
+    assert not bool((key_pos[idx] == key_neg).any())
+    assert nnz <= draws1 <= nnz * 1.01
+    neg2 = torch.empty_like(neg)
+    s.sample_epoch_exact(I, U, rowptr, items, nnz, 1, neg2)
+    assert s.draws > draws1 + nnz - 1 and float((neg2 != neg).float().mean()) > 0.99
+    # roughly uniform over the catalogue
+    hist = torch.bincount(neg.long(), minlength=I).float()
+    assert float(hist.std() / hist.mean()) < 0.1
+
+
+def test_fused_eval_full_size_against_independent_path(big):
+    """fused MFMA top-K over all 1 M users vs the dense path (skr_score_matrix -> skr_mask_train ->
+    skr_eval_scores) on a random sample of users: same ids except where fp32 summation order flips a
+    near-tie; every fused list is sorted, masked and duplicate-free; metric sums add up."""
+    import torch
+    from skrec import _hip
+    L = _hip.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(1)
+    Ut = torch.randn(U, 64, generator=g, device=dev) * 0.1
+    Vt = torch.randn(I, 64, generator=g, device=dev) * 0.1
+    bias = torch.randn(I, generator=g, device=dev) * 0.05
+    K = 10
+    rowptr, items = big["rowptr"], big["items"]
+    users = torch.arange(U, dtype=torch.int32, device=dev)
+    ids = torch.empty((U, K), dtype=torch.int32, device=dev)
+    sc = torch.empty((U, K), dtype=torch.float32, device=dev)
+    chunk = 1 << 18
+    ws = int(L.skr_eval_fused_workspace(chunk, K))
+    work = torch.empty(ws, dtype=torch.uint8, device=dev)
+    for s in range(0, U, chunk):
+        b = min(chunk, U - s)
+        _hip.check(L.skr_eval_fused_topk(_hip.ptr(Ut), _hip.ptr(users[s:s + b]), b, _hip.ptr(Vt), _hip.ptr(bias), I, 64,
+                                         _hip.ptr(rowptr), _hip.ptr(items), K, _hip.ptr(ids[s:s + b]), _hip.ptr(sc[s:s + b]),
+                                         _hip.ptr(work), ws, _hip.stream()))
+    torch.cuda.synchronize()
+    assert bool((sc[:, :-1] >= sc[:, 1:]).all())
+    assert int(ids.min()) >= 0 and int(ids.max()) < I
+    srt = torch.sort(ids, dim=1).values
+    assert not bool((srt[:, 1:] == srt[:, :-1]).any())                       # no duplicates in a list
+    key_pos = big["users"].long() * I + items.long()
+    key_top = (users.long()[:, None] * I + ids.long()).reshape(-1)
+    idx = torch.searchsorted(key_pos, key_top).clamp(max=len(key_pos) - 1)
+    assert not bool((key_pos[idx] == key_top).any())                         # train items never ranked
+    # independent dense path on a sample
+    sample = torch.randperm(U, generator=g, device=dev)[:2048].int().contiguous()
+    dense = _hip.score_matrix(Ut, sample.cpu().numpy(), Vt, bias)
+    _hip.check(L.skr_mask_train(_hip.ptr(dense), 2048, I, I, _hip.ptr(sample), _hip.ptr(rowptr), _hip.ptr(items), _hip.stream()))
+    ids2 = torch.empty((2048, K), dtype=torch.int32, device=dev)
+    _hip.check(L.skr_eval_scores(_hip.ptr(dense), 2048, I, I, None, None, None, 0, K, None, _hip.ptr(ids2), None, _hip.stream()))
+    torch.cuda.synchronize()
+    a, b2 = ids[sample.long()].cpu().numpy(), ids2.cpu().numpy()
+    agree = (a == b2).all(1)
+    assert agree.mean() > 0.97
+    sa, sb = sc[sample.long()].cpu().numpy(), np.take_along_axis(dense.cpu().numpy(), b2.astype(np.int64), 1)
+    np.testing.assert_allclose(sa, sb, rtol=2e-5, atol=2e-6)                 # even where ids swap, scores tie
+    for r in np.flatnonzero(~agree):
+        assert set(a[r]) == set(b2[r]) or abs(sa[r, -1] - sb[r, -1]) < 2e-6
+    # metrics: HR@10 from the fused lists == HR computed on the host from the same lists
+    test_ptr = torch.arange(U + 1, dtype=torch.long, device=dev)
+    rows = torch.empty((U, 2 * K), dtype=torch.float32, device=dev)
+    sums = torch.zeros(2 * K, dtype=torch.float64, device=dev)
+    _hip.check(L.skr_rank_metrics(_hip.ptr(ids), U, K, _hip.ptr(users), _hip.ptr(test_ptr), _hip.ptr(big["test_item"]),
+                                  _hip.metric_array([2, 4]), 2, _hip.ptr(rows), _hip.ptr(sums), _hip.stream()))
+    torch.cuda.synchronize()
+    hit = (ids == big["test_item"][:, None]).any(1).double().sum()
+    assert abs(float(sums[K - 1]) - float(hit)) < 0.5                        # Recall@10 == HR@10 on leave-one-out
+    np.testing.assert_allclose(sums.cpu().numpy(), rows.double().sum(0).cpu().numpy(), rtol=1e-9)
