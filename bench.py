@@ -172,14 +172,26 @@ def main():
                                       _hip.ptr(i), _hip.ptr(j), b, 1.0, 1e-3, 1.0, _hip.ptr(gU), _hip.ptr(gV),
                                       _hip.ptr(gb), _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(loss), _hip.ptr(touch),
                                       _hip.ptr(grad), st()))
-            if world > 1:   # the path's one exchange step: replicated item table => sum its gradients
-                dist.all_reduce(g_item)
             run_slice.t += 1
-            if events is not None:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-            _hip.check(L.skr_adam_step(_hip.ptr(flat), _hip.ptr(grad), _hip.ptr(m1), _hip.ptr(m2), n_par, 1e-3, 0.9, 0.999,
-                                       1e-8, run_slice.t, 1, _hip.ptr(touch), st()))
+            if world > 1:
+                # the path's one exchange step: replicated item table => sum its gradients over xGMI.
+                # It runs on RCCL's stream while Adam sweeps the (local) user part of the flat buffer.
+                work = dist.all_reduce(g_item, async_op=True)
+                nu_ = nU * D
+                _hip.check(L.skr_adam_step(_hip.ptr(flat), _hip.ptr(grad), _hip.ptr(m1), _hip.ptr(m2), nu_, 1e-3, 0.9,
+                                           0.999, 1e-8, run_slice.t, 1, _hip.ptr(touch), st()))
+                work.wait()
+                if events is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                _hip.check(L.skr_adam_step(_hip.ptr(flat[nu_:]), _hip.ptr(grad[nu_:]), _hip.ptr(m1[nu_:]), _hip.ptr(m2[nu_:]),
+                                           n_par - nu_, 1e-3, 0.9, 0.999, 1e-8, run_slice.t, 1, _hip.ptr(touch[nU:]), st()))
+            else:
+                if events is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                _hip.check(L.skr_adam_step(_hip.ptr(flat), _hip.ptr(grad), _hip.ptr(m1), _hip.ptr(m2), n_par, 1e-3, 0.9,
+                                           0.999, 1e-8, run_slice.t, 1, _hip.ptr(touch), st()))
             if events is not None:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
@@ -238,7 +250,9 @@ def main():
                 return ent["hbm_bytes_per_launch"]
         return None
     # ---- roofline of the dominant kernel (adam_kernel over the flat parameter buffer) ---------------
-    adam_bytes = float(n_par) * 28.0           # 7 fp32 per parameter per step (p,g,m,v in; p,m,v out)
+    # 7 fp32 per parameter per step (p,g,m,v in; p,m,v out).  For N > 1 the timed launch is the
+    # replicated [V | b] part (the user part overlaps the all-reduce and is not bracketed by the events).
+    adam_bytes = float(n_par if world == 1 else n_par - nU * D) * 28.0
     ach = adam_bytes / (adam_ms * 1e-3) / 1e9
     out["roofline"] = {"kernel": "adam_kernel<true> (dense Adam over the flat [U|V|b] buffer, one launch per step)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("adam_kernel") if world == 1 and args.users == 1_000_000 else None,

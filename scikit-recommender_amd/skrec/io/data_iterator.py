@@ -84,12 +84,22 @@ def _n_batches(n, batch_size, drop_last):
     return n // batch_size if drop_last else (n + batch_size - 1) // batch_size
 
 
-def _device_batches(columns, batch_size, shuffle, drop_last):
-    """Shuffle whole epoch columns once on the device, then yield consecutive slices."""
+def _device_batches(columns, batch_size, shuffle, drop_last, device_shuffle=False):
+    """Shuffle whole epoch columns once on the device, then yield consecutive slices.
+    Default: the reference's contract -- ONE np.random.permutation(n) from numpy's global generator per
+    epoch (batch_iterator.py:61-63), uploaded.  ``device_shuffle=True`` draws the
+    permutation on the GPU instead; numpy's global generator still seeds it (one integer per epoch), so
+    ``np.random.seed`` keeps runs reproducible, but the order differs from the reference's."""
     import torch
     n = columns[0].shape[0]
     if shuffle:
-        perm = torch.from_numpy(np.random.permutation(n)).to(columns[0].device)
+        dev = columns[0].device
+        if device_shuffle:
+            g = torch.Generator(device=dev)
+            g.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
+            perm = torch.randperm(n, generator=g, device=dev)
+        else:
+            perm = torch.from_numpy(np.random.permutation(n)).to(dev)
         columns = [c.index_select(0, perm) for c in columns]
     for start in range(0, n, batch_size):
         stop = min(start + batch_size, n)
@@ -103,9 +113,10 @@ class PairwiseIterator(object):
     (reference: data_iterator.py:191-234)."""
 
     def __init__(self, dataset: ImplicitFeedback, num_neg: int = 1, batch_size: int = 1024, shuffle: bool = True,
-                 drop_last: bool = False, sampler_mode: str = None, seed: int = 2020):
+                 drop_last: bool = False, sampler_mode: str = None, seed: int = 2020, device_shuffle: bool = False):
         self._s = _EpochSampler(dataset, num_neg, sampler_mode, seed)
         self.batch_size, self.shuffle, self.drop_last, self.num_neg = batch_size, shuffle, drop_last, num_neg
+        self.device_shuffle = device_shuffle
         self.num_items = self._s.num_items
         self.user_n_pos = self._s.user_n_pos
         self.all_users, self.pos_items = self._s.users_ary, self._s.pos_items
@@ -117,7 +128,8 @@ class PairwiseIterator(object):
         neg = self._s.sample()
         if self.num_neg > 1:
             neg = neg.view(-1, self.num_neg)
-        return _device_batches([self._s.d_users, self._s.d_pos, neg], self.batch_size, self.shuffle, self.drop_last)
+        return _device_batches([self._s.d_users, self._s.d_pos, neg], self.batch_size, self.shuffle, self.drop_last,
+                               self.device_shuffle)
 
     def __iter__(self):
         for u, i, j in self.iter_device():

@@ -7,7 +7,12 @@ loss = sum_b -log sigmoid(x_ui - x_uj) + reg * 0.5 * ||ego rows||^2 (:231, :242,
 constant learning rate (the LambdaLR factor is 1.0 ** (epoch / 50), :274-276).
 ``skr_csr_spmm`` does the propagation, ``skr_layer_refine_fwd/_bwd`` the cosine re-weighting and its
 hand-derived backward; A is symmetric so the backward propagation is the same kernel.
-Edge dropout (``dropout > 0``, :133-152) is not implemented yet.
+Edge dropout (``dropout > 0``, :133-152): once per epoch a fraction of the edges is pruned --
+alternately by degree-weighted sampling without replacement (``torch.multinomial`` of the normalised
+edge values, first epoch) and uniformly at random -- and the kept graph is re-normalised; training
+uses the pruned adjacency, evaluation the full one.  The pruning draws come from torch's device
+generator, so they match the reference in law, not bit for bit (the reference's own draws differ
+between its CPU and CUDA runs as well).
 """
 from typing import Dict
 
@@ -66,14 +71,20 @@ class LayerGCN(AbstractRecommender):
         self.num_users, self.num_items = self.dataset.num_users, self.dataset.num_items
         if cfg.embed_dim != 64:
             raise NotImplementedError("the MI355X kernels are specialised for embed_dim=64")
-        if cfg.dropout > 0.0:
-            raise NotImplementedError("LayerGCN edge dropout is not implemented yet (dropout must be 0.0)")
+        if not 0.0 <= cfg.dropout < 1.0:
+            raise ValueError("dropout must be in [0, 1)")
         self.device = _hip.require_gpu()
         inter = self.dataset.train_data.to_coo_matrix().astype(np.float32)
         # parameters first, like _LayerGCN.__init__ (:114-115): xavier_uniform on plain tensors
         ue = nn.init.xavier_uniform_(torch.empty(self.num_users, cfg.embed_dim))
         ie = nn.init.xavier_uniform_(torch.empty(self.num_items, cfg.embed_dim))
         self.adj = DeviceCSR(build_layergcn_adjacency(inter, self.num_users, self.num_items), self.device)
+        self.train_adj = self.adj                       # masked_adj of the reference (LayerGCN.py:119,135)
+        self.pruning_random = False                     # LayerGCN.py:121
+        # edge list + normalised edge values for the pruning step (get_edge_info, LayerGCN.py:165-171)
+        self._edge_u = torch.from_numpy(np.asarray(inter.row, dtype=np.int64)).to(self.device)
+        self._edge_i = torch.from_numpy(np.asarray(inter.col, dtype=np.int64)).to(self.device)
+        self._edge_values = self._normalize_edges(self._edge_u, self._edge_i)
         N = self.num_users + self.num_items
         self.ego = torch.cat([ue, ie], dim=0).to(self.device).contiguous()
         self.optimizer = DenseAdam(self.ego.view(-1), lr=cfg.lr)
@@ -97,13 +108,40 @@ class LayerGCN(AbstractRecommender):
     def item_embeddings(self):
         return self.ego[self.num_users:]
 
-    def forward(self):
+    def _normalize_edges(self, u, i):
+        """_normalize_adj_m (LayerGCN.py:154-163): 1/sqrt((deg_u + 1e-7)(deg_i + 1e-7)) on the given edges"""
+        ones = torch.ones(u.numel(), dtype=torch.float32, device=u.device)
+        row_sum = 1e-7 + torch.zeros(self.num_users, device=u.device).index_add_(0, u, ones)
+        col_sum = 1e-7 + torch.zeros(self.num_items, device=u.device).index_add_(0, i, ones)
+        return torch.pow(row_sum, -0.5)[u] * torch.pow(col_sum, -0.5)[i]
+
+    def pre_epoch_processing(self):
+        """edge pruning, once per epoch (LayerGCN.py:133-152); a no-op when dropout == 0"""
+        if self.config.dropout <= 0.0:
+            self.train_adj = self.adj
+            return
+        n_edges = self._edge_values.numel()
+        keep_len = int(n_edges * (1.0 - self.config.dropout))
+        if self.pruning_random:
+            keep = torch.randperm(n_edges, device=self.device)[:keep_len]
+        else:   # prune edges of high-degree nodes preferentially: keep ~ normalised edge value
+            keep = torch.multinomial(self._edge_values, keep_len)
+        self.pruning_random = True ^ self.pruning_random
+        u, i = self._edge_u[keep], self._edge_i[keep]
+        vals = self._normalize_edges(u, i)
+        n = self.num_users + self.num_items
+        rows = torch.cat([u, i + self.num_users])
+        cols = torch.cat([i + self.num_users, u])
+        self.train_adj = DeviceCSR.from_device_coo(rows, cols, torch.cat([vals, vals]), n)
+
+    def forward(self, adj=None):
         L, st = _hip.lib(), _hip.stream()
         N = self.ego.shape[0]
+        adj = adj if adj is not None else self.adj
         self.out.zero_()
         x = self.ego
         for k in range(self.config.n_layers):
-            self.adj.spmm(x, self._y[k])
+            adj.spmm(x, self._y[k])
             zk = self._z[k & 1]
             _hip.check(L.skr_layer_refine_fwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), N, 64, _hip.ptr(zk),
                                               _hip.ptr(self._w[k]), _hip.ptr(self.out), st))
@@ -114,7 +152,8 @@ class LayerGCN(AbstractRecommender):
         cfg, nu = self.config, self.num_users
         L, st = _hip.lib(), _hip.stream()
         N = self.ego.shape[0]
-        self.forward()
+        adj = self.train_adj
+        self.forward(adj)
         gO, gE = self._g_out, self._g_ego
         gO.zero_()
         _hip.check(L.skr_bpr_step(
@@ -129,10 +168,10 @@ class LayerGCN(AbstractRecommender):
             _hip.check(L.skr_layer_refine_bwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), _hip.ptr(self._w[k]),
                                               _hip.ptr(dz), N, 64, _hip.ptr(dy), _hip.ptr(gE), st))
             if k > 0:
-                self.adj.spmm(dy, tmp, addend=gO)
+                adj.spmm(dy, tmp, addend=gO)
                 dz = tmp
             else:
-                self.adj.spmm(dy, tmp, accum=gE, accum_scale=1.0)
+                adj.spmm(dy, tmp, accum=gE, accum_scale=1.0)
         self.optimizer.step()
 
     def train_epoch(self, data_iter):
@@ -146,6 +185,7 @@ class LayerGCN(AbstractRecommender):
         self.logger.info("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
         early_stopping = EarlyStopping(metric="NDCG@10", patience=self.config.early_stop)
         for epoch in range(self.config.epochs):
+            self.pre_epoch_processing()
             self.train_epoch(data_iter)
             cur_result = self.evaluate()
             self.logger.info(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")

@@ -70,6 +70,24 @@ class DeviceCSR(object):
             self.col = torch.zeros(1, dtype=torch.int32, device=device)
             self.val = torch.zeros(1, dtype=torch.float32, device=device)
 
+    @classmethod
+    def from_device_coo(cls, rows, cols, vals, n_rows):
+        """build from int64 row / col and fp32 value tensors already in HBM (entries must be unique)"""
+        self = cls.__new__(cls)
+        key = rows * n_rows + cols
+        order = torch.argsort(key)
+        rows, cols, vals = rows[order], cols[order], vals[order]
+        self.shape = (n_rows, n_rows)
+        self.nnz = int(rows.numel())
+        self.rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=rows.device)
+        self.rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n_rows), 0)
+        self.col = cols.int().contiguous()
+        self.val = vals.float().contiguous()
+        if self.nnz == 0:
+            self.col = torch.zeros(1, dtype=torch.int32, device=rows.device)
+            self.val = torch.zeros(1, dtype=torch.float32, device=rows.device)
+        return self
+
     def spmm(self, X, Y, addend=None, accum=None, accum_scale=1.0):
         """Y = A @ X (+ addend); accum += accum_scale * Y"""
         _hip.check(_hip.lib().skr_csr_spmm(self.shape[0], _hip.ptr(self.rowptr), _hip.ptr(self.col), _hip.ptr(self.val),

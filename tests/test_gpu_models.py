@@ -137,8 +137,40 @@ def test_layergcn_replays_reference(golden, tiny_dir, monkeypatch, tmp_path):
     np.testing.assert_allclose(m.user_embeddings.cpu().numpy(), g["U1"], rtol=0, atol=3e-6)
     m.forward()
     np.testing.assert_allclose(m.out[:m.num_users].cpu().numpy(), g["Uf"], rtol=0, atol=6e-6)
-    with pytest.raises(NotImplementedError):
-        LayerGCN(_run_config(tiny_dir, "LayerGCN"), dict(dropout=0.1))
+
+
+def test_layergcn_edge_dropout(golden, tiny_dir, monkeypatch, tmp_path):
+    """dropout > 0 (LayerGCN.py:133-152): kept-edge count, re-normalisation on the kept graph, symmetry,
+    the multinomial / uniform alternation, and a fit() that runs on the pruned graph while evaluation
+    keeps the full one.  (The draws themselves are matched in law only -- see the module docstring.)"""
+    import torch
+    from skrec.recommender.LayerGCN import LayerGCN
+    monkeypatch.chdir(tmp_path)
+    _seed()
+    m = LayerGCN(_run_config(tiny_dir, "LayerGCN"), dict(dropout=0.25, batch_size=256, epochs=2, n_layers=2))
+    E = m._edge_values.numel()
+    full_nnz = m.adj.nnz
+    assert m.pruning_random is False
+    m.pre_epoch_processing()
+    assert m.pruning_random is True and m.train_adj is not m.adj
+    keep = int(E * 0.75)
+    assert m.train_adj.nnz == 2 * keep and m.adj.nnz == full_nnz == 2 * E
+    rp, col, val = (t.cpu().numpy() for t in (m.train_adj.rowptr, m.train_adj.col, m.train_adj.val))
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    nU = m.num_users
+    upper = rows < nU                                                   # (user, item + nU) half
+    deg_u = np.bincount(rows[upper], minlength=nU) + 1e-7
+    deg_i = np.bincount(col[upper] - nU, minlength=m.num_items) + 1e-7
+    np.testing.assert_allclose(val[upper], (deg_u[rows[upper]] * deg_i[col[upper] - nU]) ** -0.5, rtol=1e-5)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((val, col, rp), shape=(len(rp) - 1,) * 2)
+    assert abs(A - A.T).max() < 1e-7
+    m.pre_epoch_processing()
+    assert m.pruning_random is False and m.train_adj.nnz == 2 * keep
+    best = m.fit()
+    assert np.isfinite(list(best.values())).all() and np.isfinite(m.step_losses.cpu().numpy()).all()
+    with pytest.raises(ValueError):
+        LayerGCN(_run_config(tiny_dir, "LayerGCN"), dict(dropout=1.5))
 
 
 def test_run_skrec_cli_drop_in(tiny_dir, tmp_path):
