@@ -1,20 +1,17 @@
-from .generic import OrderedDefaultDict
-from .generic import pad_sequences
-from .generic import md5sum
-from .generic import slugify
-
+"""Host-side utilities of the drop-in package.  The names exported here are the ones the reference's
+models import from ``skrec.utils.py`` (reference: skrec/utils/py/__init__.py:4-23)."""
 from .batch_iterator import BatchIterator
+from .config import Config, ModelConfig, merge_config_with_cmd_args
+from .decorator import timer, typeassert
+from .evaluator import EarlyStopping, MetricReport, RankingEvaluator
+from .generic import OrderedDefaultDict, md5sum, pad_sequences, slugify
+from .random import batch_randint_choice, randint_choice
 
-from .decorator import timer
-from .decorator import typeassert
-
-from .random import randint_choice
-from .random import batch_randint_choice
-
-from .evaluator import RankingEvaluator
-from .evaluator import MetricReport
-from .evaluator import EarlyStopping
-
-from .config import Config
-from .config import ModelConfig
-from .config import merge_config_with_cmd_args
+__all__ = [
+    "BatchIterator",
+    "Config", "ModelConfig", "merge_config_with_cmd_args",
+    "EarlyStopping", "MetricReport", "RankingEvaluator",
+    "OrderedDefaultDict", "md5sum", "pad_sequences", "slugify",
+    "batch_randint_choice", "randint_choice",
+    "timer", "typeassert",
+]

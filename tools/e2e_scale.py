@@ -59,15 +59,23 @@ from skrec.io import PairwiseIterator  # noqa: E402
 t0 = time.time()
 it = PairwiseIterator(model.dataset.train_data, batch_size=args.batch, shuffle=True, sampler_mode=args.sampler)
 print(f"[e2e] iterator constructed in {time.time() - t0:.1f}s ({len(it)} steps/epoch)", flush=True)
+ap_steps = int(os.environ.get("E2E_MAX_STEPS", "0"))
+if ap_steps:   # graph models re-propagate the whole graph every step: time a bounded number of steps
+    import itertools
+    orig_iter = it.iter_device
+    it.iter_device = lambda: itertools.islice(orig_iter(), ap_steps)
+    it.__class__.__len__ = lambda self: ap_steps
 for ep in range(args.epochs):
     torch.cuda.synchronize()
     t0 = time.time()
+    if hasattr(model, "pre_epoch_processing"):
+        model.pre_epoch_processing()
     model.train_epoch(it)
     torch.cuda.synchronize()
     t1 = time.time()
     rep = model.evaluate()
     torch.cuda.synchronize()
     t2 = time.time()
-    n = len(it.all_users)
+    n = len(it.all_users) if not ap_steps else ap_steps * args.batch
     print(f"[e2e] epoch {ep}: train {t1 - t0:.2f}s = {n / (t1 - t0) / 1e6:.2f} M interactions/s; "
           f"eval {t2 - t1:.2f}s = {args.users / (t2 - t1) / 1e6:.2f} M users/s; {rep.values_str}", flush=True)
