@@ -166,36 +166,43 @@ def main():
         uu = sl["users"].index_select(0, perm).contiguous()
         ii = sl["items"].index_select(0, perm).contiguous()
         jj = neg.index_select(0, perm).contiguous()
+        # host side of a step = three ctypes calls on cached integer addresses (no tensor slicing, no
+        # data_ptr() calls): keeps the launch rate above the kernel rate also at N = 8
+        pu, pi, pj = uu.data_ptr(), ii.data_ptr(), jj.data_ptr()
+        stream = st()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)] \
+            if events is not None else None
         for s in range(n_steps):
-            u, i, j = uu[s * b:(s + 1) * b], ii[s * b:(s + 1) * b], jj[s * b:(s + 1) * b]
-            _hip.check(L.skr_bpr_step(_hip.ptr(U), _hip.ptr(V), _hip.ptr(bias), _hip.ptr(U), _hip.ptr(V), _hip.ptr(u),
-                                      _hip.ptr(i), _hip.ptr(j), b, 1.0, 1e-3, 1.0, _hip.ptr(gU), _hip.ptr(gV),
-                                      _hip.ptr(gb), _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(loss), _hip.ptr(touch),
-                                      _hip.ptr(grad), st()))
+            o = s * b * 4
+            rc = L.skr_bpr_step(P["U"], P["V"], P["bias"], P["U"], P["V"], pu + o, pi + o, pj + o, b, 1.0, 1e-3, 1.0,
+                                P["gU"], P["gV"], P["gb"], P["gU"], P["gV"], P["loss"], P["touch"], P["grad"], stream)
             run_slice.t += 1
             if world > 1:
                 # the path's one exchange step: replicated item table => sum its gradients over xGMI.
                 # It runs on RCCL's stream while Adam sweeps the (local) user part of the flat buffer.
                 work = dist.all_reduce(g_item, async_op=True)
-                nu_ = nU * D
-                _hip.check(L.skr_adam_step(_hip.ptr(flat), _hip.ptr(grad), _hip.ptr(m1), _hip.ptr(m2), nu_, 1e-3, 0.9,
-                                           0.999, 1e-8, run_slice.t, 1, _hip.ptr(touch), st()))
+                rc |= L.skr_adam_step(P["flat"], P["grad"], P["m1"], P["m2"], n_user_par, 1e-3, 0.9, 0.999, 1e-8,
+                                      run_slice.t, 1, P["touch"], stream)
                 work.wait()
-                if events is not None:
-                    e0 = torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                _hip.check(L.skr_adam_step(_hip.ptr(flat[nu_:]), _hip.ptr(grad[nu_:]), _hip.ptr(m1[nu_:]), _hip.ptr(m2[nu_:]),
-                                           n_par - nu_, 1e-3, 0.9, 0.999, 1e-8, run_slice.t, 1, _hip.ptr(touch[nU:]), st()))
+                if ev is not None:
+                    ev[s][0].record()
+                rc |= L.skr_adam_step(P["flat"] + 4 * n_user_par, P["grad"] + 4 * n_user_par, P["m1"] + 4 * n_user_par,
+                                      P["m2"] + 4 * n_user_par, n_par - n_user_par, 1e-3, 0.9, 0.999, 1e-8, run_slice.t, 1,
+                                      P["touch"] + nU, stream)
             else:
-                if events is not None:
-                    e0 = torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                _hip.check(L.skr_adam_step(_hip.ptr(flat), _hip.ptr(grad), _hip.ptr(m1), _hip.ptr(m2), n_par, 1e-3, 0.9,
-                                           0.999, 1e-8, run_slice.t, 1, _hip.ptr(touch), st()))
-            if events is not None:
-                e1 = torch.cuda.Event(enable_timing=True)
-                e1.record()
-                events.append((e0, e1))
+                if ev is not None:
+                    ev[s][0].record()
+                rc |= L.skr_adam_step(P["flat"], P["grad"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, run_slice.t, 1,
+                                      P["touch"], stream)
+            if ev is not None:
+                ev[s][1].record()
+            if rc:
+                _hip.check(rc)
+        if events is not None:
+            events.extend(ev)
+    n_user_par = nU * D
+    P = {k: t.data_ptr() for k, t in dict(U=U, V=V, bias=bias, gU=gU, gV=gV, gb=gb, loss=loss, touch=touch, grad=grad,
+                                          flat=flat, m1=m1, m2=m2).items()}
     run_slice.t = 0
 
     def barrier():

@@ -90,9 +90,23 @@ class BPRMF(AbstractRecommender):
         self.optimizer.step()
 
     def train_epoch(self, data_iter):
+        """one epoch; the per-step host work is two ctypes calls on cached addresses"""
         self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
+        L, st, opt = _hip.lib(), _hip.stream(), self.optimizer
+        gU, gV, gb = self._grads
+        pU, pV, pb = self.user_embeddings.data_ptr(), self.item_embeddings.data_ptr(), self.item_biases.data_ptr()
+        pgU, pgV, pgb = gU.data_ptr(), gV.data_ptr(), gb.data_ptr()
+        ptouch, pgrad, pflat, pm, pv = (t.data_ptr() for t in (opt.touch, opt.grad, opt.flat, opt.m, opt.v))
+        ploss, n_par, reg = self.step_losses.data_ptr(), opt.flat.numel(), self.config.reg
         for k, (u, i, j) in enumerate(data_iter.iter_device()):
-            self.train_step(u.contiguous(), i.contiguous(), j.contiguous(), self.step_losses[k])
+            # slices of the contiguous epoch columns are themselves contiguous (num_neg == 1)
+            rc = L.skr_bpr_step(pU, pV, pb, pU, pV, u.data_ptr(), i.data_ptr(), j.data_ptr(), u.numel(), 1.0, reg, 1.0,
+                                pgU, pgV, pgb, pgU, pgV, ploss + 8 * k, ptouch, pgrad, st)
+            opt.t += 1
+            rc |= L.skr_adam_step(pflat, pgrad, pm, pv, n_par, opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.t, 1,
+                                  ptouch, st)
+            if rc:
+                _hip.check(rc)
 
     def fit(self):
         data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
