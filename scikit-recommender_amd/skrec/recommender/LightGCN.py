@@ -123,7 +123,22 @@ class LightGCN(AbstractRecommender):
         if cfg.embed_size != 64:
             raise NotImplementedError("the MI355X kernels are specialised for embed_size=64")
         self.device = _hip.require_gpu()
+        # one process per GPU (torchrun): user-sharded propagation, see skrec/parallel.py
+        from ..parallel import init_from_env, ShardedLightGCN
+        self.dist = init_from_env()
         adj = self._load_adj_mat(cfg.adj_type)
+        self._final_is_current = False
+        self.sampler_mode = getattr(run_config, "sampler_mode", None)
+        self.step_losses = None
+        if self.dist.active:
+            ue, ie = nn.Embedding(self.num_users, cfg.embed_size), nn.Embedding(self.num_items, cfg.embed_size)
+            get_initializer("xavier_uniform")(ue.weight)
+            get_initializer("xavier_uniform")(ie.weight)
+            self.engine = ShardedLightGCN(self.dist, adj, ue.weight.detach(), ie.weight.detach(), cfg.n_layers, cfg.lr,
+                                          cfg.reg, cfg.batch_size, self.device)
+            self._full_user_final = None
+            return
+        self.engine = None
         self.adj = DeviceCSR(adj, self.device)
         # backward needs A^T; 'pre' and 'plain' are symmetric, 'norm'/'gcmc' are not
         self.adj_t = self.adj if cfg.adj_type in ("pre", "plain") else DeviceCSR(sp.csr_matrix(adj).T, self.device)
@@ -141,26 +156,33 @@ class LightGCN(AbstractRecommender):
         self._g_final = z()       # dL/dE-bar, then H = dL/dE-bar / (K+1)
         self._g = [z(), z()]      # backward ping-pong
         self._final_is_current = False
-        self.step_losses = None
-        self.sampler_mode = getattr(run_config, "sampler_mode", None)
 
     # views -----------------------------------------------------------------------------------------
     @property
     def user_embeddings(self):
+        if self.engine is not None:
+            return self.engine.gather_user_table()
         return self.ego[:self.num_users]
 
     @property
     def item_embeddings(self):
+        if self.engine is not None:
+            return self.engine.item_rows
         return self.ego[self.num_users:]
 
     def _load_adj_mat(self, adj_type):
         out_dir = os.path.join(self.dataset.data_dir, f"_{self.__class__.__name__}_data")
         make_sure_dirs(out_dir)
         path = os.path.join(out_dir, f"{adj_type}_adj.npz")
-        if os.path.exists(path):   # same cache side file as the reference (LightGCN.py:130-140)
+        if self.dist.active and self.dist.rank != 0:
+            self.dist.barrier()        # rank 0 writes the cache file, the others read it
             return sp.load_npz(path)
-        adj = self._create_adj_mat(adj_type)
-        sp.save_npz(path, adj)
+        if os.path.exists(path):   # same cache side file as the reference (LightGCN.py:130-140)
+            adj = sp.load_npz(path)
+        else:
+            adj = self._create_adj_mat(adj_type)
+            sp.save_npz(path, adj)
+        self.dist.barrier()
         return adj
 
     def _create_adj_mat(self, adj_type):
@@ -207,35 +229,62 @@ class LightGCN(AbstractRecommender):
     def train_epoch(self, data_iter):
         self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
         for k, (u, i, j) in enumerate(data_iter.iter_device()):
-            self.train_step(u.contiguous(), i.contiguous(), j.contiguous(), self.step_losses[k])
+            if self.engine is not None:      # every rank walks the same global batches and keeps its users
+                self.engine.train_step(u, i, j)
+                self.step_losses[k] = self.engine.loss
+            else:
+                self.train_step(u.contiguous(), i.contiguous(), j.contiguous(), self.step_losses[k])
 
     def fit(self):
         data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
                                      drop_last=False, sampler_mode=self.sampler_mode)
-        self.logger.info("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
+        log = self.logger.info if self.dist.rank == 0 else (lambda *_: None)
+        log("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
         early_stopping = EarlyStopping(metric="NDCG@10", patience=self.config.early_stop)
         for epoch in range(self.config.epochs):
             self.train_epoch(data_iter)
             cur_result = self.evaluate()
-            self.logger.info(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
+            log(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
             if early_stopping(cur_result):
-                self.logger.info("early stop")
+                log("early stop")
                 break
-        self.logger.info("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
+        log("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
         return early_stopping.best_result
 
     def eval(self):
         """recompute and cache the final embeddings (_LightGCN.eval, LightGCN.py:109-111)"""
-        self.propagate()
+        if self.engine is not None:
+            e = self.engine
+            e.propagate()
+            full = torch.zeros((self.num_users, 64), dtype=torch.float32, device=self.device)
+            full[torch.from_numpy(e.mine).to(self.device)] = e.final[:e.n_local]
+            self._full_user_final = self.dist.all_reduce(full)    # every rank can rank any user
+        else:
+            self.propagate()
         self._final_is_current = True
 
     def evaluate(self, test_users=None):
         self.eval()
-        return self.evaluator.evaluate(self, test_users)
+        if self.engine is None:
+            return self.evaluator.evaluate(self, test_users)
+        # sharded: every rank ranks its share of the test users, the fp64 metric sums are all-reduced
+        ev = self.evaluator
+        users = list(ev.user_pos_test.keys()) if test_users is None else [u for u in test_users if u in ev.user_pos_test]
+        mine = [u for u in users if u % self.dist.world == self.dist.rank]
+        _, sums, n = ev.per_user_rows(self, mine)
+        tot = torch.from_numpy(np.concatenate([sums, [float(n)]])).to(self.device)
+        self.dist.all_reduce(tot)
+        tot = tot.cpu().numpy()
+        final = (tot[:-1] / max(tot[-1], 1.0)).astype(np.float32)
+        final = final.reshape(ev.metrics_num, ev.max_top)[:, ev.top_show - 1].reshape(-1)
+        from ..utils.py import MetricReport
+        return MetricReport(ev.metrics_list, final)
 
     def predict_factors(self):
         if not self._final_is_current:
             raise ValueError("Please first switch to 'eval' mode.")
+        if self.engine is not None:
+            return self._full_user_final, self.engine.final[self.engine.n_local:], None
         return self.final[:self.num_users], self.final[self.num_users:], None
 
     def predict(self, users):

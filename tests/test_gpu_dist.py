@@ -1,0 +1,140 @@
+"""GPU parity, multi-process: the user-sharded LightGCN engine (skrec.parallel.ShardedLightGCN) on TWO
+ranks replays the reference's recorded single-process trajectory -- same global batches, per-step
+losses within 1e-5, final tables within fp32 noise.  Both ranks share the one GPU of the test box and
+talk over gloo (the collective semantics are those of RCCL; the kernels are the real ones)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batches():
+    """the reference run's global batches: oracle stream for the negatives, numpy permutation per epoch"""
+    from oracle import oracle as O
+    from helpers import csr_from_pairs
+    d = np.load(os.path.join(GOLDEN, "tiny_dataset.npz"))
+    U, I = int(d["num_users"]), int(d["num_items"])
+    rowptr, pos, _, uary = csr_from_pairs(d["train"][:, 0], d["train"][:, 1], U)
+    s = O.Sampler(2020)
+    np.random.seed(2021)
+    out = []
+    for _ in range(2):
+        neg = s.sample_epoch(I, rowptr, pos, 1)
+        perm = np.random.permutation(len(pos))
+        for st in range(0, len(pos), 256):
+            idx = perm[st:st + 256]
+            out.append((uary[idx], pos[idx], neg[idx]))
+    return out
+
+
+def _worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from skrec.parallel import DistContext, ShardedLightGCN
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(GOLDEN, "golden_lightgcn.npz"))
+    U, I = g["U0"].shape[0], g["V0"].shape[0]
+    adj = sp.csr_matrix((g["adj_val"], (g["adj_idx"][0], g["adj_idx"][1])), shape=(U + I, U + I))
+    eng = ShardedLightGCN(DistContext(rank, world), adj, g["U0"], g["V0"], n_layers=3, lr=1e-3, reg=1e-3, batch_size_cfg=256)
+    dev = eng.device
+    losses = []
+    for u, i, j in _batches():
+        eng.train_step(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev), torch.from_numpy(j).to(dev))
+        losses.append(eng.loss.cpu().numpy().copy())
+    eng.propagate()
+    uf = torch.zeros((U, 64), device=dev)
+    uf[torch.from_numpy(eng.mine).to(dev)] = eng.final[:eng.n_local]
+    eng.ctx.all_reduce(uf)
+    ret[rank] = dict(losses=np.stack(losses), U1=eng.gather_user_table().cpu().numpy(), V1=eng.item_rows.cpu().numpy(),
+                     Uf=uf.cpu().numpy(), Vf=eng.final[eng.n_local:].cpu().numpy(), n_local=eng.n_local)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_lightgcn_replays_reference(world):
+    g = np.load(os.path.join(GOLDEN, "golden_lightgcn.npz"))
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        res = {k: ret[k] for k in range(world)}
+    assert sum(r["n_local"] for r in res.values()) == g["U0"].shape[0]
+    for r in res.values():
+        np.testing.assert_allclose(r["losses"][:, 0], g["bpr_mean"], rtol=1e-5)
+        np.testing.assert_allclose(r["losses"][:, 1], g["l2"], rtol=1e-5)
+        np.testing.assert_allclose(r["U1"], g["U1"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(r["Uf"], g["Uf"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(r["Vf"], g["Vf"], rtol=0, atol=3e-6)
+    if world > 1:   # replicas of the item table stay bit-identical
+        assert np.array_equal(res[0]["V1"], res[1]["V1"])
+
+
+def _api_worker(rank, world, port, data_dir, workdir, ret):
+    """what `torchrun ... run_skrec.py --recommender LightGCN` does on every rank"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo")
+    os.chdir(workdir)
+    import random
+    from skrec import RunConfig
+    from skrec.recommender.LightGCN import LightGCN
+    from skrec.utils.py.random import reset_global_sampler
+    reset_global_sampler(2020)
+    np.random.seed(2021); random.seed(2021); torch.manual_seed(2021)
+    rc = RunConfig(recommender="LightGCN", data_dir=data_dir, file_column="UIRT", sep="\t",
+                   metric=("Precision", "Recall", "MAP", "NDCG", "MRR"), top_k=(5, 10, 20), test_batch_size=16, seed=2021)
+    m = LightGCN(rc, dict(lr=1e-3, reg=1e-3, embed_size=64, n_layers=3, adj_type="pre", batch_size=256, epochs=2))
+    assert m.dist.world == world and m.engine is not None
+    reports, losses = [], []
+    ev, te = m.evaluate, m.train_epoch
+
+    def evaluate(test_users=None):
+        r = ev(test_users)
+        reports.append(np.array(list(r.values()), np.float32))
+        return r
+
+    def train_epoch(it):
+        te(it)
+        losses.append(m.step_losses.cpu().numpy().copy())
+    m.evaluate, m.train_epoch = evaluate, train_epoch
+    m.fit()
+    ret[rank] = dict(reports=np.stack(reports), losses=np.concatenate(losses, 0), U1=m.user_embeddings.cpu().numpy(),
+                     V1=m.item_embeddings.cpu().numpy())
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lightgcn_fit_under_torchrun_contract(tiny_dir, tmp_path):
+    """LightGCN.fit() through the drop-in API on two ranks == the reference's single-process run"""
+    g = np.load(os.path.join(GOLDEN, "golden_lightgcn.npz"))
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_api_worker, args=(world, _free_port(), tiny_dir, str(tmp_path), ret), nprocs=world, join=True)
+        res = {k: ret[k] for k in range(world)}
+    for r in res.values():
+        np.testing.assert_allclose(r["losses"][:, 0], g["bpr_mean"], rtol=1e-5)
+        np.testing.assert_allclose(r["losses"][:, 1], g["l2"], rtol=1e-5)
+        np.testing.assert_allclose(r["reports"], g["reports"], rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(r["U1"], g["U1"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=3e-6)
+    assert np.array_equal(res[0]["reports"], res[1]["reports"])
