@@ -66,6 +66,16 @@ class BPRMF(AbstractRecommender):
             raise NotImplementedError("the MI355X kernels are specialised for n_dim=64 (one row per wavefront)")
         self.device = _hip.require_gpu()
         U, V, b = _init_tables(self.num_users, self.num_items, self.config.n_dim)
+        self.step_losses = None  # device [n_steps, 2]: (bpr sum, l2) per step of the last epoch
+        self.sampler_mode = getattr(run_config, "sampler_mode", None)
+        # one process per GPU (torchrun): users sharded, item table replicated -- skrec/parallel.py
+        from ..parallel import init_from_env, ShardedBPRMF
+        self.dist = init_from_env()
+        self.engine = ShardedBPRMF(self.dist, U, V, b, self.config.lr, self.config.reg, self.device) if self.dist.active \
+            else None
+        if self.engine is not None:
+            self._full_users = None
+            return
         # one flat buffer [U | V | b] => one Adam launch per step; the tables are views into it
         nu, ni, d = self.num_users, self.num_items, self.config.n_dim
         self._flat = torch.cat([U.reshape(-1), V.reshape(-1), b.reshape(-1)]).to(self.device).contiguous()
@@ -75,8 +85,6 @@ class BPRMF(AbstractRecommender):
         self.optimizer = DenseAdam(self._flat, lr=self.config.lr, track_touch=True)
         self._grads = (self.optimizer.grad_view(0, (nu, d)), self.optimizer.grad_view(nu * d, (ni, d)),
                        self.optimizer.grad_view((nu + ni) * d, (ni,)))
-        self.step_losses = None  # device [n_steps, 2]: (bpr sum, l2) per step of the last epoch
-        self.sampler_mode = getattr(run_config, "sampler_mode", None)
 
     def train_step(self, users, pos, neg, loss_slot):
         """one mini-batch; ``users/pos/neg`` are int32 device tensors"""
@@ -92,6 +100,11 @@ class BPRMF(AbstractRecommender):
     def train_epoch(self, data_iter):
         """one epoch; the per-step host work is two ctypes calls on cached addresses"""
         self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
+        if self.engine is not None:   # every rank walks the same global batches and keeps its users
+            for k, (u, i, j) in enumerate(data_iter.iter_device()):
+                self.engine.train_step(u, i, j)
+                self.step_losses[k] = self.engine.loss
+            return
         L, st, opt = _hip.lib(), _hip.stream(), self.optimizer
         gU, gV, gb = self._grads
         pU, pV, pb = self.user_embeddings.data_ptr(), self.item_embeddings.data_ptr(), self.item_biases.data_ptr()
@@ -111,25 +124,44 @@ class BPRMF(AbstractRecommender):
     def fit(self):
         data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
                                      drop_last=False, sampler_mode=self.sampler_mode)
-        self.logger.info("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
+        log = self.logger.info if self.dist.rank == 0 else (lambda *_: None)
+        log("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
         early_stopping = EarlyStopping(metric="NDCG@10", patience=self.config.early_stop)
         for epoch in range(self.config.epochs):
             self.train_epoch(data_iter)
             cur_result = self.evaluate()
-            self.logger.info(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
+            log(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
             if early_stopping(cur_result):
-                self.logger.info("early stop")
+                log("early stop")
                 break
-        self.logger.info("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
+        log("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
         return early_stopping.best_result
 
     def evaluate(self, test_users=None):
-        return self.evaluator.evaluate(self, test_users)
+        if self.engine is None:
+            return self.evaluator.evaluate(self, test_users)
+        # sharded: every rank ranks its share of the test users, the fp64 metric sums are all-reduced
+        from ..utils.py import MetricReport
+        self._full_users = self.engine.gather_user_table()
+        ev = self.evaluator
+        users = list(ev.user_pos_test.keys()) if test_users is None else [u for u in test_users if u in ev.user_pos_test]
+        mine = [u for u in users if u % self.dist.world == self.dist.rank]
+        _, sums, n = ev.per_user_rows(self, mine)
+        tot = torch.from_numpy(np.concatenate([sums, [float(n)]])).to(self.device)
+        tot = self.dist.all_reduce(tot).cpu().numpy()
+        final = (tot[:-1] / max(tot[-1], 1.0)).astype(np.float32)
+        final = final.reshape(ev.metrics_num, ev.max_top)[:, ev.top_show - 1].reshape(-1)
+        return MetricReport(ev.metrics_list, final)
 
     def predict_factors(self):
+        if self.engine is not None:
+            if self._full_users is None:
+                self._full_users = self.engine.gather_user_table()
+            return self._full_users, self.engine.item_rows, self.engine.item_bias
         return self.user_embeddings, self.item_embeddings, self.item_biases
 
     def predict(self, users) -> np.ndarray:
         """dense [len(users), num_items] scores (API surface of BPRMF.py:145-147; the evaluator uses
         the fused kernel through ``predict_factors`` instead)"""
-        return _hip.score_matrix(self.user_embeddings, users, self.item_embeddings, self.item_biases).cpu().numpy()
+        ut, it, b = self.predict_factors()
+        return _hip.score_matrix(ut, users, it, b).cpu().numpy()

@@ -138,3 +138,58 @@ def test_lightgcn_fit_under_torchrun_contract(tiny_dir, tmp_path):
         np.testing.assert_allclose(r["U1"], g["U1"], rtol=0, atol=3e-6)
         np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=3e-6)
     assert np.array_equal(res[0]["reports"], res[1]["reports"])
+
+
+def _bprmf_worker(rank, world, port, data_dir, workdir, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo")
+    os.chdir(workdir)
+    import random
+    from skrec import RunConfig
+    from skrec.recommender.BPRMF import BPRMF
+    from skrec.utils.py.random import reset_global_sampler
+    reset_global_sampler(2020)
+    np.random.seed(2021); random.seed(2021); torch.manual_seed(2021)
+    rc = RunConfig(recommender="BPRMF", data_dir=data_dir, file_column="UIRT", sep="\t",
+                   metric=("Precision", "Recall", "MAP", "NDCG", "MRR"), top_k=(5, 10, 20), test_batch_size=16, seed=2021)
+    m = BPRMF(rc, dict(lr=1e-3, reg=1e-3, n_dim=64, batch_size=256, epochs=3))
+    assert m.engine is not None and m.engine.n_local in (32, 22, 21)
+    reports, losses = [], []
+    ev, te = m.evaluate, m.train_epoch
+
+    def evaluate(test_users=None):
+        r = ev(test_users)
+        reports.append(np.array(list(r.values()), np.float32))
+        return r
+
+    def train_epoch(it):
+        te(it)
+        losses.append(m.step_losses.cpu().numpy().copy())
+    m.evaluate, m.train_epoch = evaluate, train_epoch
+    m.fit()
+    ret[rank] = dict(reports=np.stack(reports), losses=np.concatenate(losses, 0),
+                     U1=m.engine.gather_user_table().cpu().numpy(), V1=m.engine.item_rows.cpu().numpy(),
+                     b1=m.engine.item_bias.cpu().numpy(), pred=m.predict([0, 3, 9, 63]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bprmf_fit_under_torchrun_contract(world, tiny_dir, tmp_path):
+    """BPRMF.fit() on N ranks (global batch 256 split by user ownership, item gradients all-reduced)
+    == the reference's single-process run"""
+    g = np.load(os.path.join(GOLDEN, "golden_bprmf.npz"))
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_bprmf_worker, args=(world, _free_port(), tiny_dir, str(tmp_path), ret), nprocs=world, join=True)
+        res = {k: ret[k] for k in range(world)}
+    for r in res.values():
+        np.testing.assert_allclose(r["losses"][:, 0], g["bpr_sum"], rtol=1e-5)
+        np.testing.assert_allclose(r["losses"][:, 1], g["l2"], rtol=1e-5)
+        np.testing.assert_allclose(r["reports"], g["reports"], rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(r["U1"], g["U1"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r["b1"], g["b1"].reshape(-1), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r["pred"], g["pred"], rtol=1e-4, atol=1e-6)
+    assert np.array_equal(res[0]["V1"], res[1]["V1"]) and np.array_equal(res[0]["reports"], res[world - 1]["reports"])
