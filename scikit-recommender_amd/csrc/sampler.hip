@@ -213,7 +213,7 @@ __global__ void mt_commit_kernel(uint32_t* state, int* pos_p, unsigned long long
 // 2b. exact assignment: which draw fills which slot
 // ------------------------------------------------------------------------------------------------
 constexpr int AS_T = 1024;
-constexpr int AS_PER = 8;
+constexpr int AS_PER = 16;
 constexpr int AS_C = AS_T * AS_PER;
 
 // largest u in [lo, hi] with rowptr[u] <= q   (rows with no positives can never own q)
@@ -225,12 +225,31 @@ __device__ __forceinline__ int owner_of(const int64_t* __restrict__ rowptr, int 
     return lo;
 }
 
+constexpr int AS_ROW_CAP = 8192;    // row offsets staged in LDS per chunk (32 KB)
+constexpr int AS_POS_CAP = 24576;   // positives staged in LDS per chunk (96 KB)
+
+// largest idx in [lo, hi] with a[idx] <= q (a ascending, in LDS)
+__device__ __forceinline__ int lds_owner(const int32_t* a, int lo, int hi, int32_t q) {
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (a[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// One workgroup walks the draw stream in chunks of AS_C.  Per chunk the part of the CSR the chunk can
+// touch -- row offsets of the users from the current one on, and their positives -- is staged in LDS
+// with two coalesced reads, so that the fixed-point rounds (owner search + membership search per
+// draw) run on LDS latency instead of a chain of ~14 dependent HBM misses per draw and round
+// (measured before staging: 0.45 s per 48 M-slot epoch, 8.3 ns per slot).
 __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
     const uint32_t* __restrict__ raw, int64_t n_raw, uint32_t high, const int64_t* __restrict__ rowptr, int n_users,
     const int32_t* __restrict__ pos_sorted, int num_neg, int64_t n_slots, int64_t slot_start, int32_t* __restrict__ out,
     int64_t* __restrict__ ctl) {
+    __shared__ int32_t l_row[AS_ROW_CAP + 1];
+    __shared__ int32_t l_pos[AS_POS_CAP];
     __shared__ int wave_tot[AS_T / SKR_WAVE];
-    __shared__ int s_ulo, s_uhi;
+    __shared__ int s_w0, s_uhi_global;
     __shared__ int s_last_idx;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -238,18 +257,59 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
 
     int64_t slot_base = slot_start;
     int64_t draw_base = 0;
+    int w0 = 0;  // first user of the staged window; the owner of slot_base never moves backwards
+#ifdef SKR_SAMPLER_STAMPS
+    long long tph[6] = {0, 0, 0, 0, 0, 0}, tprev = clock64(), n_iters = 0;
+#define STAMP(k) { if (tid == 0) { long long tn_ = clock64(); tph[k] += tn_ - tprev; tprev = tn_; } }
+#else
+#define STAMP(k)
+#endif
     while (slot_base < n_slots && draw_base < n_raw) {
         const int64_t left = n_raw - draw_base;
         const int clen = static_cast<int>(left < AS_C ? left : AS_C);
-        // users that can own a slot of this chunk
+        const int64_t q0 = slot_base / num_neg;
+        int64_t last_slot = slot_base + clen - 1;
+        if (last_slot > n_slots - 1) last_slot = n_slots - 1;
+        const int64_t q1 = last_slot / num_neg;
+        // ---- window of row offsets starting at a user <= owner(q0) ---------------------------------
         if (tid == 0) {
-            s_ulo = owner_of(rowptr, 0, n_users - 1, slot_base / num_neg);
-            int64_t last = slot_base + clen - 1;
-            if (last > n_slots - 1) last = n_slots - 1;
-            s_uhi = owner_of(rowptr, 0, n_users - 1, last / num_neg);
+            const int wend = (w0 + AS_ROW_CAP < n_users) ? w0 + AS_ROW_CAP : n_users;
+            int nw0 = w0;
+            if (!(rowptr[wend] > q0)) nw0 = owner_of(rowptr, w0, n_users - 1, q0);  // window would miss q0: re-anchor
+            s_w0 = nw0;
             s_last_idx = -1;
         }
-        // this lane's draws: value, Lemire rejection
+        __syncthreads();
+        STAMP(0)
+        w0 = s_w0;
+        const int wlen = (n_users - w0 < AS_ROW_CAP) ? n_users - w0 : AS_ROW_CAP;  // rows w0 .. w0+wlen-1
+        const int64_t pbeg0 = rowptr[w0];
+        for (int i = tid; i <= wlen; i += AS_T) {
+            const int64_t d = rowptr[w0 + i] - pbeg0;
+            l_row[i] = d > 0x7fffffff ? 0x7fffffff : static_cast<int32_t>(d);
+        }
+        __syncthreads();
+        const bool q_fits = (q1 - pbeg0) < 0x7fffffff;
+        const bool rows_staged = q_fits && (static_cast<int64_t>(l_row[wlen]) > q1 - pbeg0);  // owner(q1) inside the window
+        const int ulo_i = lds_owner(l_row, 0, wlen - 1, static_cast<int32_t>(q0 - pbeg0));  // q0 is inside by construction
+        int uhi_i;
+        if (rows_staged) {
+            uhi_i = lds_owner(l_row, ulo_i, wlen - 1, static_cast<int32_t>(q1 - pbeg0));
+        } else {
+            if (tid == 0) s_uhi_global = owner_of(rowptr, w0 + ulo_i, n_users - 1, q1);
+            __syncthreads();
+            uhi_i = s_uhi_global - w0;
+        }
+        const int ulo = w0 + ulo_i, uhi = w0 + uhi_i;
+        STAMP(1)
+        // ---- positives of users ulo..uhi ---------------------------------------------------------------
+        const int64_t pb = rows_staged ? pbeg0 + l_row[ulo_i] : rowptr[ulo];
+        const int64_t pe = rows_staged ? pbeg0 + l_row[uhi_i + 1] : rowptr[uhi + 1];
+        const bool pos_staged = rows_staged && (pe - pb <= AS_POS_CAP);
+        if (pos_staged)
+            for (int i = tid; i < static_cast<int>(pe - pb); i += AS_T) l_pos[i] = pos_sorted[pb + i];
+        const int32_t pb_rel = static_cast<int32_t>(pb - pbeg0);  // only used when rows_staged
+        // ---- this lane's draws: value, Lemire rejection -------------------------------------------------
         int val[AS_PER];
         uint32_t lem = 0, inr = 0, rej = 0;  // bit masks over the AS_PER draws
 #pragma unroll
@@ -265,9 +325,22 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
             if (idx < clen && static_cast<uint32_t>(prod) < lemire_thr) lem |= 1u << e;
         }
         rej = lem;
-        __syncthreads();
-        const int ulo = s_ulo, uhi = s_uhi;
+        __syncthreads();  // l_pos complete
+        STAMP(2)
         int my_off = 0, total = 0;
+        const bool nn1 = (num_neg == 1);
+        const uint32_t nn = static_cast<uint32_t>(num_neg);
+        const uint32_t rb = static_cast<uint32_t>(slot_base % num_neg);
+        const int32_t qb_rel = static_cast<int32_t>(q0 - pbeg0);
+        const int64_t sl64 = n_slots - slot_base;
+        const int slots_left = sl64 > AS_C ? AS_C + 1 : static_cast<int>(sl64);   // draws beyond it are never consumed
+        // Per draw the last (owner, membership) answer is kept: a later round shifts slots by the number of
+        // newly found rejections, and a draw whose slot stays inside the same user's row needs no new
+        // search.  Within a lane slots are consecutive, so the owner only ever moves forward.
+        int16_t own[AS_PER];       // window index of the owner the cached answer belongs to (-1: none)
+        uint32_t hitbits = 0;      // cached membership answers
+#pragma unroll
+        for (int e = 0; e < AS_PER; ++e) own[e] = -1;
         // fixed point: rej -> slot of every draw -> owner -> membership -> rej
         for (int iter = 0; iter < AS_C + 2; ++iter) {
             const int acc_cnt = __popc(inr & ~rej);
@@ -285,21 +358,88 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
             my_off = wbase + incl - acc_cnt;
             uint32_t nrej = lem;
             int run = my_off;
+            if (pos_staged) {
+                // pass 1: owners (forward walk from the previous draw's owner), decide who needs a search
+                int ui = -1;
+                uint32_t need = 0;
+                int32_t lo[AS_PER], hi[AS_PER];
 #pragma unroll
-            for (int e = 0; e < AS_PER; ++e) {
-                const uint32_t bit = 1u << e;
-                if (!(inr & bit)) continue;
-                const int64_t slot = slot_base + run;
-                if (!(rej & bit)) ++run;
-                if (lem & bit) continue;
-                if (slot >= n_slots) continue;  // never consumed: leave un-rejected, ignored below
-                const int u = owner_of(rowptr, ulo, uhi, slot / num_neg);
-                if (skr::contains_sorted(pos_sorted, rowptr[u], rowptr[u + 1], val[e])) nrej |= bit;
+                for (int e = 0; e < AS_PER; ++e) {
+                    const uint32_t bit = 1u << e;
+                    lo[e] = hi[e] = 0;
+                    if (!(inr & bit)) continue;
+                    const int run_e = run;
+                    if (!(rej & bit)) ++run;
+                    if ((lem & bit) || run_e >= slots_left) continue;
+                    // 32-bit arithmetic only: a 64-bit division per draw and round dominated this kernel
+                    const int32_t qr = qb_rel + static_cast<int32_t>(nn1 ? static_cast<uint32_t>(run_e)
+                                                                         : (rb + static_cast<uint32_t>(run_e)) / nn);
+                    if (ui < 0) ui = lds_owner(l_row, ulo_i, uhi_i, qr);
+                    else while (l_row[ui + 1] <= qr) ++ui;      // rows with no positives are skipped too
+                    if (own[e] == ui) {                         // same user as last round: answer stands
+                        if (hitbits & bit) nrej |= bit;
+                    } else {
+                        own[e] = static_cast<int16_t>(ui);
+                        need |= bit;
+                        lo[e] = l_row[ui] - pb_rel;
+                        hi[e] = l_row[ui + 1] - pb_rel;
+                    }
+                }
+                // pass 2: the membership searches of this lane in lock step (independent LDS reads per step)
+                if (__any(need != 0)) {
+                    bool go = true;
+                    while (go) {
+                        go = false;
+#pragma unroll
+                        for (int e = 0; e < AS_PER; ++e) {
+                            if ((need >> e) & 1u) {
+                                if (lo[e] < hi[e]) {
+                                    const int32_t mid = (lo[e] + hi[e]) >> 1;
+                                    if (l_pos[mid] < val[e]) lo[e] = mid + 1; else hi[e] = mid;
+                                    go = true;
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < AS_PER; ++e) {
+                        const uint32_t bit = 1u << e;
+                        if (need & bit) {
+                            const bool h = lo[e] < l_row[own[e] + 1] - pb_rel && l_pos[lo[e]] == val[e];
+                            hitbits = h ? (hitbits | bit) : (hitbits & ~bit);
+                            if (h) nrej |= bit;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < AS_PER; ++e) {
+                    const uint32_t bit = 1u << e;
+                    if (!(inr & bit)) continue;
+                    const int run_e = run;
+                    if (!(rej & bit)) ++run;
+                    if (lem & bit) continue;
+                    if (run_e >= slots_left) continue;  // never consumed: leave un-rejected, ignored below
+                    const int64_t q = q0 + (nn1 ? static_cast<uint32_t>(run_e) : (rb + static_cast<uint32_t>(run_e)) / nn);
+                    bool hit;
+                    if (rows_staged) {
+                        const int ui = lds_owner(l_row, ulo_i, uhi_i, static_cast<int32_t>(q - pbeg0));
+                        hit = skr::contains_sorted(pos_sorted, pbeg0 + l_row[ui], pbeg0 + l_row[ui + 1], val[e]);
+                    } else {
+                        const int u = owner_of(rowptr, ulo, uhi, q);
+                        hit = skr::contains_sorted(pos_sorted, rowptr[u], rowptr[u + 1], val[e]);
+                    }
+                    if (hit) nrej |= bit;
+                }
             }
             const int changed = (nrej != rej);
             rej = nrej;
+#ifdef SKR_SAMPLER_STAMPS
+            if (tid == 0) tph[5] += 1;
+#endif
             if (!__syncthreads_or(changed)) break;  // also orders wave_tot for the next round
         }
+        STAMP(3)
         // `rej` is the fixed point and my_off/total were computed from it in the last round.
         {
             int run = my_off;
@@ -325,11 +465,17 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
         __syncthreads();
         slot_base = filled;
         draw_base += consumed;
+        w0 = ulo;  // next chunk's first owner is >= this chunk's
+        STAMP(4)
     }
     if (tid == 0) {
         ctl[0] = slot_base;
         ctl[1] = draw_base;
+#ifdef SKR_SAMPLER_STAMPS
+        for (int k = 0; k < 6; ++k) ctl[4 + k] = tph[k];
+#endif
     }
+#undef STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -489,7 +635,7 @@ int skr_sampler_create(uint32_t seed, skr_sampler** out) {
     SKR_HIP(hipMalloc(&s->d_state, MT_N * sizeof(uint32_t)));
     SKR_HIP(hipMalloc(&s->d_pos, sizeof(int)));
     SKR_HIP(hipMalloc(&s->d_draws, sizeof(unsigned long long)));
-    SKR_HIP(hipMalloc(&s->d_ctl, 4 * sizeof(int64_t)));
+    SKR_HIP(hipMalloc(&s->d_ctl, 16 * sizeof(int64_t)));
     std::vector<uint32_t> mt(MT_N);
     mt[0] = seed;  // std::mt19937::seed(value)
     for (int i = 1; i < MT_N; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + static_cast<uint32_t>(i);
@@ -600,6 +746,14 @@ int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int
         SKR_HIP(hipMemcpyAsync(ctl, s->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));
         SKR_HIP(hipStreamSynchronize(st));
         if (ctl[0] <= filled && ctl[1] == 0) return skr::fail(SKR_EHIP, "exact sampler made no progress");
+#ifdef SKR_SAMPLER_STAMPS
+        {
+            int64_t st_[10];
+            SKR_HIP(hipMemcpy(st_, s->d_ctl + 4, sizeof(st_), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[exact_assign stamps] anchor %lld window %lld pos+draws %lld fixedpoint %lld finish %lld (cycles) rounds %lld\n",
+                    (long long)st_[0], (long long)st_[1], (long long)st_[2], (long long)st_[3], (long long)st_[4], (long long)st_[5]);
+        }
+#endif
         filled = ctl[0];
     }
     return SKR_OK;
