@@ -84,8 +84,129 @@ def shard(ds, rank, world, dev):
                 test_item=ds["test_item"][mine].contiguous()), mine.int()
 
 
+def lightgcn_main(args, world, rank, dev, dist, full):
+    """--workload lightgcn: BASELINE configs[2] (N = 1) / configs[3] (N > 1).  A step is the reference's
+    step: full-graph 3-layer propagation forward AND backward for one global batch of 1024*N, fused BPR
+    on the propagated tables, dense Adam over [U_local; I]; users sharded, one all-reduce of the [I, 64]
+    block per layer and direction (skrec.parallel.ShardedLightGCN)."""
+    from skrec import _hip
+    from skrec.parallel import DistContext, ShardedLightGCN
+    from skrec.utils.py.random import DeviceSampler
+    ctx = DistContext(rank, world)
+    nU, nI, b, K, W = args.users, args.items, args.batch, args.steps, args.warmup
+    n_inter_total = int(full["rowptr"][-1])
+    mine = torch.from_numpy(ctx.owned_users(nU)).to(dev)
+    g0 = torch.Generator().manual_seed(2021)
+    bound = (6.0 / (nU + D)) ** 0.5
+    user0 = ((torch.rand(nU, D, generator=g0) * 2 - 1) * bound)[mine.cpu()]
+    item0 = (torch.rand(nI, D, generator=torch.Generator().manual_seed(7)) * 2 - 1) * (6.0 / (nI + D)) ** 0.5
+    eng = ShardedLightGCN.from_device_edges(ctx, full["users"], full["items"], nU, nI, user0, item0, 3, 1e-3, 1e-3, b)
+    gb = b * world
+    # the epoch slice these steps consume: a user prefix, sampled with the exact stream on every rank
+    need = (W + K) * gb
+    end_user = min(int(torch.searchsorted(full["rowptr"], torch.tensor(need, device=dev))) + 1, nU)
+    nnz = int(full["rowptr"][end_user])
+    assert nnz >= need, "dataset too small for --steps"
+    rp = full["rowptr"][:end_user + 1].contiguous()
+    sampler = DeviceSampler(2020)
+    neg = torch.empty(nnz, dtype=torch.int32, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    gperm = torch.Generator(device=dev).manual_seed(11)
+    spmm_events = []
+
+    def run(n_steps, offset, timed):
+        sampler.sample_epoch_exact(nI, end_user, rp, full["items"][:nnz], nnz, 1, neg)
+        perm = torch.randperm(nnz, generator=gperm, device=dev)[:n_steps * gb]
+        uu, ii, jj = (t.index_select(0, perm).contiguous() for t in (full["users"][:nnz], full["items"][:nnz], neg))
+        for s_ in range(n_steps):
+            sl = slice(s_ * gb, (s_ + 1) * gb)
+            if timed and s_ % 4 == 0:   # bracket one forward propagation (3 SpMM per side) every few steps
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                eng.propagate()
+                e1.record()
+                spmm_events.append((e0, e1))
+            eng.train_step(uu[sl], ii[sl], jj[sl])
+    if W:
+        run(W, 0, False)
+    barrier()
+    t0 = time.perf_counter()
+    run(K, W, False)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    run(8, 0, True)    # untimed extra steps only to bracket the propagation with events
+    barrier()
+    prop_ms = float(np.mean([a.elapsed_time(z) for a, z in spmm_events]))
+    nnz_loc = eng.a_ui.nnz
+    # algorithmic bytes of one forward propagation on this rank (SURVEY 8d): per SpMM nnz*8 + rows*8 + X in + Y out
+    def spmm_bytes(csr, n_x):
+        return csr.nnz * 8 + (csr.shape[0] + 1) * 8 + n_x * 256 + csr.shape[0] * 256
+    alg = 3 * (spmm_bytes(eng.a_ui, nI) + spmm_bytes(eng.a_iu, eng.n_local))
+    ach = alg / (prop_ms * 1e-3) / 1e9
+    out = {
+        "metric": "train interactions/sec + eval users/sec (HR@10/NDCG@10) at 1/2/4/8 MI355X",
+        "value": K * gb / dt, "unit": "train interactions/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: LightGCN 3-layer d=64, synthetic {nU}-user/{nI}-item/"
+                               f"{args.interactions}-interaction graph, full-graph propagation fwd+bwd per mini-batch "
+                               f"(reference semantics), exact-stream sampler, dense Adam",
+                   "users": nU, "items": nI, "train_interactions": n_inter_total, "global_batch": gb,
+                   "sharding": f"users u%{world}, item block all-reduced per layer ({2 * 3 + 1} x {nI * 256 / 1e6:.1f} MB per step)"},
+        "roofline": {"kernel": "spmm_main_kernel (one forward propagation = 6 launches: 3 layers x {user side, item side})",
+                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": None, "avg_launch_ms": prop_ms / 6, "algorithmic_bytes_per_launch": alg / 6,
+                     "note": "gather-bound: nnz*256 B of row gathers come from L2/Infinity Cache at ~8 TB/s (DESIGN.md 4)",
+                     "local_nnz": nnz_loc},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        # the reference's step on the host: torch.sparse.mm x3 forward + autograd backward + dense Adam
+        import torch.nn as nn
+        idx = torch.stack([torch.cat([full["users"].long(), full["items"].long() + nU]),
+                           torch.cat([full["items"].long() + nU, full["users"].long()])]).cpu()
+        deg = torch.bincount(idx[0], minlength=nU + nI).float()
+        dinv = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+        A = torch.sparse_coo_tensor(idx, dinv[idx[0]] * dinv[idx[1]], (nU + nI, nU + nI)).coalesce()
+        E = nn.Parameter(torch.randn(nU + nI, D) * 0.01)
+        opt = torch.optim.Adam([E], lr=1e-3)
+        us, it_, ng = (t[:3 * b].cpu().long() for t in (full["users"], full["items"], neg if nnz >= 3 * b else full["items"]))
+        times = []
+        for s_ in range(3):
+            t1 = time.perf_counter()
+            x, layers = E, [E]
+            for _ in range(3):
+                x = torch.sparse.mm(A, x)
+                layers.append(x)
+            fin = torch.stack(layers, 1).mean(1)
+            u_, i_, j_ = us[s_ * b:(s_ + 1) * b], it_[s_ * b:(s_ + 1) * b] + nU, ng[s_ * b:(s_ + 1) * b] + nU
+            yui, yuj = (fin[u_] * fin[i_]).sum(-1), (fin[u_] * fin[j_]).sum(-1)
+            loss = (-torch.nn.functional.logsigmoid(yui - yuj)).mean() + 1e-3 * 0.5 * (E[u_].pow(2).sum() + E[i_].pow(2).sum()
+                                                                                       + E[j_].pow(2).sum()) / b
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            times.append(time.perf_counter() - t1)
+        t_step = float(np.mean(times[1:]))
+        out["cpu_baseline"] = {"value": b / t_step, "unit": "train interactions/s", "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": f"2 LightGCN steps of {b} with the reference's torch-CPU op sequence "
+                               f"(sparse.mm x3 + autograd + dense Adam) on the full graph: {t_step:.2f} s/step"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["bprmf", "lightgcn"], default="bprmf")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -122,6 +243,8 @@ def main():
     st = _hip.stream
 
     full = synth_dataset(args.users, args.items, args.interactions, 20260101, dev)
+    if args.workload == "lightgcn":
+        return lightgcn_main(args, world, rank, dev, dist, full)
     n_inter_total = int(full["rowptr"][-1])
     ds, _ = shard(full, rank, world, dev)
     if world > 1:

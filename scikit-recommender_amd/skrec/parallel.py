@@ -70,6 +70,19 @@ def init_from_env():
     return DistContext(rank, world)
 
 
+def _csr_from_device_coo(rows, cols, vals, n_rows, n_cols):
+    """rectangular CSR in HBM from unique (row, col) pairs"""
+    order = torch.argsort(rows * n_cols + cols)
+    csr = DeviceCSR.__new__(DeviceCSR)
+    csr.shape = (int(n_rows), int(n_cols))
+    csr.nnz = int(rows.numel())
+    csr.rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=rows.device)
+    csr.rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n_rows), 0)
+    csr.col = cols[order].int().contiguous()
+    csr.val = vals[order].float().contiguous()
+    return csr
+
+
 class ShardedLightGCN(object):
     """LightGCN step / propagation for one rank of a user-sharded job.
 
@@ -105,6 +118,41 @@ class ShardedLightGCN(object):
         self._g_final = z(nl + I)
         self._gu, self._gi = [z(nl), z(nl)], [z(I), z(I)]
         self.loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+
+    @classmethod
+    def from_device_edges(cls, ctx, users, items, num_users, num_items, user0, item0, n_layers, lr, reg, batch_size_cfg):
+        """Same engine, built entirely on the device from the train pairs (int tensors in HBM) with the
+        'pre' normalisation D^-1/2 A D^-1/2 of LightGCN._create_adj_mat (LightGCN.py:160-163): no scipy pass
+        over ~10^8 non-zeros.  ``user0`` holds only this rank's rows (owned_users order), ``item0`` all items."""
+        self = cls.__new__(cls)
+        dev = users.device
+        self.ctx, self.device = ctx, dev
+        self.num_users, self.num_items = int(num_users), int(num_items)
+        self.n_layers, self.reg, self.batch_size_cfg = int(n_layers), float(reg), int(batch_size_cfg)
+        u, i = users.long(), items.long()
+        ones = torch.ones(u.numel(), dtype=torch.float32, device=dev)
+        du = torch.zeros(num_users, device=dev).index_add_(0, u, ones)
+        di = torch.zeros(num_items, device=dev).index_add_(0, i, ones)
+        du = torch.where(du > 0, du.pow(-0.5), torch.zeros_like(du))
+        di = torch.where(di > 0, di.pow(-0.5), torch.zeros_like(di))
+        self.mine = ctx.owned_users(num_users)
+        nl = self.n_local = len(self.mine)
+        sel = (u % ctx.world) == ctx.rank
+        ul, il = torch.div(u[sel], ctx.world, rounding_mode="floor"), i[sel]
+        vals = du[u[sel]] * di[il]
+        self.a_ui = _csr_from_device_coo(ul, il, vals, nl, num_items)
+        self.a_iu = _csr_from_device_coo(il, ul, vals, num_items, nl)
+        self.ego = torch.cat([user0.to(dev), item0.to(dev)], dim=0).contiguous()
+        assert self.ego.shape == (nl + num_items, 64)
+        self.optimizer = DenseAdam(self.ego.view(-1), lr=lr)
+        self._g_ego = self.optimizer.grad.view(nl + num_items, 64)
+        z = lambda n: torch.zeros((n, 64), dtype=torch.float32, device=dev)  # noqa: E731
+        self.final = z(nl + num_items)
+        self._xu, self._xi = [z(nl), z(nl)], [z(num_items), z(num_items)]
+        self._g_final = z(nl + num_items)
+        self._gu, self._gi = [z(nl), z(nl)], [z(num_items), z(num_items)]
+        self.loss = torch.zeros(2, dtype=torch.float32, device=dev)
+        return self
 
     # ---- helpers ---------------------------------------------------------------------------------
     def _axpy(self, a, x, y):
