@@ -8,6 +8,8 @@ partial results over RCCL (``torch.distributed`` backend "nccl" on ROCm; "gloo" 
 * ``ShardedBPRMF`` -- the BPRMF step: local fused gather/score/scatter on the owned users' interactions
   of the global batch, ONE all-reduce of the [V | b] gradient slice (26 MB at I = 100 k), the same dense
   Adam on every replica.
+* ``ShardedLayerGCN`` -- the same partition for LayerGCN: the cosine re-weighting is row-local (users on
+  their owner, items redundantly and identically on every rank), 2K + 2 all-reduces of the item block.
 * ``ShardedLightGCN`` -- LightGCN's full-graph propagation as a 1-D row partition of the bipartite
   graph: per layer the user side is a local SpMM against the replicated item block, the item side is a
   local SpMM over the rank's user columns followed by ONE all-reduce of the [I, 64] partial result
@@ -26,7 +28,7 @@ from . import _hip
 from .recommender.base import DenseAdam
 from .recommender.LightGCN import DeviceCSR
 
-__all__ = ["DistContext", "ShardedBPRMF", "ShardedLightGCN", "init_from_env"]
+__all__ = ["DistContext", "ShardedBPRMF", "ShardedLightGCN", "ShardedLayerGCN", "init_from_env", "sharded_evaluate"]
 
 
 class DistContext(object):
@@ -233,6 +235,154 @@ class ShardedLightGCN(object):
         full[torch.from_numpy(self.mine).to(self.device)] = self.ego[:self.n_local]
         self.ctx.all_reduce(full)
         return full
+
+
+class ShardedLayerGCN(object):
+    """LayerGCN step / propagation for one rank of a user-sharded job (reference maths: LayerGCN.py:199-252).
+
+    edge_u / edge_i   int64 device tensors, the FULL (possibly pruned) train edge list, identical on every rank
+    user0 / item0     full initial tables, identical on every rank
+    Rows are laid out [local users ; all items].  Item rows of every intermediate are replicated: each rank
+    computes them from all-reduced inputs, so they stay bit-identical without being exchanged again.
+    """
+
+    def __init__(self, ctx, edge_u, edge_i, num_users, num_items, user0, item0, n_layers, lr, reg, device=None):
+        self.ctx = ctx
+        self.device = dev = device if device is not None else _hip.require_gpu()
+        user0 = torch.as_tensor(np.asarray(user0), dtype=torch.float32)
+        item0 = torch.as_tensor(np.asarray(item0), dtype=torch.float32)
+        self.num_users, self.num_items = int(num_users), int(num_items)
+        assert user0.shape == (self.num_users, 64) and item0.shape == (self.num_items, 64)
+        self.n_layers, self.reg = int(n_layers), float(reg)
+        self.mine = ctx.owned_users(self.num_users)
+        nl = self.n_local = len(self.mine)
+        n = nl + self.num_items
+        self.ego = torch.cat([user0[self.mine], item0], dim=0).to(dev).contiguous()
+        self.optimizer = DenseAdam(self.ego.view(-1), lr=lr)
+        self._g_ego = self.optimizer.grad.view(n, 64)
+        z = lambda: torch.zeros((n, 64), dtype=torch.float32, device=dev)  # noqa: E731
+        K = self.n_layers
+        self.out = z()
+        self._y = [z() for _ in range(K)]
+        self._w = [torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(K)]
+        self._z = [z(), z()]
+        self._g_out = z()
+        self._t = [z(), z()]
+        self.loss = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.full_blocks = self._blocks(edge_u, edge_i)
+        self.train_blocks = self.full_blocks
+
+    def _blocks(self, edge_u, edge_i):
+        """local row blocks of get_norm_adj_mat / _normalize_adj_m (LayerGCN.py:154-163,173-197):
+        value 1/sqrt((deg_u + 1e-7)(deg_i + 1e-7)), float64 then rounded to float32"""
+        dev, world, rank = self.device, self.ctx.world, self.ctx.rank
+        u, i = edge_u.to(dev).long(), edge_i.to(dev).long()
+        ones = torch.ones(u.numel(), dtype=torch.float64, device=dev)
+        du = (torch.zeros(self.num_users, dtype=torch.float64, device=dev).index_add_(0, u, ones) + 1e-7).pow(-0.5)
+        di = (torch.zeros(self.num_items, dtype=torch.float64, device=dev).index_add_(0, i, ones) + 1e-7).pow(-0.5)
+        sel = (u % world) == rank
+        ul, il = torch.div(u[sel], world, rounding_mode="floor"), i[sel]
+        vals = (du[u[sel]] * di[il]).float()
+        return (_csr_from_device_coo(ul, il, vals, self.n_local, self.num_items),
+                _csr_from_device_coo(il, ul, vals, self.num_items, self.n_local))
+
+    def set_train_edges(self, edge_u=None, edge_i=None):
+        """the pruned graph of this epoch (LayerGCN.py:133-152); None restores the full graph"""
+        self.train_blocks = self.full_blocks if edge_u is None else self._blocks(edge_u, edge_i)
+
+    @property
+    def item_rows(self):
+        return self.ego[self.n_local:]
+
+    def _axpy(self, a, x, y):
+        _hip.check(_hip.lib().skr_axpy(float(a), _hip.ptr(x), _hip.ptr(y), x.numel(), _hip.stream()))
+
+    def propagate(self, train=False):
+        """out = sum_k  w_k * (A X_k),  w_k = cos(A X_k, E0) row-wise,  X_{k+1} = w_k * (A X_k)"""
+        L, st, nl = _hip.lib(), _hip.stream(), self.n_local
+        a_ui, a_iu = self.train_blocks if train else self.full_blocks
+        n = self.ego.shape[0]
+        self.out.zero_()
+        x = self.ego
+        for k in range(self.n_layers):
+            y = self._y[k]
+            a_ui.spmm(x[nl:], y[:nl])
+            a_iu.spmm(x[:nl], y[nl:])
+            self.ctx.all_reduce(y[nl:])
+            zk = self._z[k & 1]
+            _hip.check(L.skr_layer_refine_fwd(_hip.ptr(y), _hip.ptr(self.ego), n, 64, _hip.ptr(zk), _hip.ptr(self._w[k]),
+                                              _hip.ptr(self.out), st))
+            x = zk
+        return self.out
+
+    def train_step(self, users, pos, neg):
+        """global batch in, identical on every rank; ``self.loss`` = global (bpr sum, l2) afterwards"""
+        L, st = _hip.lib(), _hip.stream()
+        nl, world, rank, K = self.n_local, self.ctx.world, self.ctx.rank, self.n_layers
+        n = self.ego.shape[0]
+        if world > 1:
+            sel = (users % world) == rank
+            ul = torch.div(users[sel], world, rounding_mode="floor").int().contiguous()
+            il, jl = pos[sel].contiguous(), neg[sel].contiguous()
+        else:
+            ul, il, jl = users.contiguous(), pos.contiguous(), neg.contiguous()
+        a_ui, a_iu = self.train_blocks
+        self.propagate(train=True)
+        gO, gE = self._g_out, self._g_ego
+        gO.zero_()
+        self.loss.zero_()
+        if ul.numel() > 0:
+            _hip.check(L.skr_bpr_step(
+                _hip.ptr(self.out[:nl]), _hip.ptr(self.out[nl:]), None, _hip.ptr(self.ego[:nl]), _hip.ptr(self.ego[nl:]),
+                _hip.ptr(ul), _hip.ptr(il), _hip.ptr(jl), ul.numel(), 1.0, self.reg, 1.0,
+                _hip.ptr(gO[:nl]), _hip.ptr(gO[nl:]), None, _hip.ptr(gE[:nl]), _hip.ptr(gE[nl:]), _hip.ptr(self.loss),
+                None, None, st))
+        self.ctx.all_reduce(self.loss)
+        self.ctx.all_reduce(gO[nl:])          # dL/d out, item rows: now the full value everywhere
+        self.ctx.all_reduce(gE[nl:])          # the regulariser's part of the item gradient
+        dz = gO
+        dy, tmp = self._t
+        for k in range(K - 1, -1, -1):
+            _hip.check(L.skr_layer_refine_bwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), _hip.ptr(self._w[k]),
+                                              _hip.ptr(dz), n, 64, _hip.ptr(dy), _hip.ptr(gE), st))
+            if k > 0:
+                a_ui.spmm(dy[nl:], tmp[:nl], addend=gO[:nl])
+                a_iu.spmm(dy[:nl], tmp[nl:])
+                self.ctx.all_reduce(tmp[nl:])
+                self._axpy(1.0, gO[nl:], tmp[nl:])
+                dz = tmp
+            else:
+                a_ui.spmm(dy[nl:], tmp[:nl], accum=gE[:nl], accum_scale=1.0)
+                a_iu.spmm(dy[:nl], tmp[nl:])
+                self.ctx.all_reduce(tmp[nl:])
+                self._axpy(1.0, tmp[nl:], gE[nl:])
+        self.optimizer.step()
+
+    def gather_user_rows(self, local_rows):
+        """[U, 64] on every rank from each rank's [U_local, 64] block"""
+        full = torch.zeros((self.num_users, 64), dtype=torch.float32, device=self.device)
+        full[torch.from_numpy(self.mine).to(self.device)] = local_rows
+        self.ctx.all_reduce(full)
+        return full
+
+    def gather_user_table(self):
+        return self.gather_user_rows(self.ego[:self.n_local])
+
+
+def sharded_evaluate(ctx, evaluator, model, test_users, device):
+    """every rank ranks its share (u % world) of the test users with the fused evaluator; the fp64 metric
+    sums and the user count are all-reduced, so every rank returns the same report"""
+    from .utils.py import MetricReport
+    ev = evaluator
+    users = list(ev.user_pos_test.keys()) if test_users is None else [u for u in test_users if u in ev.user_pos_test]
+    mine = [u for u in users if u % ctx.world == ctx.rank]
+    _, sums, n = ev.per_user_rows(model, mine)
+    tot = torch.from_numpy(np.concatenate([sums, [float(n)]])).to(device)
+    ctx.all_reduce(tot)
+    tot = tot.cpu().numpy()
+    final = (tot[:-1] / max(tot[-1], 1.0)).astype(np.float32)
+    final = final.reshape(ev.metrics_num, ev.max_top)[:, ev.top_show - 1].reshape(-1)
+    return MetricReport(ev.metrics_list, final)
 
 
 class ShardedBPRMF(object):

@@ -74,13 +74,28 @@ class LayerGCN(AbstractRecommender):
         if not 0.0 <= cfg.dropout < 1.0:
             raise ValueError("dropout must be in [0, 1)")
         self.device = _hip.require_gpu()
+        from ..parallel import init_from_env, ShardedLayerGCN
+        self.dist = init_from_env()      # one process per GPU under torchrun; world 1 otherwise
         inter = self.dataset.train_data.to_coo_matrix().astype(np.float32)
         # parameters first, like _LayerGCN.__init__ (:114-115): xavier_uniform on plain tensors
         ue = nn.init.xavier_uniform_(torch.empty(self.num_users, cfg.embed_dim))
         ie = nn.init.xavier_uniform_(torch.empty(self.num_items, cfg.embed_dim))
+        self.pruning_random = False                     # LayerGCN.py:121
+        self.step_losses = None
+        self.sampler_mode = getattr(run_config, "sampler_mode", None)
+        self.engine = None
+        if self.dist.active:
+            # user-sharded rows, replicated item rows (skrec/parallel.py); duplicate pairs collapse to one edge
+            pairs = np.unique(np.stack([inter.row, inter.col], 1).astype(np.int64), axis=0)
+            self._edge_u = torch.from_numpy(pairs[:, 0].copy()).to(self.device)
+            self._edge_i = torch.from_numpy(pairs[:, 1].copy()).to(self.device)
+            self._edge_values = self._normalize_edges(self._edge_u, self._edge_i)
+            self.engine = ShardedLayerGCN(self.dist, self._edge_u, self._edge_i, self.num_users, self.num_items, ue, ie,
+                                          cfg.n_layers, cfg.lr, cfg.reg, self.device)
+            self._full_user_out = None
+            return
         self.adj = DeviceCSR(build_layergcn_adjacency(inter, self.num_users, self.num_items), self.device)
         self.train_adj = self.adj                       # masked_adj of the reference (LayerGCN.py:119,135)
-        self.pruning_random = False                     # LayerGCN.py:121
         # edge list + normalised edge values for the pruning step (get_edge_info, LayerGCN.py:165-171)
         self._edge_u = torch.from_numpy(np.asarray(inter.row, dtype=np.int64)).to(self.device)
         self._edge_i = torch.from_numpy(np.asarray(inter.col, dtype=np.int64)).to(self.device)
@@ -97,15 +112,17 @@ class LayerGCN(AbstractRecommender):
         self._z = [z(), z()]                             # refined layer ping-pong
         self._g_out = z()
         self._t = [z(), z()]
-        self.step_losses = None
-        self.sampler_mode = getattr(run_config, "sampler_mode", None)
 
     @property
     def user_embeddings(self):
+        if self.engine is not None:
+            return self.engine.gather_user_table()
         return self.ego[:self.num_users]
 
     @property
     def item_embeddings(self):
+        if self.engine is not None:
+            return self.engine.item_rows
         return self.ego[self.num_users:]
 
     def _normalize_edges(self, u, i):
@@ -118,7 +135,10 @@ class LayerGCN(AbstractRecommender):
     def pre_epoch_processing(self):
         """edge pruning, once per epoch (LayerGCN.py:133-152); a no-op when dropout == 0"""
         if self.config.dropout <= 0.0:
-            self.train_adj = self.adj
+            if self.engine is not None:
+                self.engine.set_train_edges(None)
+            else:
+                self.train_adj = self.adj
             return
         n_edges = self._edge_values.numel()
         keep_len = int(n_edges * (1.0 - self.config.dropout))
@@ -127,6 +147,13 @@ class LayerGCN(AbstractRecommender):
         else:   # prune edges of high-degree nodes preferentially: keep ~ normalised edge value
             keep = torch.multinomial(self._edge_values, keep_len)
         self.pruning_random = True ^ self.pruning_random
+        if self.engine is not None:
+            # every rank must prune the SAME edges: rank 0's draw is broadcast (one int64 per kept edge)
+            if self.dist.rank != 0:
+                keep.zero_()
+            self.dist.all_reduce(keep)
+            self.engine.set_train_edges(self._edge_u[keep], self._edge_i[keep])
+            return
         u, i = self._edge_u[keep], self._edge_i[keep]
         vals = self._normalize_edges(u, i)
         n = self.num_users + self.num_items
@@ -177,31 +204,51 @@ class LayerGCN(AbstractRecommender):
     def train_epoch(self, data_iter):
         self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
         for k, (u, i, j) in enumerate(data_iter.iter_device()):
-            self.train_step(u.contiguous(), i.contiguous(), j.contiguous(), self.step_losses[k])
+            if self.engine is not None:      # every rank walks the same global batches and keeps its users
+                self.engine.train_step(u, i, j)
+                self.step_losses[k] = self.engine.loss
+            else:
+                self.train_step(u.contiguous(), i.contiguous(), j.contiguous(), self.step_losses[k])
 
     def fit(self):
         data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
                                      drop_last=False, sampler_mode=self.sampler_mode)
-        self.logger.info("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
+        log = self.logger.info if self.dist.rank == 0 else (lambda *_: None)
+        log("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
         early_stopping = EarlyStopping(metric="NDCG@10", patience=self.config.early_stop)
         for epoch in range(self.config.epochs):
             self.pre_epoch_processing()
             self.train_epoch(data_iter)
             cur_result = self.evaluate()
-            self.logger.info(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
+            log(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
             if early_stopping(cur_result):
-                self.logger.info("early stop")
+                log("early stop")
                 break
-        self.logger.info("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
+        log("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
         return early_stopping.best_result
 
+    def _refresh_outputs(self):
+        """one full-graph propagation per evaluation (the reference repeats it per batch, :255-262)"""
+        if self.engine is not None:
+            e = self.engine
+            e.propagate(train=False)
+            self._full_user_out = e.gather_user_rows(e.out[:e.n_local])   # every rank can rank any user
+        else:
+            self.forward()
+
     def evaluate(self, test_users=None):
-        self.forward()   # one propagation per evaluation (the reference repeats it per batch, :255-262)
-        return self.evaluator.evaluate(self, test_users)
+        self._refresh_outputs()
+        if self.engine is None:
+            return self.evaluator.evaluate(self, test_users)
+        from ..parallel import sharded_evaluate
+        return sharded_evaluate(self.dist, self.evaluator, self, test_users, self.device)
 
     def predict_factors(self):
+        if self.engine is not None:
+            return self._full_user_out, self.engine.out[self.engine.n_local:], None
         return self.out[:self.num_users], self.out[self.num_users:], None
 
     def predict(self, users):
-        self.forward()
-        return _hip.score_matrix(self.out[:self.num_users], users, self.out[self.num_users:], None).cpu().numpy()
+        self._refresh_outputs()
+        uf, vf, _ = self.predict_factors()
+        return _hip.score_matrix(uf, users, vf, None).cpu().numpy()

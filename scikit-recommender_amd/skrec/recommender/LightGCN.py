@@ -267,18 +267,8 @@ class LightGCN(AbstractRecommender):
         self.eval()
         if self.engine is None:
             return self.evaluator.evaluate(self, test_users)
-        # sharded: every rank ranks its share of the test users, the fp64 metric sums are all-reduced
-        ev = self.evaluator
-        users = list(ev.user_pos_test.keys()) if test_users is None else [u for u in test_users if u in ev.user_pos_test]
-        mine = [u for u in users if u % self.dist.world == self.dist.rank]
-        _, sums, n = ev.per_user_rows(self, mine)
-        tot = torch.from_numpy(np.concatenate([sums, [float(n)]])).to(self.device)
-        self.dist.all_reduce(tot)
-        tot = tot.cpu().numpy()
-        final = (tot[:-1] / max(tot[-1], 1.0)).astype(np.float32)
-        final = final.reshape(ev.metrics_num, ev.max_top)[:, ev.top_show - 1].reshape(-1)
-        from ..utils.py import MetricReport
-        return MetricReport(ev.metrics_list, final)
+        from ..parallel import sharded_evaluate
+        return sharded_evaluate(self.dist, self.evaluator, self, test_users, self.device)
 
     def predict_factors(self):
         if not self._final_is_current:

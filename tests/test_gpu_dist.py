@@ -193,3 +193,79 @@ def test_bprmf_fit_under_torchrun_contract(world, tiny_dir, tmp_path):
         np.testing.assert_allclose(r["b1"], g["b1"].reshape(-1), rtol=0, atol=2e-6)
         np.testing.assert_allclose(r["pred"], g["pred"], rtol=1e-4, atol=1e-6)
     assert np.array_equal(res[0]["V1"], res[1]["V1"]) and np.array_equal(res[0]["reports"], res[world - 1]["reports"])
+
+
+def _layergcn_worker(rank, world, port, data_dir, workdir, dropout, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo")
+    os.chdir(workdir)
+    import random
+    from skrec import RunConfig
+    from skrec.recommender.LayerGCN import LayerGCN
+    from skrec.utils.py.random import reset_global_sampler
+    reset_global_sampler(2020)
+    np.random.seed(2021); random.seed(2021); torch.manual_seed(2021)
+    rc = RunConfig(recommender="LayerGCN", data_dir=data_dir, file_column="UIRT", sep="\t",
+                   metric=("Precision", "Recall", "MAP", "NDCG", "MRR"), top_k=(5, 10, 20), test_batch_size=16, seed=2021)
+    m = LayerGCN(rc, dict(lr=1e-3, reg=1e-2, embed_dim=64, n_layers=4, dropout=dropout, batch_size=256, epochs=2))
+    assert m.engine is not None and m.dist.world == world
+    reports, losses, nnz = [], [], []
+    ev, te = m.evaluate, m.train_epoch
+
+    def evaluate(test_users=None):
+        r = ev(test_users)
+        reports.append(np.array(list(r.values()), np.float32))
+        return r
+
+    def train_epoch(it):
+        nnz.append(m.engine.train_blocks[0].nnz)
+        te(it)
+        losses.append(m.step_losses.cpu().numpy().copy())
+    m.evaluate, m.train_epoch = evaluate, train_epoch
+    m.fit()
+    e = m.engine
+    ret[rank] = dict(reports=np.stack(reports), losses=np.concatenate(losses, 0), U1=m.user_embeddings.cpu().numpy(),
+                     V1=m.item_embeddings.cpu().numpy(), Uf=e.gather_user_rows(e.out[:e.n_local]).cpu().numpy(),
+                     pred=m.predict([0, 3, 9, 63]), n_test=len(m.evaluator.user_pos_test), nnz=nnz,
+                     full_nnz=e.full_blocks[0].nnz)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_layergcn_fit_under_torchrun_contract(world, tiny_dir, tmp_path):
+    """LayerGCN.fit() on N ranks (user-sharded rows, replicated item rows, 2K+2 all-reduces per step)
+    == the reference's single-process run"""
+    from helpers import layergcn_tie_adjust
+    g = np.load(os.path.join(GOLDEN, "golden_layergcn.npz"))
+    tiny = np.load(os.path.join(GOLDEN, "tiny_dataset.npz"))
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_layergcn_worker, args=(world, _free_port(), tiny_dir, str(tmp_path), 0.0, ret), nprocs=world, join=True)
+        res = {k: ret[k] for k in range(world)}
+    adjust = layergcn_tie_adjust(tiny, g["V0"].shape[0], res[0]["n_test"])
+    for r in res.values():
+        total = r["losses"][:, 0] + np.float32(1e-2) * r["losses"][:, 1]
+        np.testing.assert_allclose(total, g["loss"], rtol=1e-5)
+        np.testing.assert_allclose(r["reports"], g["reports"] + adjust[None, :], rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(r["U1"], g["U1"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(r["Uf"], g["Uf"], rtol=0, atol=6e-6)
+        np.testing.assert_allclose(r["pred"], g["pred"], rtol=1e-4, atol=2e-6)
+    assert np.array_equal(res[0]["V1"], res[1]["V1"]) and np.array_equal(res[0]["reports"], res[world - 1]["reports"])
+
+
+def test_layergcn_sharded_edge_dropout(tiny_dir, tmp_path):
+    """dropout > 0 on two ranks: every rank prunes the SAME edges (rank 0's draw), so the replicas of the
+    item table stay bit-identical and the kept-edge counts add up to int(E * (1 - dropout))"""
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_layergcn_worker, args=(world, _free_port(), tiny_dir, str(tmp_path), 0.25, ret), nprocs=world, join=True)
+        res = {k: ret[k] for k in range(world)}
+    n_edges = sum(r["full_nnz"] for r in res.values())
+    for ep in range(2):
+        assert sum(r["nnz"][ep] for r in res.values()) == int(n_edges * 0.75)
+    assert np.array_equal(res[0]["V1"], res[1]["V1"]) and np.array_equal(res[0]["reports"], res[1]["reports"])
+    assert np.isfinite(res[0]["losses"]).all()
