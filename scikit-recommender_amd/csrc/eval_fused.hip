@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int FE_WAVES = 4;   // waves per workgroup (independent of each other)
 constexpr int FE_UW = 64;     // users per wave
 constexpr int FE_TI = 32;     // items per tile
-constexpr int FE_CAP = 256;   // candidate capacity per user (keys of 8 B)
+constexpr int FE_CAP = 256;   // candidate capacity per user (keys of 8 B); 512 was measured and bought nothing
 constexpr int FE_D = 64;
 
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
@@ -88,31 +88,105 @@ struct FusedArgs {
     const int64_t* train_rowptr;
     const int32_t* train_items;
     int top_k;
-    uint64_t* cand;  // [ceil(B/64)*64][FE_CAP]
+    uint64_t* cand;  // [ceil(B/64)*64][cap]
     int32_t* out_ids;
     float* out_scores;
     int ablate;      // timing experiments only (SKR_FUSED_ABLATE): 1 = thresholds +inf (pure GEMM sweep)
-    int trigger;     // a list is compacted once it holds more than this many candidates (K <= trigger <= CAP-32)
+    int trigger;     // a list is compacted once it holds more than this many candidates (K <= trigger <= cap-32)
+    int cap;         // list capacity per user (FE_CAP)
 };
+
+constexpr int FE_ROWBUF = 256;   // train rows up to this length are staged in LDS for the membership searches
+
+struct WaveCtx {
+    int lane, c, h;
+    int64_t ubase;
+    int* cnt;            // LDS: list length per user of this wave
+    uint64_t* my_cand;   // HBM: the wave's 64 candidate lists
+    int64_t* row_beg;    // LDS: start of each user's train row
+    int* row_len;        // LDS: its length (0 when no train mask was given)
+    int* rowbuf;         // LDS: FE_ROWBUF ints of scratch for one staged row
+};
+
+// Drop the user's train items from the NR keys each lane holds: NR binary searches per lane advance in
+// lock-step, so a compaction pays ceil(log2(row length)) dependent load latencies, not NR times that.
+template <int NR>
+__device__ __forceinline__ void mask_train_lockstep(const FusedArgs& a, const WaveCtx& w, int ul, uint64_t (&k)[NR]) {
+    const int len = w.row_len[ul];   // wave-uniform
+    if (len <= 0) return;
+    const int32_t* __restrict__ row = a.train_items + w.row_beg[ul];
+    int lo[NR], hi[NR], v[NR];
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+        lo[e] = 0;
+        hi[e] = (k[e] != SKR_KEY_MIN) ? len : 0;
+        v[e] = skr::key_id(k[e]);
+    }
+    const int steps = 32 - __clz(len);
+    if (len <= FE_ROWBUF) {
+        // one coalesced read of the row into LDS, then the searches run at LDS latency
+        int* __restrict__ buf = w.rowbuf;
+#pragma unroll
+        for (int e = 0; e < FE_ROWBUF / 64; ++e) {
+            const int idx = e * 64 + w.lane;
+            if (idx < len) buf[idx] = row[idx];
+        }
+        __threadfence_block();   // the wave's own LDS writes, ordered before its reads
+        for (int s = 0; s < steps; ++s) {
+#pragma unroll
+            for (int e = 0; e < NR; ++e) {
+                const int mid = (lo[e] + hi[e]) >> 1;
+                const int x = buf[mid < len ? mid : len - 1];
+                if (lo[e] < hi[e]) {
+                    if (x < v[e]) lo[e] = mid + 1; else hi[e] = mid;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NR; ++e) {
+            const bool in_range = (k[e] != SKR_KEY_MIN) && lo[e] < len;
+            if (in_range && buf[lo[e] < len ? lo[e] : 0] == v[e]) k[e] = SKR_KEY_MIN;
+        }
+        __threadfence_block();   // reads done before the next compaction overwrites the buffer
+        return;
+    }
+    for (int s = 0; s < steps; ++s) {
+        int x[NR], mid[NR];
+#pragma unroll
+        for (int e = 0; e < NR; ++e) {
+            mid[e] = (lo[e] + hi[e]) >> 1;
+            x[e] = row[mid[e] < len ? mid[e] : len - 1];
+        }
+#pragma unroll
+        for (int e = 0; e < NR; ++e) {
+            if (lo[e] < hi[e]) {
+                if (x[e] < v[e]) lo[e] = mid[e] + 1; else hi[e] = mid[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+        const bool in_range = (k[e] != SKR_KEY_MIN) && lo[e] < len;
+        const int x = row[in_range ? lo[e] : 0];
+        if (in_range && x == v[e]) k[e] = SKR_KEY_MIN;
+    }
+}
 
 // Sort user `ul`'s candidate list (at most 64*NR entries), drop train items, keep the best top_k at
 // the front.  Returns the new threshold (score of the K-th best, or -inf while fewer than K are
 // known).  If out_row >= 0 the final top_k ids / scores are also written to the outputs.
 template <int NR>
-__device__ __forceinline__ float compact_user_n(const FusedArgs& a, int lane, uint64_t* __restrict__ list, int* cnt_p,
-                                                int n, int uid, int64_t out_row) {
+__device__ __forceinline__ float compact_user_n(const FusedArgs& a, const WaveCtx& w, int ul, int n, int64_t out_row) {
+    const int lane = w.lane;
+    uint64_t* __restrict__ list = w.my_cand + static_cast<int64_t>(ul) * a.cap;
+    int* cnt_p = &w.cnt[ul];
     uint64_t k[NR];
 #pragma unroll
     for (int e = 0; e < NR; ++e) {
         const int idx = e * 64 + lane;
         k[e] = (idx < n) ? list[idx] : SKR_KEY_MIN;
     }
-    if (a.train_rowptr) {
-        const int64_t rb = a.train_rowptr[uid], re = a.train_rowptr[uid + 1];
-#pragma unroll
-        for (int e = 0; e < NR; ++e)
-            if (k[e] != SKR_KEY_MIN && skr::contains_sorted(a.train_items, rb, re, skr::key_id(k[e]))) k[e] = SKR_KEY_MIN;
-    }
+    mask_train_lockstep<NR>(a, w, ul, k);
     wave_sort_desc<NR>(k, lane);
     int valid = 0;
 #pragma unroll
@@ -142,14 +216,106 @@ __device__ __forceinline__ float compact_user_n(const FusedArgs& a, int lane, ui
     return thr;
 }
 
-__device__ __forceinline__ float compact_user(const FusedArgs& a, int lane, uint64_t* __restrict__ list, int* cnt_p,
-                                              int uid, int64_t out_row) {
+// smallest real key among the NR*64 held by the wave (the K-th best when exactly K are real)
+template <int NR>
+__device__ __forceinline__ uint64_t kth_min_key(const uint64_t (&k)[NR], int lane) {
+    (void)lane;
+    uint64_t m = ~0ull;
+#pragma unroll
+    for (int e = 0; e < NR; ++e)
+        if (k[e] != SKR_KEY_MIN && k[e] < m) m = k[e];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint64_t o = shfl_xor_u64(m, d);
+        m = o < m ? o : m;
+    }
+    return m;
+}
+
+// Mid-sweep compaction: only the K best entries and the K-th best score are needed, not their order, so
+// this SELECTS instead of sorting.  The K-th largest key is built bit by bit from the top: a candidate
+// value is kept if at least K keys are >= it.  The counts are v_cmp + s_bcnt1 on the wave's mask, i.e.
+// NR vector compares per step and the rest on the scalar unit (the sort costs ~10 VALU instructions per
+// register and stage, 36 stages for 256 keys).  Keys of one user are distinct (an item is scored once),
+// so exactly K keys are >= the result.  Survivors are written back unordered; the final compaction sorts.
+template <int NR>
+__device__ __forceinline__ float compact_select_n(const FusedArgs& a, const WaveCtx& w, int ul, int n) {
+    const int lane = w.lane;
+    uint64_t* __restrict__ list = w.my_cand + static_cast<int64_t>(ul) * a.cap;
+    int* cnt_p = &w.cnt[ul];
+    uint64_t k[NR];
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+        const int idx = e * 64 + lane;
+        k[e] = (idx < n) ? list[idx] : SKR_KEY_MIN;
+    }
+    mask_train_lockstep<NR>(a, w, ul, k);
+    if (a.ablate == 6) mask_train_lockstep<NR>(a, w, ul, k);
+    const int K = a.top_k;
+    int valid = 0;
+#pragma unroll
+    for (int e = 0; e < NR; ++e) valid += __popcll(__ballot(k[e] != SKR_KEY_MIN));
+    uint64_t T = 1;   // keep every real key
+    if (valid > K) {
+        // score word first (32 steps on 32-bit compares) ...
+        uint32_t hi[NR];
+#pragma unroll
+        for (int e = 0; e < NR; ++e) hi[e] = static_cast<uint32_t>(k[e] >> 32);
+        uint32_t th = 0;
+        for (int rep = (a.ablate == 5 ? 2 : 1); rep > 0; --rep) {
+            th = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = th | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int e = 0; e < NR; ++e) c += __popcll(__ballot(hi[e] >= cand));
+                if (c >= K) th = cand;
+            }
+        }
+        int c_ge = 0, c_gt = 0;
+#pragma unroll
+        for (int e = 0; e < NR; ++e) {
+            c_ge += __popcll(__ballot(hi[e] >= th));
+            c_gt += __popcll(__ballot(hi[e] > th));
+        }
+        uint32_t tl = 0;
+        if (c_ge > K) {   // ... then, only if equal scores straddle the K-th place, the id word among them
+            const int need = K - c_gt;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = tl | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int e = 0; e < NR; ++e) c += __popcll(__ballot(hi[e] == th && static_cast<uint32_t>(k[e]) >= cand));
+                if (c >= need) tl = cand;
+            }
+        }
+        T = (static_cast<uint64_t>(th) << 32) | tl;
+    }
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+        const bool p = (k[e] >= T);
+        const uint64_t m = __ballot(p);
+        if (p) list[base + __popcll(m & ((1ull << lane) - 1ull))] = k[e];
+        base += __popcll(m);
+    }
+    if (lane == 0) *cnt_p = base;
+    return (base == K && valid >= K) ? skr::key_score(valid > K ? T : kth_min_key<NR>(k, lane)) : -INFINITY;
+}
+
+__device__ __forceinline__ float compact_user(const FusedArgs& a, const WaveCtx& w, int ul, int64_t out_row) {
     __threadfence_block();  // this wave's earlier appends must have landed before they are re-read
-    const int n = *cnt_p;   // wave-uniform
+    const int n = w.cnt[ul];   // wave-uniform
     float thr;
-    if (n <= 64 && a.top_k <= 64) thr = compact_user_n<1>(a, lane, list, cnt_p, n, uid, out_row);
-    else if (n <= 128) thr = compact_user_n<2>(a, lane, list, cnt_p, n, uid, out_row);
-    else thr = compact_user_n<4>(a, lane, list, cnt_p, n, uid, out_row);
+    if (out_row < 0) {      // mid-sweep: select
+        if (n <= 64) thr = compact_select_n<1>(a, w, ul, n);
+        else if (n <= 128) thr = compact_select_n<2>(a, w, ul, n);
+        else thr = compact_select_n<4>(a, w, ul, n);
+    } else {                // end of the sweep: sort, write the results
+        if (n <= 64 && a.top_k <= 64) thr = compact_user_n<1>(a, w, ul, n, out_row);
+        else if (n <= 128) thr = compact_user_n<2>(a, w, ul, n, out_row);
+        else thr = compact_user_n<4>(a, w, ul, n, out_row);
+    }
     __threadfence_block();
     return thr;
 }
@@ -178,12 +344,6 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
         static_cast<int>(reinterpret_cast<uintptr_t>((lds_ptr_t)p))));
 }
 
-struct WaveCtx {
-    int lane, c, h;
-    int64_t ubase;
-    int* cnt;
-    uint64_t* my_cand;
-};
 
 // candidate path for one finished tile: append every score above the user's threshold, then compact
 // the lists that came within one tile of their capacity
@@ -211,12 +371,12 @@ __device__ __forceinline__ void tile_candidates(const FusedArgs& a, const WaveCt
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const int n = __popc(m[f]);
-        base[f] = n ? atomicAdd(&w.cnt[32 * f + w.c], n) : 0;  // < FE_CAP by the compaction rule
+        base[f] = n ? atomicAdd(&w.cnt[32 * f + w.c], n) : 0;  // < cap by the compaction rule
     }
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const f32x16& acc = f ? acc1 : acc0;
-        uint64_t* list = w.my_cand + static_cast<int64_t>(32 * f + w.c) * FE_CAP + base[f];
+        uint64_t* list = w.my_cand + static_cast<int64_t>(32 * f + w.c) * a.cap + base[f];
         if (m[f]) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -232,8 +392,7 @@ __device__ __forceinline__ void tile_candidates(const FusedArgs& a, const WaveCt
         const int ul = __ffsll(static_cast<long long>(need)) - 1;
         need &= need - 1;
         const int f = ul >> 5;
-        const int u_id = __shfl(f ? uid[1] : uid[0], ul & 31, 64);
-        const float nt = compact_user(a, w.lane, w.my_cand + static_cast<int64_t>(ul) * FE_CAP, &w.cnt[ul], u_id, -1);
+        const float nt = compact_user(a, w, ul, -1);
         if (w.c == (ul & 31)) {
             if (f) thr[1] = nt; else thr[0] = nt;
         }
@@ -275,6 +434,9 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v3(FusedAr
     __shared__ float4 s_bias0[FE_WAVES][16];
     __shared__ float4 s_bias1[FE_WAVES][16];
     __shared__ int s_cnt[FE_WAVES][FE_UW];
+    __shared__ int64_t s_row_beg[FE_WAVES][FE_UW];
+    __shared__ int s_row_len[FE_WAVES][FE_UW];
+    __shared__ int s_rowbuf[FE_WAVES][FE_ROWBUF];
     WaveCtx w;
     w.lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -285,7 +447,22 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v3(FusedAr
     if (w.ubase >= a.B) return;
     w.cnt = s_cnt[wv];
     w.cnt[lane] = 0;
-    w.my_cand = a.cand + w.ubase * FE_CAP;
+    w.my_cand = a.cand + w.ubase * a.cap;
+    w.row_beg = s_row_beg[wv];
+    w.row_len = s_row_len[wv];
+    w.rowbuf = s_rowbuf[wv];
+    {   // lane l caches the train-row extent of the wave's l-th user
+        const int64_t row = w.ubase + lane;
+        int64_t rb = 0;
+        int len = 0;
+        if (a.train_rowptr && row < a.B) {
+            const int u = a.users[row];
+            rb = a.train_rowptr[u];
+            len = static_cast<int>(a.train_rowptr[u + 1] - rb);
+        }
+        w.row_beg[lane] = rb;
+        w.row_len[lane] = len;
+    }
 
     float bf[2][32];
     float thr[2];
@@ -440,9 +617,16 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v3(FusedAr
     for (int ul = 0; ul < FE_UW; ++ul) {
         const int64_t row = w.ubase + ul;
         if (row >= a.B) break;
-        const int u_id = __shfl((ul >> 5) ? uid[1] : uid[0], ul & 31, 64);
-        compact_user(a, lane, w.my_cand + static_cast<int64_t>(ul) * FE_CAP, &w.cnt[ul], u_id, row);
+        compact_user(a, w, ul, row);
     }
+}
+
+// list capacity per user.  Measured on MI355X (K = 10..100, 262 144 users): 512-entry lists with a
+// trigger of 480 were no faster than 256 / 224 once the mid-sweep compaction selects instead of sorting
+// (profiles/r01_eval_history.txt), so the smaller scratch footprint stays.
+int fused_cap(int top_k) {
+    (void)top_k;
+    return FE_CAP;
 }
 
 }  // namespace
@@ -450,10 +634,9 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v3(FusedAr
 extern "C" {
 
 size_t skr_eval_fused_workspace(int B, int top_k) {
-    (void)top_k;
     if (B <= 0) return 0;
     const size_t padded = (static_cast<size_t>(B) + FE_UW - 1) / FE_UW * FE_UW;
-    return padded * FE_CAP * sizeof(uint64_t);
+    return padded * fused_cap(top_k) * sizeof(uint64_t);
 }
 
 int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B, const float* d_item_table,
@@ -472,14 +655,14 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     if (work_bytes < skr_eval_fused_workspace(B, top_k) || !d_work)
         return skr::fail(SKR_ENOMEM, "workspace too small: need %zu bytes", skr_eval_fused_workspace(B, top_k));
     FusedArgs a{d_user_table, d_users, B, d_item_table, d_item_bias, n_items, d_train_rowptr, d_train_items,
-                top_k, static_cast<uint64_t*>(d_work), d_topk_ids, d_topk_scores, 0, 0};
+                top_k, static_cast<uint64_t*>(d_work), d_topk_ids, d_topk_scores, 0, 0, fused_cap(top_k)};
     // compaction trigger: small lists keep the thresholds fresh (fewer candidate events per tile);
-    // a tile adds at most 32 entries per user, so trigger + 32 <= FE_CAP must hold
+    // a tile adds at most 32 entries per user, so trigger + 32 <= cap must hold
     static const int trig_env = [] { const char* e = getenv("SKR_FUSED_TRIGGER"); return e ? atoi(e) : 0; }();
     // measured on MI355X (profiles/r01_eval_history.txt): K=10 is best around K+48, K>=50 at the cap
     a.trigger = trig_env > 0 ? trig_env : 30 + 3 * top_k;
     if (a.trigger < top_k) a.trigger = top_k;
-    if (a.trigger > FE_CAP - FE_TI) a.trigger = FE_CAP - FE_TI;
+    if (a.trigger > a.cap - FE_TI) a.trigger = a.cap - FE_TI;
     static const int ablate = [] { const char* e = getenv("SKR_FUSED_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate;
     const int64_t waves = (static_cast<int64_t>(B) + FE_UW - 1) / FE_UW;
