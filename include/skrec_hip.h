@@ -89,6 +89,19 @@ int skr_randint_choice(skr_sampler* s, int high, int size, int replace, const fl
 int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
                            const int32_t* d_pos_sorted, int64_t nnz, int num_neg, int32_t* d_out, void* stream);
 
+/* The same exact-stream epoch when the number of draws of a user is NOT the size of its exclusion set:
+ * the sequential iterators (data_iterator.py:237-331: one draw group per training sequence, exclusion =
+ * the user's whole history, `user_n_pos` from _generative_time_order_positive_items :44-78) and the
+ * knowledge-graph iterator (_sampling_negative_tails :406-420: one group per triple of a head,
+ * exclusion = its distinct tails).  Users ascending, users with no draws skipped, exactly as the
+ * reference's loop over `user_n_pos.items()`.
+ *   d_rowptr / d_excl_sorted  CSR of the exclusion sets (ascending within a row), nnz entries
+ *   d_drawptr                 int64[n_users+1] cumulative number of draws; n_draws == d_drawptr[n_users]
+ *   d_out                     int32[n_draws] */
+int skr_sample_epoch_exact_counts(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
+                                  const int32_t* d_excl_sorted, int64_t nnz, const int64_t* d_drawptr, int64_t n_draws,
+                                  int32_t* d_out, void* stream);
+
 /* The same distribution, embarrassingly parallel: slot a of user u in epoch e draws from a
  * xoshiro128++ stream keyed by (seed, epoch, global slot index), Lemire-mapped to [0, num_items),
  * retried until not in u's positives.  Bit-exact with its CPU twin (tests/fast_sampler_twin.py),

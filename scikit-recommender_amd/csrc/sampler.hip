@@ -227,6 +227,7 @@ __device__ __forceinline__ int owner_of(const int64_t* __restrict__ rowptr, int 
 
 constexpr int AS_ROW_CAP = 8192;    // row offsets staged in LDS per chunk (32 KB)
 constexpr int AS_POS_CAP = 24576;   // positives staged in LDS per chunk (96 KB)
+constexpr int AS_POS_CAP_SEP = 16384;   // ... when a second offset window shares the LDS (64 KB)
 
 // largest idx in [lo, hi] with a[idx] <= q (a ascending, in LDS)
 __device__ __forceinline__ int lds_owner(const int32_t* a, int lo, int hi, int32_t q) {
@@ -242,12 +243,22 @@ __device__ __forceinline__ int lds_owner(const int32_t* a, int lo, int hi, int32
 // with two coalesced reads, so that the fixed-point rounds (owner search + membership search per
 // draw) run on LDS latency instead of a chain of ~14 dependent HBM misses per draw and round
 // (measured before staging: 0.45 s per 48 M-slot epoch, 8.3 ns per slot).
+//
+// SEP = false: user u owns rowptr[u+1]-rowptr[u] positives and num_neg slots per positive (the pairwise /
+// pointwise iterators).  SEP = true: the slots of user u are drawptr[u] .. drawptr[u+1] while the CSR row
+// is only the exclusion set (sequential and knowledge-graph iterators: the number of training instances
+// of a user is not the size of its exclusion set); num_neg is 1 then.
+template <bool SEP>
 __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
     const uint32_t* __restrict__ raw, int64_t n_raw, uint32_t high, const int64_t* __restrict__ rowptr, int n_users,
     const int32_t* __restrict__ pos_sorted, int num_neg, int64_t n_slots, int64_t slot_start, int32_t* __restrict__ out,
-    int64_t* __restrict__ ctl) {
+    int64_t* __restrict__ ctl, const int64_t* __restrict__ drawptr) {
+    constexpr int POS_CAP = SEP ? AS_POS_CAP_SEP : AS_POS_CAP;
     __shared__ int32_t l_row[AS_ROW_CAP + 1];
-    __shared__ int32_t l_pos[AS_POS_CAP];
+    __shared__ int32_t l_draw[SEP ? AS_ROW_CAP + 1 : 1];
+    __shared__ int32_t l_pos[POS_CAP];
+    const int32_t* l_own = SEP ? l_draw : l_row;          // cumulative slot counts: who owns a slot
+    const int64_t* __restrict__ optr = SEP ? drawptr : rowptr;
     __shared__ int wave_tot[AS_T / SKR_WAVE];
     __shared__ int s_w0, s_uhi_global;
     __shared__ int s_last_idx;
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
         if (tid == 0) {
             const int wend = (w0 + AS_ROW_CAP < n_users) ? w0 + AS_ROW_CAP : n_users;
             int nw0 = w0;
-            if (!(rowptr[wend] > q0)) nw0 = owner_of(rowptr, w0, n_users - 1, q0);  // window would miss q0: re-anchor
+            if (!(optr[wend] > q0)) nw0 = owner_of(optr, w0, n_users - 1, q0);  // window would miss q0: re-anchor
             s_w0 = nw0;
             s_last_idx = -1;
         }
@@ -284,19 +295,24 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
         w0 = s_w0;
         const int wlen = (n_users - w0 < AS_ROW_CAP) ? n_users - w0 : AS_ROW_CAP;  // rows w0 .. w0+wlen-1
         const int64_t pbeg0 = rowptr[w0];
+        const int64_t obeg0 = optr[w0];
         for (int i = tid; i <= wlen; i += AS_T) {
             const int64_t d = rowptr[w0 + i] - pbeg0;
             l_row[i] = d > 0x7fffffff ? 0x7fffffff : static_cast<int32_t>(d);
+            if (SEP) {
+                const int64_t dd = drawptr[w0 + i] - obeg0;
+                l_draw[i] = dd > 0x7fffffff ? 0x7fffffff : static_cast<int32_t>(dd);
+            }
         }
         __syncthreads();
-        const bool q_fits = (q1 - pbeg0) < 0x7fffffff;
-        const bool rows_staged = q_fits && (static_cast<int64_t>(l_row[wlen]) > q1 - pbeg0);  // owner(q1) inside the window
-        const int ulo_i = lds_owner(l_row, 0, wlen - 1, static_cast<int32_t>(q0 - pbeg0));  // q0 is inside by construction
+        const bool q_fits = (q1 - obeg0) < 0x7fffffff;
+        const bool rows_staged = q_fits && (static_cast<int64_t>(l_own[wlen]) > q1 - obeg0);  // owner(q1) inside the window
+        const int ulo_i = lds_owner(l_own, 0, wlen - 1, static_cast<int32_t>(q0 - obeg0));  // q0 is inside by construction
         int uhi_i;
         if (rows_staged) {
-            uhi_i = lds_owner(l_row, ulo_i, wlen - 1, static_cast<int32_t>(q1 - pbeg0));
+            uhi_i = lds_owner(l_own, ulo_i, wlen - 1, static_cast<int32_t>(q1 - obeg0));
         } else {
-            if (tid == 0) s_uhi_global = owner_of(rowptr, w0 + ulo_i, n_users - 1, q1);
+            if (tid == 0) s_uhi_global = owner_of(optr, w0 + ulo_i, n_users - 1, q1);
             __syncthreads();
             uhi_i = s_uhi_global - w0;
         }
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
         // ---- positives of users ulo..uhi ---------------------------------------------------------------
         const int64_t pb = rows_staged ? pbeg0 + l_row[ulo_i] : rowptr[ulo];
         const int64_t pe = rows_staged ? pbeg0 + l_row[uhi_i + 1] : rowptr[uhi + 1];
-        const bool pos_staged = rows_staged && (pe - pb <= AS_POS_CAP);
+        const bool pos_staged = rows_staged && (pe - pb <= POS_CAP);
         if (pos_staged)
             for (int i = tid; i < static_cast<int>(pe - pb); i += AS_T) l_pos[i] = pos_sorted[pb + i];
         const int32_t pb_rel = static_cast<int32_t>(pb - pbeg0);  // only used when rows_staged
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
         const bool nn1 = (num_neg == 1);
         const uint32_t nn = static_cast<uint32_t>(num_neg);
         const uint32_t rb = static_cast<uint32_t>(slot_base % num_neg);
-        const int32_t qb_rel = static_cast<int32_t>(q0 - pbeg0);
+        const int32_t qb_rel = static_cast<int32_t>(q0 - obeg0);
         const int64_t sl64 = n_slots - slot_base;
         const int slots_left = sl64 > AS_C ? AS_C + 1 : static_cast<int>(sl64);   // draws beyond it are never consumed
         // Per draw the last (owner, membership) answer is kept: a later round shifts slots by the number of
@@ -374,8 +390,8 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
                     // 32-bit arithmetic only: a 64-bit division per draw and round dominated this kernel
                     const int32_t qr = qb_rel + static_cast<int32_t>(nn1 ? static_cast<uint32_t>(run_e)
                                                                          : (rb + static_cast<uint32_t>(run_e)) / nn);
-                    if (ui < 0) ui = lds_owner(l_row, ulo_i, uhi_i, qr);
-                    else while (l_row[ui + 1] <= qr) ++ui;      // rows with no positives are skipped too
+                    if (ui < 0) ui = lds_owner(l_own, ulo_i, uhi_i, qr);
+                    else while (l_own[ui + 1] <= qr) ++ui;      // users that own no slot are skipped too
                     if (own[e] == ui) {                         // same user as last round: answer stands
                         if (hitbits & bit) nrej |= bit;
                     } else {
@@ -423,10 +439,10 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
                     const int64_t q = q0 + (nn1 ? static_cast<uint32_t>(run_e) : (rb + static_cast<uint32_t>(run_e)) / nn);
                     bool hit;
                     if (rows_staged) {
-                        const int ui = lds_owner(l_row, ulo_i, uhi_i, static_cast<int32_t>(q - pbeg0));
+                        const int ui = lds_owner(l_own, ulo_i, uhi_i, static_cast<int32_t>(q - obeg0));
                         hit = skr::contains_sorted(pos_sorted, pbeg0 + l_row[ui], pbeg0 + l_row[ui + 1], val[e]);
                     } else {
-                        const int u = owner_of(rowptr, ulo, uhi, q);
+                        const int u = owner_of(optr, ulo, uhi, q);
                         hit = skr::contains_sorted(pos_sorted, rowptr[u], rowptr[u + 1], val[e]);
                     }
                     if (hit) nrej |= bit;
@@ -702,20 +718,10 @@ int skr_randint_choice(skr_sampler* s, int high, int size, int replace, const fl
     return SKR_OK;
 }
 
-int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
-                           const int32_t* d_pos_sorted, int64_t nnz, int num_neg, int32_t* d_out, void* stream) {
-    SKR_REQUIRE(s && d_rowptr && d_pos_sorted && d_out, "skr_sample_epoch_exact: NULL argument");
-    SKR_REQUIRE(num_items > 1, "'high' must be larger than 1.");
-    SKR_REQUIRE(n_users > 0 && num_neg > 0, "skr_sample_epoch_exact: n_users and num_neg must be positive");
-    SKR_REQUIRE(nnz >= 0, "skr_sample_epoch_exact: negative nnz");
-    hipStream_t st = skr::as_stream(stream);
-    if (nnz == 0) return SKR_OK;
-    int max_len = 0;
-    int rc = skr::max_row_len(d_rowptr, n_users, reinterpret_cast<int*>(s->d_ctl + 2), st, &max_len);
-    if (rc) return rc;
-    SKR_REQUIRE(max_len < num_items, "The length of 'exclusion' must be smaller than 'high'.");  // pyx_random.pyx:49
-    const int64_t n_slots = nnz * num_neg;
-    SKR_REQUIRE(n_slots < (int64_t(1) << 31), "more than 2^31-1 samples per call (the reference's int limit)");
+// shared driver of the exact epoch: generate a stretch of the word stream, assign, commit, repeat
+static int run_exact_epoch(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
+                           const int32_t* d_pos_sorted, const int64_t* d_drawptr, int num_neg, int64_t n_slots,
+                           int32_t* d_out, hipStream_t st) {
     int64_t filled = 0;
     int pos = 0;
     while (filled < n_slots) {
@@ -735,9 +741,14 @@ int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int
         }
         hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(GEN_T), 0, st, s->d_state, s->d_pos, s->d_raw, n_gen);
         SKR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(exact_assign_kernel, dim3(1), dim3(AS_T), 0, st, s->d_raw, n_gen,
-                           static_cast<uint32_t>(num_items), d_rowptr, n_users, d_pos_sorted, num_neg, n_slots, filled,
-                           d_out, s->d_ctl);
+        if (d_drawptr)
+            hipLaunchKernelGGL(exact_assign_kernel<true>, dim3(1), dim3(AS_T), 0, st, s->d_raw, n_gen,
+                               static_cast<uint32_t>(num_items), d_rowptr, n_users, d_pos_sorted, 1, n_slots, filled,
+                               d_out, s->d_ctl, d_drawptr);
+        else
+            hipLaunchKernelGGL(exact_assign_kernel<false>, dim3(1), dim3(AS_T), 0, st, s->d_raw, n_gen,
+                               static_cast<uint32_t>(num_items), d_rowptr, n_users, d_pos_sorted, num_neg, n_slots, filled,
+                               d_out, s->d_ctl, static_cast<const int64_t*>(nullptr));
         SKR_LAUNCH_CHECK();
         hipLaunchKernelGGL(mt_commit_kernel, dim3(1), dim3(256), 0, st, s->d_state, s->d_pos, s->d_draws, s->d_raw,
                            n_gen, s->d_ctl);
@@ -757,6 +768,41 @@ int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int
         filled = ctl[0];
     }
     return SKR_OK;
+}
+
+int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
+                           const int32_t* d_pos_sorted, int64_t nnz, int num_neg, int32_t* d_out, void* stream) {
+    SKR_REQUIRE(s && d_rowptr && d_pos_sorted && d_out, "skr_sample_epoch_exact: NULL argument");
+    SKR_REQUIRE(num_items > 1, "'high' must be larger than 1.");
+    SKR_REQUIRE(n_users > 0 && num_neg > 0, "skr_sample_epoch_exact: n_users and num_neg must be positive");
+    SKR_REQUIRE(nnz >= 0, "skr_sample_epoch_exact: negative nnz");
+    hipStream_t st = skr::as_stream(stream);
+    if (nnz == 0) return SKR_OK;
+    int max_len = 0;
+    int rc = skr::max_row_len(d_rowptr, n_users, reinterpret_cast<int*>(s->d_ctl + 2), st, &max_len);
+    if (rc) return rc;
+    SKR_REQUIRE(max_len < num_items, "The length of 'exclusion' must be smaller than 'high'.");  // pyx_random.pyx:49
+    const int64_t n_slots = nnz * num_neg;
+    SKR_REQUIRE(n_slots < (int64_t(1) << 31), "more than 2^31-1 samples per call (the reference's int limit)");
+    return run_exact_epoch(s, num_items, n_users, d_rowptr, d_pos_sorted, nullptr, num_neg, n_slots, d_out, st);
+}
+
+int skr_sample_epoch_exact_counts(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
+                                  const int32_t* d_excl_sorted, int64_t nnz, const int64_t* d_drawptr, int64_t n_draws,
+                                  int32_t* d_out, void* stream) {
+    SKR_REQUIRE(s && d_rowptr && d_drawptr && d_out, "skr_sample_epoch_exact_counts: NULL argument");
+    SKR_REQUIRE(nnz == 0 || d_excl_sorted, "skr_sample_epoch_exact_counts: NULL exclusion array");
+    SKR_REQUIRE(num_items > 1, "'high' must be larger than 1.");
+    SKR_REQUIRE(n_users > 0, "skr_sample_epoch_exact_counts: n_users must be positive");
+    SKR_REQUIRE(nnz >= 0 && nnz < (int64_t(1) << 31), "skr_sample_epoch_exact_counts: bad exclusion size");
+    SKR_REQUIRE(n_draws >= 0 && n_draws < (int64_t(1) << 31), "more than 2^31-1 samples per call (the reference's int limit)");
+    hipStream_t st = skr::as_stream(stream);
+    if (n_draws == 0) return SKR_OK;
+    int max_len = 0;
+    int rc = skr::max_row_len(d_rowptr, n_users, reinterpret_cast<int*>(s->d_ctl + 2), st, &max_len);
+    if (rc) return rc;
+    SKR_REQUIRE(max_len < num_items, "The length of 'exclusion' must be smaller than 'high'.");  // pyx_random.pyx:49
+    return run_exact_epoch(s, num_items, n_users, d_rowptr, d_excl_sorted, d_drawptr, 1, n_draws, d_out, st);
 }
 
 int skr_sample_epoch_fast(uint64_t seed, uint64_t epoch, int64_t slot_offset, int num_items, int n_users,

@@ -30,6 +30,7 @@ SIGNATURES = {
     "skr_sampler_draws": (i32, [vp, C.POINTER(u64)]),
     "skr_randint_choice": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp]),
     "skr_sample_epoch_exact": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, vp]),
+    "skr_sample_epoch_exact_counts": (i32, [vp, i32, i32, vp, vp, i64, vp, i64, vp, vp]),
     "skr_sample_epoch_fast": (i32, [u64, u64, i64, i32, i32, vp, vp, i64, i32, vp, vp]),
     "skr_eval_scores": (i32, [vp, i32, i32, i64, vp, vp, C.POINTER(i32), i32, i32, vp, vp, vp, vp]),
     "skr_eval_fused_workspace": (sz, [i32, i32]),

@@ -197,17 +197,220 @@ PairwiseSampler = PairwiseIterator
 PointwiseSampler = PointwiseIterator
 
 
-def _out_of_scope(name):
-    class _Missing(object):
-        def __init__(self, *args, **kwargs):
-            raise NotImplementedError(f"{name} is outside the hot path this implementation covers "
-                                      f"(SURVEY.md section 8f, row f-3)")
-    _Missing.__name__ = name
-    return _Missing
+class _GroupSampler(object):
+    """Exact-stream negatives when a group's draw count is not the size of its exclusion set: the reference's
+    loop `for key, n in counts.items(): randint_choice(high, size=n * k, exclusion=sets[key])`
+    (data_iterator.py:81-94, :406-420) as one `skr_sample_epoch_exact_counts` call."""
+
+    def __init__(self, high, exclusion_dict, counts, per_group):
+        import torch
+        if high <= 1:
+            raise ValueError("'high' must be larger than 1.")
+        keys = list(counts.keys())
+        rows = [np.unique(np.asarray(exclusion_dict[k], dtype=np.int32)) for k in keys]
+        lens = np.array([len(r) for r in rows], dtype=np.int64)
+        if len(lens) and lens.max() >= high:   # pyx_random.pyx:49
+            raise ValueError("The length of 'exclusion' must be smaller than 'high'.")
+        self.high, self.n_groups = int(high), len(keys)
+        rowptr = np.zeros(self.n_groups + 1, np.int64)
+        np.cumsum(lens, out=rowptr[1:])
+        draws = np.array([counts[k] for k in keys], dtype=np.int64) * int(per_group)
+        drawptr = np.zeros(self.n_groups + 1, np.int64)
+        np.cumsum(draws, out=drawptr[1:])
+        self.nnz, self.n_draws = int(rowptr[-1]), int(drawptr[-1])
+        self.dev = _hip.require_gpu()
+        flat = np.concatenate(rows) if rows and self.nnz else np.zeros(1, np.int32)
+        self.d_rowptr = torch.from_numpy(rowptr).to(self.dev)
+        self.d_excl = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.int32)).to(self.dev)
+        self.d_drawptr = torch.from_numpy(drawptr).to(self.dev)
+
+    def sample(self):
+        import torch
+        out = torch.empty(self.n_draws, dtype=torch.int32, device=self.dev)
+        if self.n_draws:
+            global_sampler().sample_epoch_exact_counts(self.high, self.n_groups, self.d_rowptr, self.d_excl, self.nnz,
+                                                       self.d_drawptr, self.n_draws, out)
+        return out
 
 
-SequentialPointwiseIterator = _out_of_scope("SequentialPointwiseIterator")
-SequentialPairwiseIterator = _out_of_scope("SequentialPairwiseIterator")
-UserVecIterator = _out_of_scope("UserVecIterator")
-ItemVecIterator = _out_of_scope("ItemVecIterator")
-KGPairwiseIterator = _out_of_scope("KGPairwiseIterator")
+def _pad_pre(seqs, value, max_len):
+    """pad_sequences(..., padding='pre', truncating='pre') of utils/py/generic.py for int32 lists"""
+    out = np.full((len(seqs), max_len), value, dtype=np.int32)
+    for r, q in enumerate(seqs):
+        q = q[-max_len:]
+        if len(q):
+            out[r, max_len - len(q):] = q
+    return out
+
+
+def _time_ordered_instances(user_pos_dict, num_previous=1, num_next=1, pad=None):
+    """_generative_time_order_positive_items (data_iterator.py:44-78): for every user, from the full
+    history backwards, the last `num_previous + num_next` items of each prefix; shorter prefixes are kept
+    (left-padded) only when `pad` is given and more than `num_next` items remain."""
+    assert user_pos_dict, "'user_pos_dict' cannot be empty."
+    assert num_previous >= 1
+    assert num_next >= 1
+    tot = num_previous + num_next
+    users, seqs = [], []
+    user_n_pos = OrderedDict()
+    for user, items in user_pos_dict.items():
+        n_items = len(items)
+        stop = num_next if pad is not None else tot - 1     # prefixes of length <= stop end the walk
+        n_inst = max(n_items - stop, 0)
+        if n_inst == 0:
+            continue
+        user_n_pos[user] = n_inst
+        for idx in range(n_items, stop, -1):
+            seqs.append(items[max(idx - tot, 0):idx])
+        users.extend([user] * n_inst)
+    if pad is not None and tot > 2:
+        seqs_ary = _pad_pre(seqs, pad, tot)
+    else:
+        seqs_ary = np.int32(seqs) if seqs else np.zeros((0, tot), np.int32)
+    return user_n_pos, np.int32(users), seqs_ary[:, :num_previous], seqs_ary[:, num_previous:]
+
+
+class SequentialPairwiseIterator(object):
+    """(users, item_seqs, pos_next, neg_next) batches (reference: data_iterator.py:292-331)."""
+
+    def __init__(self, dataset: ImplicitFeedback, num_previous: int = 1, num_next: int = 1, pad: int = None,
+                 batch_size: int = 1024, shuffle: bool = True, drop_last: bool = False):
+        import torch
+        self.num_previous, self.num_next, self.pad = num_previous, num_next, pad
+        self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
+        self.num_items = dataset.num_items
+        self.user_pos_dict = dataset.to_user_dict_by_time()
+        self.user_n_pos, self.all_users, seqs, nxt = _time_ordered_instances(self.user_pos_dict, num_previous, num_next, pad)
+        self.all_item_seqs, self.pos_next_items = seqs.squeeze(), nxt.squeeze()
+        self._g = _GroupSampler(self.num_items, self.user_pos_dict, self.user_n_pos, num_next)
+        dev = self._g.dev
+        self._cols = [torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                      for a in (self.all_users, self.all_item_seqs, self.pos_next_items)]
+
+    def __len__(self):
+        return _n_batches(len(self.all_users), self.batch_size, self.drop_last)
+
+    def iter_device(self):
+        neg = self._g.sample()
+        if self.num_next > 1:
+            neg = neg.view(-1, self.num_next)
+        return _device_batches(self._cols + [neg], self.batch_size, self.shuffle, self.drop_last)
+
+    def __iter__(self):
+        for cols in self.iter_device():
+            yield tuple(c.cpu().numpy() for c in cols)
+
+
+class SequentialPointwiseIterator(object):
+    """(users, item_seqs, next_items, labels) batches (reference: data_iterator.py:237-289).  The reference
+    raises inside np.concatenate when num_neg * num_next == 1 (a 1-D negative array meets the [n, 1]
+    positives, :277-278); here that case yields the squeezed 1-D columns the other shapes reduce to."""
+
+    def __init__(self, dataset: ImplicitFeedback, num_previous: int = 1, num_next: int = 1, num_neg: int = 1,
+                 pad: int = None, batch_size: int = 1024, shuffle: bool = True, drop_last: bool = False):
+        import torch
+        assert num_neg >= 1
+        self.num_previous, self.num_next, self.num_neg, self.pad = num_previous, num_next, num_neg, pad
+        self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
+        self.num_items = dataset.num_items
+        self.user_pos_dict = dataset.to_user_dict_by_time()
+        self.user_n_pos, users, seqs, self.pos_next_items = _time_ordered_instances(self.user_pos_dict, num_previous,
+                                                                                    num_next, pad)
+        self.all_users = np.tile(users, num_neg + 1)
+        self.all_item_seqs = np.tile(seqs, [num_neg + 1, 1]).squeeze()
+        n = len(self.pos_next_items)
+        self.all_labels = np.concatenate([np.ones([n, num_next], np.float32),
+                                          np.zeros([n * num_neg, num_next], np.float32)], axis=0).squeeze()
+        self._g = _GroupSampler(self.num_items, self.user_pos_dict, self.user_n_pos, num_neg * num_next)
+        dev = self._g.dev
+        self._d_users, self._d_seqs, self._d_labels = (torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                                                       for a in (self.all_users, self.all_item_seqs, self.all_labels))
+        self._d_pos_next = torch.from_numpy(np.ascontiguousarray(self.pos_next_items)).to(dev)
+
+    def __len__(self):
+        return _n_batches(len(self.all_users), self.batch_size, self.drop_last)
+
+    def iter_device(self):
+        import torch
+        neg = self._g.sample().view(-1, self.num_neg, self.num_next)           # [n, num_neg * num_next] per user row
+        neg = neg.permute(1, 0, 2).reshape(-1, self.num_next)                    # split on the last axis, stack (:275)
+        nxt = torch.cat([self._d_pos_next, neg], dim=0)
+        if self.num_next == 1:
+            nxt = nxt.view(-1)
+        return _device_batches([self._d_users, self._d_seqs, nxt, self._d_labels], self.batch_size, self.shuffle,
+                               self.drop_last)
+
+    def __iter__(self):
+        for cols in self.iter_device():
+            yield tuple(c.cpu().numpy() for c in cols)
+
+
+class KGPairwiseIterator(object):
+    """(heads, relations, pos_tails, neg_tails) batches (reference: data_iterator.py:423-457).  ``dataset`` is
+    anything with ``num_entities`` and ``to_head_dict()`` -> {head: {"relation": int32[], "tail": int32[]}}."""
+
+    def __init__(self, dataset, num_neg: int = 1, batch_size: int = 1024, shuffle: bool = True, drop_last: bool = False):
+        import torch
+        if num_neg <= 0:
+            raise ValueError("'num_neg' must be a positive integer.")
+        self.batch_size, self.shuffle, self.drop_last, self.num_neg = batch_size, shuffle, drop_last, num_neg
+        self.num_entities = dataset.num_entities
+        self.head_pos_dict = dataset.to_head_dict()
+        assert self.head_pos_dict, "'head_pos_dict' cannot be empty."
+        heads, rels, tails = [], [], []
+        self.head_n_pos = OrderedDict()
+        for head, d in self.head_pos_dict.items():
+            t = np.asarray(d["tail"], dtype=np.int32)
+            tails.append(t)
+            rels.append(np.asarray(d["relation"], dtype=np.int32))
+            heads.append(np.full_like(t, head))
+            self.head_n_pos[head] = len(t)
+        self.all_heads, self.relations, self.pos_tails = (np.concatenate(x) for x in (heads, rels, tails))
+        self._g = _GroupSampler(self.num_entities, {h: d["tail"] for h, d in self.head_pos_dict.items()},
+                                self.head_n_pos, num_neg)
+        self._cols = [torch.from_numpy(np.ascontiguousarray(a)).to(self._g.dev)
+                      for a in (self.all_heads, self.relations, self.pos_tails)]
+
+    def __len__(self):
+        return _n_batches(len(self.all_heads), self.batch_size, self.drop_last)
+
+    def iter_device(self):
+        neg = self._g.sample()
+        if self.num_neg > 1:
+            neg = neg.view(-1, self.num_neg)
+        return _device_batches(self._cols + [neg], self.batch_size, self.shuffle, self.drop_last)
+
+    def __iter__(self):
+        for cols in self.iter_device():
+            yield tuple(c.cpu().numpy() for c in cols)
+
+
+class _VecIterator(object):
+    def __init__(self, matrix, n, batch_size, shuffle, drop_last):
+        self._m, self._n = matrix, n
+        self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
+
+    def __len__(self):
+        return _n_batches(self._n, self.batch_size, self.drop_last)
+
+    def __iter__(self):
+        order = np.random.permutation(self._n) if self.shuffle else np.arange(self._n)
+        for start in range(0, self._n, self.batch_size):
+            idx = order[start:start + self.batch_size]
+            if len(idx) < self.batch_size and self.drop_last:
+                return
+            yield self._m[idx].toarray()
+
+
+class UserVecIterator(_VecIterator):
+    """dense rows of the user-item matrix per batch of users (reference: data_iterator.py:334-352); host-side"""
+
+    def __init__(self, dataset: ImplicitFeedback, batch_size: int = 1024, shuffle: bool = True, drop_last: bool = False):
+        super().__init__(dataset.to_csr_matrix(), dataset.num_users, batch_size, shuffle, drop_last)
+
+
+class ItemVecIterator(_VecIterator):
+    """dense rows of the item-user matrix per batch of items (reference: data_iterator.py:355-373); host-side"""
+
+    def __init__(self, dataset: ImplicitFeedback, batch_size: int = 1024, shuffle: bool = True, drop_last: bool = False):
+        super().__init__(dataset.to_csr_matrix().transpose().tocsr(), dataset.num_items, batch_size, shuffle, drop_last)

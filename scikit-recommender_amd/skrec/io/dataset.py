@@ -132,10 +132,39 @@ class ImplicitFeedback(object):
 
 
 class KnowledgeGraph(object):
-    """Out of the hot path (reference: dataset.py:199-270); present so that imports keep working."""
+    """(head, relation, tail) triples; only what KGPairwiseIterator needs (reference: dataset.py:199-231).
+    Knowledge-graph FILE loading (KGData / CFKGData) stays out of scope."""
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("knowledge-graph data is outside this implementation's scope")
+    def __init__(self, data: pd.DataFrame = None, num_entities: int = None, num_relations: int = None):
+        assert data is None or isinstance(data, pd.DataFrame)
+        if data is None or data.empty:
+            self._data = pd.DataFrame()
+            self.num_entities = self.num_relations = self.num_triplets = 0
+        else:
+            self._data = data
+            self.num_entities = num_entities if num_entities is not None else \
+                int(max(data[_HEAD].max(), data[_TAIL].max())) + 1
+            self.num_relations = num_relations if num_relations is not None else int(data[_RELATION].max()) + 1
+            self.num_triplets = len(data)
+
+    def is_empty(self) -> bool:
+        return self._data is None or self._data.empty
+
+    def to_triplets(self) -> np.ndarray:
+        return self._data[[_HEAD, _RELATION, _TAIL]].to_numpy(copy=True, dtype=np.int32)
+
+    def to_head_dict(self) -> Dict[int, Dict[str, np.ndarray]]:
+        """head -> {"relation": int32[], "tail": int32[]}; heads ascending, triples of a head in file order"""
+        heads = self._data[_HEAD].to_numpy(dtype=np.int64)
+        order = np.argsort(heads, kind="stable")
+        rel = self._data[_RELATION].to_numpy(dtype=np.int32)[order]
+        tail = self._data[_TAIL].to_numpy(dtype=np.int32)[order]
+        bounds = np.flatnonzero(np.diff(heads[order])) + 1
+        out = OrderedDict()
+        for h, r, t in zip(np.split(heads[order], bounds), np.split(rel, bounds), np.split(tail, bounds)):
+            if len(h):
+                out[int(h[0])] = {_RELATION: r, _TAIL: t}
+        return out
 
 
 def _read_table(path, sep, names, missing):

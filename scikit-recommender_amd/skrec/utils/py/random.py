@@ -73,6 +73,12 @@ class DeviceSampler(object):
                                                      _hip.ptr(d_pos_sorted), int(nnz), int(num_neg), _hip.ptr(d_out),
                                                      _hip.stream()))
 
+    def sample_epoch_exact_counts(self, num_items, n_users, d_rowptr, d_excl_sorted, nnz, d_drawptr, n_draws, d_out):
+        """exclusion CSR and per-user draw counts given separately (sequential / knowledge-graph iterators)"""
+        _hip.check(_hip.lib().skr_sample_epoch_exact_counts(self._h, int(num_items), int(n_users), _hip.ptr(d_rowptr),
+                                                            _hip.ptr(d_excl_sorted), int(nnz), _hip.ptr(d_drawptr),
+                                                            int(n_draws), _hip.ptr(d_out), _hip.stream()))
+
 
 _global = None
 

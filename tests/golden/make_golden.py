@@ -310,8 +310,55 @@ def make_layergcn():
     print("layergcn: steps", len(losses), "first/last", losses[0], losses[-1])
 
 
+def make_iterators():
+    """SURVEY 8f-3: the sequential and knowledge-graph iterators, shuffle=False, one process = one stream;
+    tests/test_gpu_iterators.py replays the same constructions in the same order."""
+    _install()
+    import pandas as pd
+    from skrec.io import RSDataset, SequentialPairwiseIterator, SequentialPointwiseIterator, KGPairwiseIterator
+    from skrec.io.dataset import KnowledgeGraph
+    ds = RSDataset(DATA_DIR, "\t", "UIRT")
+    train = ds.train_data
+    out = {}
+
+    def run(it):
+        cols = None
+        for batch in it:
+            if cols is None:
+                cols = [[] for _ in batch]
+            for c, b in zip(cols, batch):
+                c.append(np.asarray(b))
+        return [np.concatenate(c, axis=0) for c in cols]
+
+    def record(tag, it, epochs=1):
+        out[tag + "_len"] = len(it)
+        for e in range(epochs):
+            for k, col in enumerate(run(it)):
+                out[f"{tag}_e{e}_c{k}"] = col
+
+    record("spw", SequentialPairwiseIterator(train, num_previous=3, num_next=1, pad=None, batch_size=128, shuffle=False), 2)
+    record("spwpad", SequentialPairwiseIterator(train, num_previous=4, num_next=2, pad=ds.num_items, batch_size=100,
+                                                shuffle=False, drop_last=True))
+    record("spw11", SequentialPairwiseIterator(train, num_previous=1, num_next=1, pad=None, batch_size=256, shuffle=False))
+    record("spt", SequentialPointwiseIterator(train, num_previous=2, num_next=1, num_neg=2, pad=None, batch_size=128,
+                                              shuffle=False))
+    record("sptpad", SequentialPointwiseIterator(train, num_previous=3, num_next=2, num_neg=2, pad=ds.num_items,
+                                                 batch_size=128, shuffle=False))
+    rng = np.random.default_rng(5)
+    n_ent, n_rel, n_tri = 60, 4, 400
+    tri = np.unique(np.stack([rng.integers(0, 40, n_tri), rng.integers(0, n_rel, n_tri), rng.integers(0, n_ent, n_tri)], 1),
+                    axis=0)
+    tri = tri[rng.permutation(len(tri))]                     # heads in arbitrary file order, duplicate tails per head
+    out["kg_triplets"] = tri.astype(np.int32)
+    kg = KnowledgeGraph(pd.DataFrame(tri, columns=["head", "relation", "tail"]), num_entities=n_ent, num_relations=n_rel)
+    record("kg", KGPairwiseIterator(kg, num_neg=1, batch_size=64, shuffle=False))
+    record("kg3", KGPairwiseIterator(kg, num_neg=3, batch_size=64, shuffle=False))
+    np.savez_compressed(os.path.join(HERE, "golden_iterators.npz"), **out)
+    print("iterators: ok", {k: np.shape(v) for k, v in out.items() if k.endswith("_c0") or k.endswith("_len")})
+
+
 SECTIONS = {"dataset": make_dataset, "sampler": make_sampler, "eval": make_eval, "bprmf": make_bprmf,
-            "lightgcn": make_lightgcn, "layergcn": make_layergcn}
+            "lightgcn": make_lightgcn, "layergcn": make_layergcn, "iterators": make_iterators}
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"

@@ -125,3 +125,31 @@ def test_hot_path_fails_loudly_without_gpu():
     from skrec import _hip
     with pytest.raises(_hip.HipError):
         skrec.randint_choice(10, 3)
+
+
+def test_time_ordered_instances_match_reference(golden, tiny_dir):
+    """_generative_time_order_positive_items restated (data_iterator.py:44-78) == the columns the reference's
+    sequential iterators produced on the tiny dataset (golden_iterators.npz, shuffle=False)."""
+    from skrec.io import RSDataset
+    from skrec.io.data_iterator import _time_ordered_instances
+    g = golden("golden_iterators")
+    ds = RSDataset(tiny_dir, "\t", "UIRT")
+    ud = ds.train_data.to_user_dict_by_time()
+    for tag, (npv, nnx, pad), n_take in (("spw", (3, 1, None), None), ("spw11", (1, 1, None), None),
+                                         ("spwpad", (4, 2, ds.num_items), 600)):
+        n_pos, users, seqs, nxt = _time_ordered_instances(ud, npv, nnx, pad)
+        assert sum(n_pos.values()) == len(users)
+        sl = slice(0, n_take)
+        assert np.array_equal(users[sl], g[tag + "_e0_c0"])
+        assert np.array_equal(seqs.squeeze()[sl], g[tag + "_e0_c1"])
+        assert np.array_equal(nxt.squeeze()[sl], g[tag + "_e0_c2"])
+
+
+def test_knowledge_graph_head_dict_order():
+    import pandas as pd
+    from skrec.io.dataset import KnowledgeGraph
+    tri = np.array([[3, 0, 5], [1, 1, 2], [3, 1, 5], [1, 0, 9], [0, 0, 1]])
+    kg = KnowledgeGraph(pd.DataFrame(tri, columns=["head", "relation", "tail"]))
+    d = kg.to_head_dict()
+    assert list(d) == [0, 1, 3] and kg.num_entities == 10 and kg.num_relations == 2
+    assert d[3]["tail"].tolist() == [5, 5] and d[3]["relation"].tolist() == [0, 1] and d[1]["tail"].tolist() == [2, 9]

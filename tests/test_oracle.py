@@ -179,3 +179,45 @@ def test_layergcn_trajectory_matches_reference(golden):
     np.testing.assert_allclose(E0[:U], g["U1"], rtol=0, atol=2e-6)
     out, _, _ = O.layergcn_forward(A, E0, 4)
     np.testing.assert_allclose(out[:U], g["Uf"], rtol=0, atol=5e-6)
+
+
+def test_oracle_stream_reproduces_sequential_and_kg_iterators(golden):
+    """The restated sampler, driven the way the reference's loops drive it (one randint_choice per user / head
+    with that group's draw count and exclusion set), reproduces the negatives of the reference's
+    sequential and knowledge-graph iterators (golden_iterators.npz) -- pins the oracle for SURVEY 8f-3."""
+    from oracle import oracle as O
+    g = golden("golden_iterators")
+    tiny = golden("tiny_dataset")
+    tr = tiny["train"]
+    order = np.lexsort((np.arange(len(tr)), tr[:, 2], tr[:, 0]))      # columns (user, item, time): by user, then time
+    users, items = tr[order, 0].astype(np.int64), tr[order, 1].astype(np.int32)
+    hist = {int(u): items[users == u] for u in np.unique(users)}
+    n_items = int(tiny["num_items"])
+    s = O.Sampler(2020)
+
+    def epoch(counts, excl, high, k):
+        out = []
+        for key, n in counts:
+            r = np.atleast_1d(s.randint_choice(high, n * k, exclusion=excl[key]))
+            out.append(r.reshape(n, k) if k > 1 else r)
+        return np.concatenate(out)
+
+    def counts(stop):
+        return [(u, len(h) - stop) for u, h in hist.items() if len(h) > stop]
+
+    # the constructions of make_golden.make_iterators, in order
+    assert np.array_equal(epoch(counts(3), hist, n_items, 1), g["spw_e0_c3"])
+    assert np.array_equal(epoch(counts(3), hist, n_items, 1), g["spw_e1_c3"])
+    assert np.array_equal(epoch(counts(2), hist, n_items, 2)[:600], g["spwpad_e0_c3"])
+    assert np.array_equal(epoch(counts(1), hist, n_items, 1), g["spw11_e0_c3"])
+    neg = epoch(counts(2), hist, n_items, 2)                             # spt: num_neg=2, num_next=1
+    n = len(neg)
+    assert np.array_equal(np.concatenate([neg[:, 0], neg[:, 1]]), g["spt_e0_c2"][n:])
+    neg = epoch(counts(2), hist, n_items, 4)                             # sptpad: num_neg=2, num_next=2
+    assert np.array_equal(np.concatenate([neg[:, :2], neg[:, 2:]], 0), g["sptpad_e0_c2"][len(neg):])
+    tri = g["kg_triplets"]
+    heads = np.unique(tri[:, 0])
+    tails = {int(h): tri[tri[:, 0] == h][:, 2] for h in heads}
+    kc = [(int(h), len(tails[int(h)])) for h in heads]
+    assert np.array_equal(epoch(kc, tails, 60, 1), g["kg_e0_c3"])
+    assert np.array_equal(epoch(kc, tails, 60, 3), g["kg3_e0_c3"])
