@@ -235,6 +235,52 @@ int skr_gather_rows(const float* d_table, const int32_t* d_idx, int64_t n, int d
 int skr_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
 int skr_scale(float a, float* d_x, int64_t n, void* stream);                 /* x *= a */
 
+/* ---------------------------------------------------------------------------------------------
+ * G rows: GRU4RecPlus, recommender/GRU4RecPlus.py.  PARITY UNPINNED -- the reference runs this
+ * model on TensorFlow 1.14, absent here; these entry points follow the graph of GRU4RecPlus.py:124-200 and
+ * the published semantics of tf.nn.rnn_cell.GRUCell / tf.train.AdamOptimizer (oracle/gru4rec.py).
+ * hid in {32, 64, 128}, in_dim <= 128.  hidden_act_kind: 0 tanh, 1 relu (:76-81).  final_act_kind:
+ * 0 linear, 1 relu, 2 leaky_relu(0.2) (:84-91).  loss_kind: 0 bpr_max, 1 top1_max (:93-98).
+ * ------------------------------------------------------------------------------------------- */
+
+/* One GRUCell.call for B sessions (GRU4RecPlus.py:168-178):
+ *   [r|u] = sigmoid([x,h] Wg + bg), c = act([x, r*h] Wc + bc), h' = u*h + (1-u)*c.
+ *   d_x        float32 [B, in_dim], or -- when d_x_index != NULL -- an embedding table whose row
+ *              d_x_index[b] is the input of session b (tf.nn.embedding_lookup fused in)
+ *   d_active   uint8 [B] or NULL: 0 keeps h' = h (histories that already ended, _get_user_embeddings)
+ *   d_Wg [in_dim+hid, 2*hid], d_bg [2*hid], d_Wc [in_dim+hid, hid], d_bc [hid]   (TF kernel layout)
+ *   d_r, d_u, d_c  float32 [B, hid] saved for the backward pass, each may be NULL;  d_h_new [B, hid] */
+int skr_gru_cell_fwd(const float* d_x, const int32_t* d_x_index, const float* d_h, const uint8_t* d_active, int B,
+                     int in_dim, int hid, const float* d_Wg, const float* d_bg, const float* d_Wc, const float* d_bc,
+                     int hidden_act_kind, float* d_r, float* d_u, float* d_c, float* d_h_new, void* stream);
+
+/* Its backward for one step (the state enters through a placeholder, :127: no gradient into h).
+ * Accumulates (+=) into d_gWg, d_gbg, d_gWc, d_gbc; writes dL/dx to d_dx [B, in_dim].
+ * d_work: float32 scratch of 3*B*hid elements. */
+int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_h, int B, int in_dim, int hid,
+                     const float* d_Wg, const float* d_Wc, int hidden_act_kind, const float* d_r, const float* d_u,
+                     const float* d_c, const float* d_dh_new, float* d_gWg, float* d_gbg, float* d_gWc, float* d_gbc,
+                     float* d_dx, float* d_work, void* stream);
+
+/* logits = final_act(out . E[Y]^T + bias[Y]) for B sessions against n_y targets (the batch's own next
+ * items first: column b is session b's positive, :180-186), bpr_max / top1_max loss (:137-166) and its
+ * gradient.  d_loss[0] += mean loss; d_dlogits [B, n_y] = dL/d(pre-activation logits);
+ * d_dout [B, hid] = dL/d out.  B <= n_y <= 8192. */
+int skr_session_loss(const float* d_out, int B, int hid, const float* d_item_table, const float* d_item_bias,
+                     const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
+                     float* d_dout, float* d_loss, void* stream);
+
+/* Output-side gradients of the same step, accumulated into dense gradient tables:
+ *   d_g_table[Y[y]] += sum_b dlogits[b,y] out[b] + reg * E[Y[y]],  d_g_bias[Y[y]] += sum_b dlogits[b,y] + reg * bias[Y[y]]
+ * (reg: the l2_loss term of :189-191; repeated targets count each time).  d_touch / d_touch_base as in skr_bpr_step. */
+int skr_session_out_grads(const float* d_dlogits, const float* d_out, int B, int hid, const int32_t* d_y, int n_y,
+                          const float* d_item_table, const float* d_item_bias, float reg, float* d_g_table,
+                          float* d_g_bias, uint8_t* d_touch, const float* d_touch_base, void* stream);
+
+/* d_g_table[index[n]] += src[n] + reg * table[index[n]]: gradient of an embedding lookup (+ l2_loss of the looked-up rows) */
+int skr_scatter_add_rows(const float* d_src, const int32_t* d_index, int n, int dim, const float* d_table, float reg,
+                         float* d_g_table, uint8_t* d_touch, const float* d_touch_base, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,521 @@
+// gru.hip -- SURVEY 8 row G / f-4: GRU4RecPlus, the session-parallel recurrent recommender.
+//
+// Replaces the TensorFlow-1.14 graph the reference builds (recommender/GRU4RecPlus.py:124-200):
+//   :168-178  embedding lookup + tf.nn.rnn_cell.GRUCell stack           -> gru_fwd_kernel / gru_bwd_*
+//   :180-186  logits against the batch's own positives + shared samples -> session_loss_kernel
+//   :137-166  _softmax_neg, _bpr_max_loss, _top1_max_loss (+ autograd)  -> session_loss_kernel
+//   :190-192  l2_loss + AdamOptimizer.minimize (dense update)           -> session_out_grads_kernel,
+//                                                                          scatter_add_rows_kernel, skr_adam_step
+// The recurrent state is fed through placeholders, so a training step is a one-step truncated BPTT:
+// gradients stop at the incoming state.  The work per step is tiny (b = 128 sessions, 2 176 targets),
+// so these kernels are written for few launches and L2-resident operands, not for MFMA; the inference
+// sweep (`_get_user_embeddings`, :256-302) runs ALL users in parallel, one GRU step per history
+// position, through the same forward kernel.  PARITY UNPINNED (TensorFlow absent): the tests check
+// against a torch-CPU restatement of the same graph.
+#include "skr_common.h"
+
+#include <cmath>
+
+namespace {
+
+constexpr int G_ROWS = 16;     // sessions per workgroup
+constexpr int G_T = 256;
+constexpr int G_KMAX = 256;    // in_dim + hid
+constexpr int G_HMAX = 128;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float hidden_act(float x, int act) { return act == 0 ? tanhf(x) : fmaxf(x, 0.0f); }
+// derivative of the hidden activation expressed through its OUTPUT c
+__device__ __forceinline__ float hidden_act_grad(float c, int act) { return act == 0 ? 1.0f - c * c : (c > 0.0f ? 1.0f : 0.0f); }
+
+struct GruIn {
+    const float* x;          // [B, in] rows, or an embedding table when x_index != nullptr
+    const int32_t* x_index;  // nullable: x row of session b = x[x_index[b]]
+    const float* h;          // [B, hid]
+    int B, in_dim, hid;
+};
+
+__device__ __forceinline__ const float* x_row(const GruIn& g, int row) {
+    return g.x + static_cast<int64_t>(g.x_index ? g.x_index[row] : row) * g.in_dim;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: tf.nn.rnn_cell.GRUCell.call
+//   [r | u] = sigmoid([x, h] Wg + bg) ;  c = act([x, r*h] Wc + bc) ;  h' = u*h + (1-u)*c
+// 16 sessions per workgroup, their [x, h] rows staged in LDS; a thread owns one output column and
+// 16 / (256 / columns) of the rows, so each weight is read once per workgroup from L2.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __restrict__ active,
+                                                      const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                      const float* __restrict__ Wc, const float* __restrict__ bc, int act,
+                                                      float* __restrict__ r_out, float* __restrict__ u_out,
+                                                      float* __restrict__ c_out, float* __restrict__ h_new) {
+    __shared__ float a[G_ROWS][G_KMAX];
+    __shared__ float rh[G_ROWS][G_HMAX];
+    __shared__ float us[G_ROWS][G_HMAX];
+    const int tid = threadIdx.x;
+    const int IN = g.in_dim, H = g.hid, K = IN + H;
+    const int row0 = blockIdx.x * G_ROWS;
+    for (int idx = tid; idx < G_ROWS * K; idx += G_T) {
+        const int r = idx / K, k = idx - r * K;
+        const int row = row0 + r;
+        float v = 0.0f;
+        if (row < g.B) v = (k < IN) ? x_row(g, row)[k] : g.h[static_cast<int64_t>(row) * H + (k - IN)];
+        a[r][k] = v;
+    }
+    __syncthreads();
+    {   // gates
+        const int C = 2 * H;
+        const int j = tid % C, g0 = tid / C, ng = G_T / C, per = G_ROWS / ng;
+        float acc[G_ROWS];
+#pragma unroll
+        for (int i = 0; i < G_ROWS; ++i) acc[i] = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float w = Wg[static_cast<int64_t>(k) * C + j];
+#pragma unroll
+            for (int i = 0; i < G_ROWS; ++i)
+                if (i < per) acc[i] = fmaf(a[g0 + i * ng][k], w, acc[i]);
+        }
+        const float b = bg[j];
+#pragma unroll
+        for (int i = 0; i < G_ROWS; ++i) {
+            if (i < per) {
+                const int r = g0 + i * ng, row = row0 + r;
+                const float s = sigmoidf_(acc[i] + b);
+                if (j < H) {
+                    rh[r][j] = s * a[r][IN + j];
+                    if (r_out && row < g.B) r_out[static_cast<int64_t>(row) * H + j] = s;
+                } else {
+                    us[r][j - H] = s;
+                    if (u_out && row < g.B) u_out[static_cast<int64_t>(row) * H + (j - H)] = s;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {   // candidate and new state
+        const int j = tid % H, g0 = tid / H, ng = G_T / H, per = G_ROWS / ng;
+        float acc[G_ROWS / 2];
+#pragma unroll
+        for (int i = 0; i < G_ROWS / 2; ++i) acc[i] = 0.0f;
+        for (int k = 0; k < IN; ++k) {
+            const float w = Wc[static_cast<int64_t>(k) * H + j];
+#pragma unroll
+            for (int i = 0; i < G_ROWS / 2; ++i)
+                if (i < per) acc[i] = fmaf(a[g0 + i * ng][k], w, acc[i]);
+        }
+        for (int k = 0; k < H; ++k) {
+            const float w = Wc[static_cast<int64_t>(IN + k) * H + j];
+#pragma unroll
+            for (int i = 0; i < G_ROWS / 2; ++i)
+                if (i < per) acc[i] = fmaf(rh[g0 + i * ng][k], w, acc[i]);
+        }
+        const float b = bc[j];
+#pragma unroll
+        for (int i = 0; i < G_ROWS / 2; ++i) {
+            if (i < per) {
+                const int r = g0 + i * ng, row = row0 + r;
+                if (row < g.B) {
+                    const float c = hidden_act(acc[i] + b, act);
+                    const float ho = a[r][IN + j], u = us[r][j];
+                    float hn = u * ho + (1.0f - u) * c;
+                    if (active && !active[row]) hn = ho;        // finished history: the state is carried
+                    if (c_out) c_out[static_cast<int64_t>(row) * H + j] = c;
+                    h_new[static_cast<int64_t>(row) * H + j] = hn;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 1 (per session): pre-activation gradients and dL/dx
+//   dc~ = dh' (1-u) act'(c) ;  du~ = dh' (h - c) u (1-u) ;  d(rh) = dc~ Wc[in:,:]^T ;  dr~ = d(rh) h r (1-r)
+//   dx  = dc~ Wc[:in,:]^T + [dr~ | du~] Wg[:in,:]^T
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float* __restrict__ Wg,
+                                                           const float* __restrict__ Wc, int act,
+                                                           const float* __restrict__ r_in, const float* __restrict__ u_in,
+                                                           const float* __restrict__ c_in, const float* __restrict__ dh_new,
+                                                           float* __restrict__ dcp_out, float* __restrict__ dg_out,
+                                                           float* __restrict__ dx_out) {
+    __shared__ float dcp[G_ROWS][G_HMAX];
+    __shared__ float dg[G_ROWS][2 * G_HMAX];
+    __shared__ float hh[G_ROWS][G_HMAX];
+    __shared__ float rr[G_ROWS][G_HMAX];
+    const int tid = threadIdx.x;
+    const int IN = g.in_dim, H = g.hid;
+    const int row0 = blockIdx.x * G_ROWS;
+    for (int idx = tid; idx < G_ROWS * H; idx += G_T) {
+        const int r = idx / H, j = idx - r * H, row = row0 + r;
+        float vdc = 0.0f, vdu = 0.0f, vh = 0.0f, vr = 0.0f;
+        if (row < g.B) {
+            const int64_t o = static_cast<int64_t>(row) * H + j;
+            const float d = dh_new[o], u = u_in[o], c = c_in[o];
+            vh = g.h[o];
+            vr = r_in[o];
+            vdc = d * (1.0f - u) * hidden_act_grad(c, act);
+            vdu = d * (vh - c) * u * (1.0f - u);
+        }
+        dcp[r][j] = vdc;
+        dg[r][H + j] = vdu;
+        hh[r][j] = vh;
+        rr[r][j] = vr;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G_ROWS * H; idx += G_T) {
+        const int r = idx / H, k = idx - r * H;
+        const float* w = Wc + static_cast<int64_t>(IN + k) * H;
+        float s = 0.0f;
+        for (int j = 0; j < H; ++j) s = fmaf(dcp[r][j], w[j], s);
+        const float rv = rr[r][k];
+        dg[r][k] = s * hh[r][k] * rv * (1.0f - rv);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G_ROWS * IN; idx += G_T) {
+        const int r = idx / IN, i = idx - r * IN, row = row0 + r;
+        if (row >= g.B) continue;
+        const float* wc = Wc + static_cast<int64_t>(i) * H;
+        const float* wg = Wg + static_cast<int64_t>(i) * 2 * H;
+        float s = 0.0f;
+        for (int j = 0; j < H; ++j) s = fmaf(dcp[r][j], wc[j], s);
+        for (int j = 0; j < 2 * H; ++j) s = fmaf(dg[r][j], wg[j], s);
+        dx_out[static_cast<int64_t>(row) * IN + i] = s;
+    }
+    for (int idx = tid; idx < G_ROWS * H; idx += G_T) {
+        const int r = idx / H, j = idx - r * H, row = row0 + r;
+        if (row >= g.B) continue;
+        dcp_out[static_cast<int64_t>(row) * H + j] = dcp[r][j];
+        dg_out[static_cast<int64_t>(row) * 2 * H + j] = dg[r][j];
+        dg_out[static_cast<int64_t>(row) * 2 * H + H + j] = dg[r][H + j];
+    }
+}
+
+// backward, part 2 (per weight): dWg += [x,h]^T [dr~|du~] ; dWc += [x, r*h]^T dc~ ; bias sums.
+// One thread per weight, a loop over the (few) sessions of the batch.
+__global__ __launch_bounds__(G_T) void gru_bwd_weights_kernel(GruIn g, const float* __restrict__ r_in,
+                                                              const float* __restrict__ dcp, const float* __restrict__ dgp,
+                                                              float* __restrict__ gWg, float* __restrict__ gbg,
+                                                              float* __restrict__ gWc, float* __restrict__ gbc) {
+    const int IN = g.in_dim, H = g.hid, K = IN + H;
+    const int64_t n_g = static_cast<int64_t>(K) * 2 * H, n_c = static_cast<int64_t>(K) * H;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * G_T + threadIdx.x;
+    if (t < n_g) {
+        const int k = static_cast<int>(t / (2 * H)), j = static_cast<int>(t - static_cast<int64_t>(k) * 2 * H);
+        float s = 0.0f;
+        for (int b = 0; b < g.B; ++b) {
+            const float av = (k < IN) ? x_row(g, b)[k] : g.h[static_cast<int64_t>(b) * H + (k - IN)];
+            s = fmaf(av, dgp[static_cast<int64_t>(b) * 2 * H + j], s);
+        }
+        gWg[t] += s;
+    } else if (t < n_g + n_c) {
+        const int64_t q = t - n_g;
+        const int k = static_cast<int>(q / H), j = static_cast<int>(q - static_cast<int64_t>(k) * H);
+        float s = 0.0f;
+        for (int b = 0; b < g.B; ++b) {
+            const int64_t o = static_cast<int64_t>(b) * H + (k - IN);
+            const float av = (k < IN) ? x_row(g, b)[k] : r_in[o] * g.h[o];
+            s = fmaf(av, dcp[static_cast<int64_t>(b) * H + j], s);
+        }
+        gWc[q] += s;
+    } else if (t < n_g + n_c + 2 * H) {
+        const int j = static_cast<int>(t - n_g - n_c);
+        float s = 0.0f;
+        for (int b = 0; b < g.B; ++b) s += dgp[static_cast<int64_t>(b) * 2 * H + j];
+        gbg[j] += s;
+    } else if (t < n_g + n_c + 3 * H) {
+        const int j = static_cast<int>(t - n_g - n_c - 2 * H);
+        float s = 0.0f;
+        for (int b = 0; b < g.B; ++b) s += dcp[static_cast<int64_t>(b) * H + j];
+        gbc[j] += s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss: one workgroup per session b.  logits[y] = final_act(out[b] . E[Y[y]] + bias[Y[y]]); the
+// session's own positive is column b.  _softmax_neg masks that column, bpr_max / top1_max weigh the
+// pairwise terms with it; the hand-derived gradient (checked against autograd in the tests):
+//   s_y = softmax over y != b of l_y (the masked column enters the max as 0, GRU4RecPlus.py:139-141)
+//   bpr_max : P = sum s_y sig(l_b - l_y), R = sum s_y l_y^2, L = -log(P + 1e-24) + lam R
+//             dL/dl_y = -[ s_y (sig_y - P) - sig_y (1 - sig_y) s_y ] / (P + eps) + lam [ 2 l_y s_y + s_y (l_y^2 - R) ]
+//             dL/dl_b = -[ sum_y sig_y (1 - sig_y) s_y ] / (P + eps)
+//   top1_max: q_y = sig(l_y - l_b) + sig(l_y^2), L = sum s_y q_y
+//             dL/dl_y = s_y [ sig'(l_y - l_b) + 2 l_y sig'(l_y^2) ] + s_y (q_y - L) ;  dL/dl_b = -sum_y s_y sig'(l_y - l_b)
+// ------------------------------------------------------------------------------------------------
+constexpr int L_NY_MAX = 8192;
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(v, o, 64);
+        v = is_max ? fmaxf(v, t) : v + t;
+    }
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < G_T / 64; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+    return r;
+}
+
+__device__ __forceinline__ float final_act_fwd(float x, int kind) {
+    return kind == 0 ? x : (kind == 1 ? fmaxf(x, 0.0f) : fmaxf(x, 0.2f * x));
+}
+__device__ __forceinline__ float final_act_grad(float l, int kind) {  // through the OUTPUT l
+    return kind == 0 ? 1.0f : (kind == 1 ? (l > 0.0f ? 1.0f : 0.0f) : (l > 0.0f ? 1.0f : 0.2f));
+}
+
+__global__ __launch_bounds__(G_T) void session_loss_kernel(const float* __restrict__ out, int B, int H,
+                                                           const float* __restrict__ E, const float* __restrict__ bias,
+                                                           const int32_t* __restrict__ Y, int n_y, int fact, int loss_kind,
+                                                           float bpr_reg, float* __restrict__ dlogits,
+                                                           float* __restrict__ dout, float* __restrict__ loss) {
+    __shared__ float lg[L_NY_MAX];
+    __shared__ float hrow[G_HMAX];
+    __shared__ float red[G_T / 64];
+    __shared__ float part[G_T];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int d = tid; d < H; d += G_T) hrow[d] = out[static_cast<int64_t>(b) * H + d];
+    __syncthreads();
+    float mx = 0.0f;   // the masked column contributes a 0 to the max
+    for (int y = tid; y < n_y; y += G_T) {
+        const int item = Y[y];
+        const float4* e = reinterpret_cast<const float4*>(E + static_cast<int64_t>(item) * H);
+        float s = 0.0f;
+        for (int q = 0; q < H / 4; ++q) {
+            const float4 v = e[q];
+            s = fmaf(hrow[4 * q], v.x, s); s = fmaf(hrow[4 * q + 1], v.y, s);
+            s = fmaf(hrow[4 * q + 2], v.z, s); s = fmaf(hrow[4 * q + 3], v.w, s);
+        }
+        const float l = final_act_fwd(s + bias[item], fact);
+        lg[y] = l;
+        if (y != b) mx = fmaxf(mx, l);
+    }
+    mx = block_reduce(mx, red, true);
+    const float pos = lg[b];
+    float z = 0.0f;
+    for (int y = tid; y < n_y; y += G_T)
+        if (y != b) z += expf(lg[y] - mx);
+    z = block_reduce(z, red, false);
+    // first moments: P and R (bpr_max) or L (top1_max), plus the gradient of the positive
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int y = tid; y < n_y; y += G_T) {
+        if (y == b) continue;
+        const float l = lg[y], s = expf(l - mx) / z;
+        if (loss_kind == 0) {
+            const float sg = sigmoidf_(pos - l);
+            a0 += sg * s;
+            a1 += l * l * s;
+            a2 += sg * (1.0f - sg) * s;
+        } else {
+            const float s1 = sigmoidf_(l - pos), s2 = sigmoidf_(l * l);
+            a0 += (s1 + s2) * s;
+            a2 += s1 * (1.0f - s1) * s;
+        }
+    }
+    a0 = block_reduce(a0, red, false);
+    a1 = block_reduce(a1, red, false);
+    a2 = block_reduce(a2, red, false);
+    const float invB = 1.0f / static_cast<float>(B);
+    float lb, gpos;
+    if (loss_kind == 0) {
+        lb = -logf(a0 + 1e-24f) + bpr_reg * a1;
+        gpos = -a2 / (a0 + 1e-24f);
+    } else {
+        lb = a0;
+        gpos = -a2;
+    }
+    if (tid == 0) atomicAdd(loss, lb * invB);
+    __syncthreads();
+    for (int y = tid; y < n_y; y += G_T) {
+        const float l = lg[y];
+        float gy;
+        if (y == b) {
+            gy = gpos;
+        } else {
+            const float s = expf(l - mx) / z;
+            if (loss_kind == 0) {
+                const float sg = sigmoidf_(pos - l);
+                const float dP = s * (sg - a0) - sg * (1.0f - sg) * s;
+                const float dR = 2.0f * l * s + s * (l * l - a1);
+                gy = -dP / (a0 + 1e-24f) + bpr_reg * dR;
+            } else {
+                const float s1 = sigmoidf_(l - pos), s2 = sigmoidf_(l * l);
+                gy = s * (s1 * (1.0f - s1) + 2.0f * l * s2 * (1.0f - s2)) + s * ((s1 + s2) - a0);
+            }
+        }
+        gy *= invB * final_act_grad(l, fact);
+        dlogits[static_cast<int64_t>(b) * n_y + y] = gy;
+        lg[y] = gy;   // each y is owned by one thread in both loops
+    }
+    __syncthreads();
+    // dL/dout[b] = sum_y g_y E[Y[y]]: threads split into 256/H groups over y, lanes over the dimension
+    {
+        const int d = tid % H, grp = tid / H, ng = G_T / H;
+        float s = 0.0f;
+        for (int y = grp; y < n_y; y += ng) s = fmaf(lg[y], E[static_cast<int64_t>(Y[y]) * H + d], s);
+        part[tid] = s;
+        __syncthreads();
+        if (tid < H) {
+            float t = 0.0f;
+            for (int q = 0; q < ng; ++q) t += part[q * H + tid];
+            dout[static_cast<int64_t>(b) * H + tid] = t;
+        }
+    }
+}
+
+// mark the 64-float blocks of the flat gradient buffer that [a, a+n) overlaps (DenseAdam's touch bytes)
+__device__ __forceinline__ void mark_range(uint8_t* touch, const float* base, const float* a, int n) {
+    const int64_t b0 = (a - base) >> 6, b1 = (a + n - 1 - base) >> 6;
+    for (int64_t k = b0; k <= b1; ++k)
+        if (touch[k] == 0) touch[k] = 1;
+}
+
+// output-side gradients: one wavefront per target y.
+//   gE[Y[y]] += sum_b dlogits[b, y] out[b] + reg E[Y[y]] ;  gb[Y[y]] += sum_b dlogits[b, y] + reg bias[Y[y]]
+// (an item that occurs several times in Y is counted each time, like tf.gather's gradient and l2_loss)
+__global__ __launch_bounds__(G_T) void session_out_grads_kernel(const float* __restrict__ dlogits,
+                                                                const float* __restrict__ out, int B, int H,
+                                                                const int32_t* __restrict__ Y, int n_y,
+                                                                const float* __restrict__ E, const float* __restrict__ bias,
+                                                                float reg, float* __restrict__ gE, float* __restrict__ gb,
+                                                                uint8_t* __restrict__ touch, const float* touch_base) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int y = blockIdx.x * (G_T / 64) + wv;
+    if (y >= n_y) return;
+    const int64_t item = Y[y];
+    float acc0 = 0.0f, acc1 = 0.0f, colsum = 0.0f;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int bl = b0 + lane;
+        const float mine = bl < B ? dlogits[static_cast<int64_t>(bl) * n_y + y] : 0.0f;
+        colsum += mine;
+        const int lim = (B - b0) < 64 ? (B - b0) : 64;
+        for (int k = 0; k < lim; ++k) {
+            const float gk = __shfl(mine, k, 64);
+            const float* o = out + static_cast<int64_t>(b0 + k) * H;
+            acc0 = fmaf(gk, lane < H ? o[lane] : 0.0f, acc0);
+            if (H > 64) acc1 = fmaf(gk, o[64 + lane], acc1);
+        }
+    }
+    colsum = skr::wave_sum(colsum);
+    float* ge = gE + item * H;
+    if (lane < H) atomicAdd(&ge[lane], acc0 + reg * E[item * H + lane]);
+    if (H > 64) atomicAdd(&ge[64 + lane], acc1 + reg * E[item * H + 64 + lane]);
+    if (lane == 0) {
+        atomicAdd(&gb[item], colsum + reg * bias[item]);
+        if (touch) {
+            mark_range(touch, touch_base, ge, H);
+            mark_range(touch, touch_base, &gb[item], 1);
+        }
+    }
+}
+
+// g_table[index[n]] += src[n] + reg * table[index[n]]   (the input-embedding gradient)
+__global__ __launch_bounds__(G_T) void scatter_add_rows_kernel(const float* __restrict__ src,
+                                                               const int32_t* __restrict__ index, int n, int dim,
+                                                               const float* __restrict__ table, float reg,
+                                                               float* __restrict__ g_table, uint8_t* __restrict__ touch,
+                                                               const float* touch_base) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * (G_T / 64) + wv;
+    if (r >= n) return;
+    const int64_t row = index[r];
+    for (int d = lane; d < dim; d += 64) {
+        float v = src[static_cast<int64_t>(r) * dim + d];
+        if (reg != 0.0f) v += reg * table[row * dim + d];
+        atomicAdd(&g_table[row * dim + d], v);
+    }
+    if (touch && lane == 0) mark_range(touch, touch_base, g_table + row * dim, dim);
+}
+
+bool dims_ok(int in_dim, int hid) {
+    return (hid == 32 || hid == 64 || hid == 128) && in_dim >= 1 && in_dim <= 128 && in_dim + hid <= G_KMAX;
+}
+
+}  // namespace
+
+extern "C" {
+
+int skr_gru_cell_fwd(const float* d_x, const int32_t* d_x_index, const float* d_h, const uint8_t* d_active, int B,
+                     int in_dim, int hid, const float* d_Wg, const float* d_bg, const float* d_Wc, const float* d_bc,
+                     int hidden_act_kind, float* d_r, float* d_u, float* d_c, float* d_h_new, void* stream) {
+    SKR_REQUIRE(d_x && d_h && d_Wg && d_bg && d_Wc && d_bc && d_h_new, "skr_gru_cell_fwd: NULL argument");
+    SKR_REQUIRE(dims_ok(in_dim, hid), "skr_gru_cell_fwd: hid must be 32, 64 or 128 and in_dim <= 128 (got %d, %d)", in_dim, hid);
+    SKR_REQUIRE(hidden_act_kind == 0 || hidden_act_kind == 1, "There is not hidden_act named '%d'.", hidden_act_kind);
+    SKR_REQUIRE(B >= 0 && d_h != d_h_new, "skr_gru_cell_fwd: bad batch or in-place state");
+    if (B == 0) return SKR_OK;
+    GruIn g{d_x, d_x_index, d_h, B, in_dim, hid};
+    hipLaunchKernelGGL(gru_fwd_kernel, dim3((B + G_ROWS - 1) / G_ROWS), dim3(G_T), 0, skr::as_stream(stream), g, d_active,
+                       d_Wg, d_bg, d_Wc, d_bc, hidden_act_kind, d_r, d_u, d_c, d_h_new);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_h, int B, int in_dim, int hid,
+                     const float* d_Wg, const float* d_Wc, int hidden_act_kind, const float* d_r, const float* d_u,
+                     const float* d_c, const float* d_dh_new, float* d_gWg, float* d_gbg, float* d_gWc, float* d_gbc,
+                     float* d_dx, float* d_work, void* stream) {
+    SKR_REQUIRE(d_x && d_h && d_Wg && d_Wc && d_r && d_u && d_c && d_dh_new && d_gWg && d_gbg && d_gWc && d_gbc && d_dx &&
+                d_work, "skr_gru_cell_bwd: NULL argument");
+    SKR_REQUIRE(dims_ok(in_dim, hid), "skr_gru_cell_bwd: hid must be 32, 64 or 128 and in_dim <= 128 (got %d, %d)", in_dim, hid);
+    SKR_REQUIRE(hidden_act_kind == 0 || hidden_act_kind == 1, "There is not hidden_act named '%d'.", hidden_act_kind);
+    SKR_REQUIRE(B >= 0, "skr_gru_cell_bwd: negative batch");
+    if (B == 0) return SKR_OK;
+    hipStream_t st = skr::as_stream(stream);
+    GruIn g{d_x, d_x_index, d_h, B, in_dim, hid};
+    float* dcp = d_work;                                   // [B, hid]
+    float* dgp = d_work + static_cast<int64_t>(B) * hid;   // [B, 2 hid]
+    hipLaunchKernelGGL(gru_bwd_rows_kernel, dim3((B + G_ROWS - 1) / G_ROWS), dim3(G_T), 0, st, g, d_Wg, d_Wc,
+                       hidden_act_kind, d_r, d_u, d_c, d_dh_new, dcp, dgp, d_dx);
+    SKR_LAUNCH_CHECK();
+    const int64_t n_out = static_cast<int64_t>(in_dim + hid) * 3 * hid + 3 * hid;
+    hipLaunchKernelGGL(gru_bwd_weights_kernel, dim3(static_cast<unsigned>((n_out + G_T - 1) / G_T)), dim3(G_T), 0, st, g,
+                       d_r, dcp, dgp, d_gWg, d_gbg, d_gWc, d_gbc);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_session_loss(const float* d_out, int B, int hid, const float* d_item_table, const float* d_item_bias,
+                     const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
+                     float* d_dout, float* d_loss, void* stream) {
+    SKR_REQUIRE(d_out && d_item_table && d_item_bias && d_y && d_dlogits && d_dout && d_loss, "skr_session_loss: NULL argument");
+    SKR_REQUIRE(hid == 32 || hid == 64 || hid == 128, "skr_session_loss: hid must be 32, 64 or 128 (got %d)", hid);
+    SKR_REQUIRE(B >= 1 && n_y >= B && n_y <= L_NY_MAX, "skr_session_loss: need B <= n_y <= %d (got %d, %d)", L_NY_MAX, B, n_y);
+    SKR_REQUIRE(final_act_kind >= 0 && final_act_kind <= 2, "There is not final_act named '%d'.", final_act_kind);
+    SKR_REQUIRE(loss_kind == 0 || loss_kind == 1, "There is not loss named '%d'.", loss_kind);
+    hipLaunchKernelGGL(session_loss_kernel, dim3(B), dim3(G_T), 0, skr::as_stream(stream), d_out, B, hid, d_item_table,
+                       d_item_bias, d_y, n_y, final_act_kind, loss_kind, bpr_reg, d_dlogits, d_dout, d_loss);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_session_out_grads(const float* d_dlogits, const float* d_out, int B, int hid, const int32_t* d_y, int n_y,
+                          const float* d_item_table, const float* d_item_bias, float reg, float* d_g_table,
+                          float* d_g_bias, uint8_t* d_touch, const float* d_touch_base, void* stream) {
+    SKR_REQUIRE(d_dlogits && d_out && d_y && d_item_table && d_item_bias && d_g_table && d_g_bias,
+                "skr_session_out_grads: NULL argument");
+    SKR_REQUIRE(hid == 32 || hid == 64 || hid == 128, "skr_session_out_grads: hid must be 32, 64 or 128 (got %d)", hid);
+    SKR_REQUIRE(B >= 1 && n_y >= 1, "skr_session_out_grads: empty batch");
+    SKR_REQUIRE((d_touch == nullptr) == (d_touch_base == nullptr), "touch: both pointers or neither");
+    hipLaunchKernelGGL(session_out_grads_kernel, dim3((n_y + G_T / 64 - 1) / (G_T / 64)), dim3(G_T), 0,
+                       skr::as_stream(stream), d_dlogits, d_out, B, hid, d_y, n_y, d_item_table, d_item_bias, reg, d_g_table,
+                       d_g_bias, d_touch, d_touch_base);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_scatter_add_rows(const float* d_src, const int32_t* d_index, int n, int dim, const float* d_table, float reg,
+                         float* d_g_table, uint8_t* d_touch, const float* d_touch_base, void* stream) {
+    SKR_REQUIRE(d_src && d_index && d_g_table, "skr_scatter_add_rows: NULL argument");
+    SKR_REQUIRE(reg == 0.0f || d_table, "skr_scatter_add_rows: reg needs the table");
+    SKR_REQUIRE(n >= 0 && dim >= 1, "skr_scatter_add_rows: bad shape");
+    SKR_REQUIRE((d_touch == nullptr) == (d_touch_base == nullptr), "touch: both pointers or neither");
+    if (n == 0) return SKR_OK;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((n + G_T / 64 - 1) / (G_T / 64)), dim3(G_T), 0, skr::as_stream(stream),
+                       d_src, d_index, n, dim, d_table, reg, d_g_table, d_touch, d_touch_base);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+}  // extern "C"

@@ -32,6 +32,11 @@ SIGNATURES = {
     "skr_sample_epoch_exact": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, vp]),
     "skr_sample_epoch_exact_counts": (i32, [vp, i32, i32, vp, vp, i64, vp, i64, vp, vp]),
     "skr_sample_epoch_fast": (i32, [u64, u64, i64, i32, i32, vp, vp, i64, i32, vp, vp]),
+    "skr_gru_cell_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "skr_gru_cell_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "skr_session_loss": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "skr_session_out_grads": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, f32, vp, vp, vp, vp, vp]),
+    "skr_scatter_add_rows": (i32, [vp, vp, i32, i32, vp, f32, vp, vp, vp, vp]),
     "skr_eval_scores": (i32, [vp, i32, i32, i64, vp, vp, C.POINTER(i32), i32, i32, vp, vp, vp, vp]),
     "skr_eval_fused_workspace": (sz, [i32, i32]),
     "skr_eval_fused_topk": (i32, [vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, sz, vp]),

@@ -1,0 +1,321 @@
+"""GRU4RecPlus on MI355X (reference: skrec/recommender/GRU4RecPlus.py, a TensorFlow-1.14 graph).
+
+Paper: Recurrent Neural Networks with Top-k Gains for Session-based Recommendations (Hidasi and
+Karatzoglou).  Same constructor, config fields, session-parallel ``fit`` loop (:202-254), inference sweep
+(:256-302) and ``predict`` (:309-324) as the reference; the graph itself (embedding lookup, GRUCell stack,
+logits against the batch's own next items plus ``n_sample`` popularity^alpha negatives, bpr_max / top1_max
+loss, l2 term, TF-style dense Adam) runs through ``skr_gru_cell_fwd/_bwd``, ``skr_session_loss``,
+``skr_session_out_grads``, ``skr_scatter_add_rows`` and ``skr_adam_step`` (csrc/gru.hip, train.hip).
+
+What differs, and why:
+
+* PARITY UNPINNED against the reference: TensorFlow is not installed, so the reference cannot be run and holds
+  no recorded output for this model; tests compare the HIP path with a torch-CPU restatement of the graph.
+* Initial values: truncated normal(0, 0.01) tables and glorot-uniform kernels like the reference, but drawn
+  from torch's CPU generator (TF's random stream is not reproducible outside TF).
+* ``_get_user_embeddings`` advances ALL users together, one GRU step per history position (users whose
+  history has ended keep their state), instead of 128 at a time: the embeddings are the same, the sweep is
+  max-history-length launches instead of sum-of-lengths / 128.
+* negative samples come from numpy's global generator exactly as in the reference (:198-200), so
+  ``np.random.seed`` reproduces its sample stream.
+"""
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..run_config import RunConfig
+from ..utils.py import EarlyStopping, ModelConfig
+from .base import AbstractRecommender, DenseAdam
+
+__all__ = ["GRU4RecPlus", "GRU4RecPlusConfig"]
+
+_HIDDEN = {"tanh": 0, "relu": 1}
+_FINAL = {"linear": 0, "relu": 1, "leaky_relu": 2}
+_LOSS = {"bpr_max": 0, "top1_max": 1}
+
+
+class GRU4RecPlusConfig(ModelConfig):
+    def __init__(self, lr=0.001, reg=0.0, bpr_reg=1.0, layers=[64], batch_size=128, loss="bpr_max", hidden_act="tanh",
+                 final_act="linear", n_sample=2048, sample_alpha=0.75, epochs=500, early_stop=100, **kwargs):
+        super().__init__()
+        self.lr: float = lr
+        self.reg: float = reg
+        self.bpr_reg: float = bpr_reg
+        self.layers: List[int] = layers
+        self.batch_size: int = batch_size
+        self.loss: str = loss                  # top1_max, bpr_max
+        self.hidden_act: str = hidden_act      # relu, tanh
+        self.final_act: str = final_act        # linear, relu, leaky_relu
+        self.n_sample: int = n_sample
+        self.sample_alpha: float = sample_alpha
+        self.epochs: int = epochs
+        self.early_stop: int = early_stop
+
+    def _validate(self):
+        assert isinstance(self.lr, float) and self.lr > 0
+        assert isinstance(self.reg, float) and self.reg >= 0
+        assert isinstance(self.bpr_reg, float) and self.bpr_reg >= 0
+        assert isinstance(self.layers, list)
+        assert isinstance(self.batch_size, int) and self.batch_size > 0
+        assert isinstance(self.loss, str) and self.loss in {"top1_max", "bpr_max"}
+        assert isinstance(self.hidden_act, str) and self.hidden_act in {"relu", "tanh"}
+        assert isinstance(self.final_act, str) and self.final_act in {"linear", "relu", "leaky_relu"}
+        assert isinstance(self.n_sample, int) and self.n_sample >= 0
+        assert isinstance(self.sample_alpha, float) and 0 < self.sample_alpha <= 1
+        assert isinstance(self.epochs, int) and self.epochs >= 0
+        assert isinstance(self.early_stop, int)
+
+
+class SessionGRU(object):
+    """Device state + one training / inference step of the GRU4RecPlus graph.  Parameters live in ONE flat
+    buffer [E_in | E_out | b_out | (Wg, bg, Wc, bc) per layer], every section starting on a 64-float block,
+    stepped by a single dense Adam launch with TensorFlow's epsilon placement."""
+
+    def __init__(self, E_in, cells, E_out, b_out, hidden_act="tanh", final_act="linear", loss="bpr_max", bpr_reg=1.0,
+                 reg=0.0, lr=1e-3, device=None):
+        self.device = dev = device if device is not None else _hip.require_gpu()
+        if hidden_act not in _HIDDEN:
+            raise ValueError("There is not hidden_act named '%s'." % hidden_act)
+        if final_act not in _FINAL:
+            raise ValueError("There is not final_act named '%s'." % final_act)
+        if loss not in _LOSS:
+            raise ValueError("There is not loss named '%s'." % loss)
+        self.hidden_act, self.final_act, self.loss_kind = _HIDDEN[hidden_act], _FINAL[final_act], _LOSS[loss]
+        self.bpr_reg, self.reg = float(bpr_reg), float(reg)
+        t32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32)  # noqa: E731
+        E_in, E_out, b_out = t32(E_in), t32(E_out), t32(b_out).reshape(-1)
+        cells = [tuple(t32(w) for w in cell) for cell in cells]
+        self.n_items, self.in_dim = E_in.shape
+        self.hids = [int(c[2].shape[1]) for c in cells]
+        dims_in = [self.in_dim] + self.hids[:-1]
+        for (Wg, bg, Wc, bc), i_d, h in zip(cells, dims_in, self.hids):
+            assert Wg.shape == (i_d + h, 2 * h) and bg.shape == (2 * h,) and Wc.shape == (i_d + h, h) and bc.shape == (h,)
+            if h not in (32, 64, 128) or i_d > 128:
+                raise NotImplementedError("the MI355X GRU kernels take layer sizes 32, 64 or 128")
+        assert E_out.shape == (self.n_items, self.hids[-1]) and b_out.shape == (self.n_items,)
+        sections = [E_in, E_out, b_out] + [w for c in cells for w in c]
+        offs, n = [], 0
+        for s in sections:
+            offs.append(n)
+            n += (s.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        views = []
+        for s, o in zip(sections, offs):
+            v = self.flat[o:o + s.numel()].view(s.shape)
+            v.copy_(s)
+            views.append(v)
+        self.opt = DenseAdam(self.flat, lr=lr, track_touch=True, tf_epsilon=True)
+        self.opt.touch[offs[3] // 64:] = 2                # the recurrent weights get a gradient every step
+        gviews = [self.opt.grad[o:o + s.numel()].view(s.shape) for s, o in zip(sections, offs)]
+        self.E_in, self.E_out, self.b_out = views[:3]
+        self.gE_in, self.gE_out, self.gb_out = gviews[:3]
+        self.cells = [tuple(views[3 + 4 * l:7 + 4 * l]) for l in range(len(cells))]
+        self.gcells = [tuple(gviews[3 + 4 * l:7 + 4 * l]) for l in range(len(cells))]
+        self.dims_in = dims_in
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._bufs = {}
+
+    def _buf(self, name, shape):
+        key = (name, tuple(shape))
+        if key not in self._bufs:
+            self._bufs[key] = torch.empty(shape, dtype=torch.float32, device=self.device)
+        return self._bufs[key]
+
+    def zero_states(self, b):
+        return [torch.zeros((b, h), dtype=torch.float32, device=self.device) for h in self.hids]
+
+    def forward(self, x_index, states, active=None, save=False, tag="f"):
+        """one step of the stack: -> new states (fresh buffers per `tag`), optionally keeping r, u, c"""
+        L, st = _hip.lib(), _hip.stream()
+        b = x_index.numel()
+        src, idx = self.E_in, x_index
+        new_states, saved = [], []
+        for l, ((Wg, bg, Wc, bc), i_d, h) in enumerate(zip(self.cells, self.dims_in, self.hids)):
+            hn = self._buf(f"{tag}_h{l}", (b, h))
+            r = u = c = None
+            if save:
+                r, u, c = (self._buf(f"{tag}_{n}{l}", (b, h)) for n in "ruc")
+            _hip.check(L.skr_gru_cell_fwd(_hip.ptr(src), _hip.ptr(idx), _hip.ptr(states[l]), _hip.ptr(active), b, i_d, h,
+                                          _hip.ptr(Wg), _hip.ptr(bg), _hip.ptr(Wc), _hip.ptr(bc), self.hidden_act,
+                                          _hip.ptr(r), _hip.ptr(u), _hip.ptr(c), _hip.ptr(hn), st))
+            saved.append((src, idx, r, u, c))
+            new_states.append(hn)
+            src, idx = hn, None
+        return new_states, saved
+
+    def train_step(self, x_index, y_index, states):
+        """`sess.run([update_opt, final_state])` of the reference (:231): x_index int32 [b], y_index int32
+        [b + n_sample] (device), states: list of [b, h_l].  Returns the new states; ``self.loss`` holds the
+        mean bpr_max / top1_max loss of the step.  The returned tensors are reused by the next call with the
+        other parity, so a caller may keep them for exactly one more step (the fit loop does)."""
+        L, st = _hip.lib(), _hip.stream()
+        b, n_y, hn = x_index.numel(), y_index.numel(), self.hids[-1]
+        self._parity = 1 - getattr(self, "_parity", 0)
+        new_states, saved = self.forward(x_index, states, save=True, tag=f"t{self._parity}")
+        out = new_states[-1]
+        dlog, dout = self._buf("dlogits", (b, n_y)), self._buf("dout", (b, hn))
+        self.loss.zero_()
+        g = self.opt
+        _hip.check(L.skr_session_loss(_hip.ptr(out), b, hn, _hip.ptr(self.E_out), _hip.ptr(self.b_out), _hip.ptr(y_index),
+                                      n_y, self.final_act, self.loss_kind, self.bpr_reg, _hip.ptr(dlog), _hip.ptr(dout),
+                                      _hip.ptr(self.loss), st))
+        _hip.check(L.skr_session_out_grads(_hip.ptr(dlog), _hip.ptr(out), b, hn, _hip.ptr(y_index), n_y,
+                                           _hip.ptr(self.E_out), _hip.ptr(self.b_out), self.reg, _hip.ptr(self.gE_out),
+                                           _hip.ptr(self.gb_out), _hip.ptr(g.touch), _hip.ptr(g.grad), st))
+        dh = dout
+        for l in range(len(self.cells) - 1, -1, -1):
+            (Wg, bg, Wc, bc), (gWg, gbg, gWc, gbc) = self.cells[l], self.gcells[l]
+            src, idx, r, u, c = saved[l]
+            i_d, h = self.dims_in[l], self.hids[l]
+            dx, work = self._buf(f"dx{l}", (b, i_d)), self._buf(f"work{l}", (3 * b * h,))
+            _hip.check(L.skr_gru_cell_bwd(_hip.ptr(src), _hip.ptr(idx), _hip.ptr(states[l]), b, i_d, h, _hip.ptr(Wg),
+                                          _hip.ptr(Wc), self.hidden_act, _hip.ptr(r), _hip.ptr(u), _hip.ptr(c), _hip.ptr(dh),
+                                          _hip.ptr(gWg), _hip.ptr(gbg), _hip.ptr(gWc), _hip.ptr(gbc), _hip.ptr(dx),
+                                          _hip.ptr(work), st))
+            dh = dx
+        _hip.check(L.skr_scatter_add_rows(_hip.ptr(dh), _hip.ptr(x_index), b, self.in_dim, _hip.ptr(self.E_in), self.reg,
+                                          _hip.ptr(self.gE_in), _hip.ptr(g.touch), _hip.ptr(g.grad), st))
+        g.step()
+        return new_states
+
+    def user_embeddings(self, d_rowptr, d_items_by_time, max_len):
+        """top-layer state after each user's whole history (zero rows for users without one)"""
+        n_users = d_rowptr.numel() - 1
+        lens = d_rowptr[1:] - d_rowptr[:-1]
+        states = self.zero_states(n_users)
+        last = d_items_by_time.numel() - 1
+        for t in range(int(max_len)):
+            active = (lens > t).to(torch.uint8)
+            x_index = d_items_by_time[torch.clamp(d_rowptr[:-1] + t, max=last)].contiguous()
+            states, _ = self.forward(x_index, states, active=active, tag=f"e{t & 1}")
+        return states[-1]
+
+
+class GRU4RecPlus(AbstractRecommender):
+    def __init__(self, run_config: RunConfig, model_config: Dict):
+        self.config = GRU4RecPlusConfig(**model_config)
+        super().__init__(run_config, self.config)
+        config: GRU4RecPlusConfig = self.config
+        self.device = _hip.require_gpu()
+        self.users_num, self.items_num = self.dataset.num_users, self.dataset.num_items
+        self.user_pos_train = self.dataset.train_data.to_user_dict_by_time()
+        self.data_ui, self.offset_idx = self._init_data()
+        # for sampling negative items (:103-106)
+        _, pop = np.unique(self.data_ui[:, 1], return_counts=True)
+        pop = np.power(pop, config.sample_alpha)
+        pop_cumsum = np.cumsum(pop)
+        self.pop_cumsum = pop_cumsum / pop_cumsum[-1]
+        # variables (:124-135) and the GRUCell kernels (glorot uniform, gate bias 1, candidate bias 0)
+        l1, ln = config.layers[0], config.layers[-1]
+        E_in = nn.init.trunc_normal_(torch.empty(self.items_num, l1), mean=0.0, std=0.01, a=-0.02, b=0.02)
+        E_out = nn.init.trunc_normal_(torch.empty(self.items_num, ln), mean=0.0, std=0.01, a=-0.02, b=0.02)
+        cells, i_d = [], l1
+        for h in config.layers:
+            cells.append((nn.init.xavier_uniform_(torch.empty(i_d + h, 2 * h)), torch.ones(2 * h),
+                          nn.init.xavier_uniform_(torch.empty(i_d + h, h)), torch.zeros(h)))
+            i_d = h
+        self.net = SessionGRU(E_in, cells, E_out, torch.zeros(self.items_num), config.hidden_act, config.final_act,
+                              config.loss, config.bpr_reg, config.reg, config.lr, self.device)
+        # histories by time as a CSR over ALL users for the inference sweep
+        rowptr = np.zeros(self.users_num + 1, np.int64)
+        for u, items in self.user_pos_train.items():
+            rowptr[u + 1] = len(items)
+        self._max_len = int(rowptr.max())
+        np.cumsum(rowptr, out=rowptr)
+        flat = np.concatenate([self.user_pos_train[u] for u in sorted(self.user_pos_train)]).astype(np.int32)
+        self._d_rowptr = torch.from_numpy(rowptr).to(self.device)
+        self._d_hist = torch.from_numpy(flat).to(self.device)
+        self._d_items = torch.from_numpy(np.ascontiguousarray(self.data_ui[:, 1], dtype=np.int32)).to(self.device)
+        self.step_losses = []
+
+    def _init_data(self):
+        data_ui = self.dataset.train_data.to_user_item_pairs_by_time()
+        _, idx = np.unique(data_ui[:, 0], return_index=True)
+        offset_idx = np.zeros(len(idx) + 1, dtype=np.int32)
+        offset_idx[:-1] = idx
+        offset_idx[-1] = len(data_ui)
+        return data_ui, offset_idx
+
+    def _sample_neg_items(self, size):
+        return np.searchsorted(self.pop_cumsum, np.random.rand(size))
+
+    def train_epoch(self):
+        """the session-parallel loop of GRU4RecPlus.fit (:210-247), control flow on the host as there"""
+        cfg, net, dev = self.config, self.net, self.device
+        offset_idx, d_items = self.offset_idx, self._d_items
+        b = cfg.batch_size
+        state = net.zero_states(b)
+        user_idx = np.random.permutation(len(offset_idx) - 1)
+        iters = np.arange(b, dtype=np.int32)
+        maxiter = iters.max()
+        start = offset_idx[user_idx[iters]].astype(np.int64)
+        end = offset_idx[user_idx[iters] + 1].astype(np.int64)
+        losses = []
+        finished = False
+        while not finished:
+            min_len = int((end - start).min())
+            d_start = torch.from_numpy(start).to(dev)
+            out_idx = d_items[d_start]
+            for i in range(min_len - 1):
+                in_idx = out_idx
+                out_idx = d_items[d_start + (i + 1)]
+                out_items = out_idx
+                if cfg.n_sample:
+                    neg = torch.from_numpy(self._sample_neg_items(cfg.n_sample).astype(np.int32)).to(dev)
+                    out_items = torch.cat([out_idx, neg])
+                state = net.train_step(in_idx.contiguous(), out_items.contiguous(), state)
+                losses.append(net.loss.clone())
+            start = start + min_len - 1
+            mask = np.arange(len(iters))[(end - start) <= 1]
+            for idx in mask:
+                maxiter += 1
+                if maxiter >= len(offset_idx) - 1:
+                    finished = True
+                    break
+                iters[idx] = maxiter
+                start[idx] = offset_idx[user_idx[maxiter]]
+                end[idx] = offset_idx[user_idx[maxiter] + 1]
+            if len(mask):
+                d_mask = torch.from_numpy(mask).to(dev)
+                state = [s.index_fill(0, d_mask, 0.0) for s in state]
+        self.step_losses = torch.cat(losses).cpu().numpy() if losses else np.zeros(0, np.float32)
+
+    def fit(self):
+        self.logger.info("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
+        if len(self.offset_idx) - 1 < self.config.batch_size:
+            raise ValueError("batch_size is larger than the number of training sessions")   # the reference's index error
+        early_stopping = EarlyStopping(metric="NDCG@10", patience=self.config.early_stop)
+        for epoch in range(self.config.epochs):
+            self.train_epoch()
+            cur_result = self.evaluate()
+            self.logger.info(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
+            if early_stopping(cur_result):
+                self.logger.info("early stop")
+                break
+        self.logger.info("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
+        return early_stopping.best_result
+
+    def _get_user_embeddings(self):
+        return self.net.user_embeddings(self._d_rowptr, self._d_hist, self._max_len)
+
+    def evaluate(self, test_users=None):
+        self.cur_user_embeddings = self._get_user_embeddings().clone()
+        return self.evaluator.evaluate(self, test_users)
+
+    def predict_factors(self):
+        """fused evaluator: a strictly increasing final activation does not change the ranking"""
+        if self.config.final_act == "relu" or self.config.layers[-1] != 64:
+            return None
+        return self.cur_user_embeddings, self.net.E_out, self.net.b_out
+
+    def predict(self, users):
+        ue = self.cur_user_embeddings[torch.as_tensor(np.asarray(users, dtype=np.int64)).to(self.device)]
+        scores = torch.addmm(self.net.b_out.unsqueeze(0), ue, self.net.E_out.t())      # plain library GEMM
+        if self.config.final_act == "relu":
+            scores = torch.relu(scores)
+        elif self.config.final_act == "leaky_relu":
+            scores = torch.maximum(scores, scores * 0.2)
+        return scores.cpu().numpy().astype(np.float32)

@@ -63,7 +63,7 @@ class DenseAdam(object):
     like the reference's dense Adam; with ``track_touch`` a byte per 64-float block lets the kernel
     skip READING gradients that are known to be zero (same result, 24 instead of 32 B/param)."""
 
-    def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8, track_touch=False):
+    def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8, track_touch=False, tf_epsilon=False):
         import torch
         assert flat.dim() == 1 and flat.is_contiguous()
         self.flat = flat
@@ -72,6 +72,9 @@ class DenseAdam(object):
         self.v = torch.zeros_like(flat)
         self.touch = torch.zeros((flat.numel() + 63) // 64, dtype=torch.uint8, device=flat.device) if track_touch else None
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        # tf.train.AdamOptimizer puts epsilon outside the bias correction: p -= lr_t * m / (sqrt(v) + eps) with
+        # lr_t = lr * sqrt(1-b2^t) / (1-b1^t), i.e. torch's form with eps / sqrt(1-b2^t)   (GRU4RecPlus.py:192)
+        self.tf_epsilon = bool(tf_epsilon)
         self.t = 0
 
     def grad_view(self, start, shape):
@@ -83,6 +86,7 @@ class DenseAdam(object):
     def step(self):
         from .. import _hip
         self.t += 1
+        eps = self.eps / (1.0 - self.betas[1] ** self.t) ** 0.5 if self.tf_epsilon else self.eps
         _hip.check(_hip.lib().skr_adam_step(_hip.ptr(self.flat), _hip.ptr(self.grad), _hip.ptr(self.m), _hip.ptr(self.v),
-                                            self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t, 1,
+                                            self.flat.numel(), self.lr, self.betas[0], self.betas[1], eps, self.t, 1,
                                             _hip.ptr(self.touch), _hip.stream()))

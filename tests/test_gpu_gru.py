@@ -1,0 +1,202 @@
+"""GPU parity, SURVEY 8f-4 (GRU4RecPlus): the HIP kernels of csrc/gru.hip against oracle/gru4rec.py -- a
+torch-CPU restatement of the reference's TensorFlow-1.14 graph with autograd supplying the gradients the
+kernels derive by hand.  PARITY UNPINNED against the reference itself (TensorFlow absent, no recorded
+output in the reference).  Tolerance: 1e-5 relative (fp32 summation order) unless noted."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gru4rec as G
+from gpu_utils import to_dev
+from skrec import _hip
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+
+def _cell(rng, i_d, h):
+    lim_g, lim_c = np.sqrt(6.0 / (i_d + 3 * h)), np.sqrt(6.0 / (i_d + 2 * h))
+    return (rng.uniform(-lim_g, lim_g, (i_d + h, 2 * h)).astype(np.float32), (1 + 0.1 * rng.standard_normal(2 * h)).astype(np.float32),
+            rng.uniform(-lim_c, lim_c, (i_d + h, h)).astype(np.float32), (0.1 * rng.standard_normal(h)).astype(np.float32))
+
+
+def _close(got, want, rtol=1e-5, atol=1e-6):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = max(np.abs(want).max(), 1e-30)
+    assert np.abs(got - want).max() <= rtol * scale + atol, (np.abs(got - want).max(), scale)
+
+
+@pytest.mark.parametrize("i_d,h,B,act", [(64, 64, 128, "tanh"), (128, 128, 37, "tanh"), (64, 128, 16, "relu"), (48, 32, 5, "tanh")])
+def test_gru_cell_fwd_bwd(i_d, h, B, act):
+    rng = np.random.default_rng(i_d + h + B)
+    n_rows = 300
+    table = (0.5 * rng.standard_normal((n_rows, i_d))).astype(np.float32)
+    idx = rng.integers(0, n_rows, B).astype(np.int32)
+    hprev = (0.5 * rng.standard_normal((B, h))).astype(np.float32)
+    Wg, bg, Wc, bc = _cell(rng, i_d, h)
+    G_out = rng.standard_normal((B, h)).astype(np.float32)
+    # oracle
+    tt = [torch.tensor(a, requires_grad=True) for a in (table, Wg, bg, Wc, bc)]
+    hn = G.gru_cell(tt[0][torch.as_tensor(idx, dtype=torch.long)], torch.tensor(hprev), tt[1], tt[2], tt[3], tt[4], act)
+    (hn * torch.tensor(G_out)).sum().backward()
+    # device
+    L, st = _hip.lib(), _hip.stream()
+    d = {k: to_dev(v) for k, v in dict(table=table, idx=idx, h=hprev, Wg=Wg, bg=bg, Wc=Wc, bc=bc, dh=G_out).items()}
+    r, u, c, out = (torch.empty((B, h), device="cuda") for _ in range(4))
+    kind = {"tanh": 0, "relu": 1}[act]
+    _hip.check(L.skr_gru_cell_fwd(_hip.ptr(d["table"]), _hip.ptr(d["idx"]), _hip.ptr(d["h"]), None, B, i_d, h, _hip.ptr(d["Wg"]),
+                                  _hip.ptr(d["bg"]), _hip.ptr(d["Wc"]), _hip.ptr(d["bc"]), kind, _hip.ptr(r), _hip.ptr(u),
+                                  _hip.ptr(c), _hip.ptr(out), st))
+    _close(out.cpu().numpy(), hn.detach().numpy())
+    gWg, gbg, gWc, gbc = (torch.zeros_like(d[k]) for k in ("Wg", "bg", "Wc", "bc"))
+    dx = torch.empty((B, i_d), device="cuda")
+    work = torch.empty(3 * B * h, device="cuda")
+    _hip.check(L.skr_gru_cell_bwd(_hip.ptr(d["table"]), _hip.ptr(d["idx"]), _hip.ptr(d["h"]), B, i_d, h, _hip.ptr(d["Wg"]),
+                                  _hip.ptr(d["Wc"]), kind, _hip.ptr(r), _hip.ptr(u), _hip.ptr(c), _hip.ptr(d["dh"]),
+                                  _hip.ptr(gWg), _hip.ptr(gbg), _hip.ptr(gWc), _hip.ptr(gbc), _hip.ptr(dx), _hip.ptr(work), st))
+    _close(gWg.cpu().numpy(), tt[1].grad.numpy(), 2e-5)
+    _close(gbg.cpu().numpy(), tt[2].grad.numpy(), 2e-5)
+    _close(gWc.cpu().numpy(), tt[3].grad.numpy(), 2e-5)
+    _close(gbc.cpu().numpy(), tt[4].grad.numpy(), 2e-5)
+    want_dx = np.zeros((n_rows, i_d), np.float32)       # autograd gives the scattered table gradient
+    gtab = torch.zeros((n_rows, i_d), device="cuda")
+    _hip.check(L.skr_scatter_add_rows(_hip.ptr(dx), _hip.ptr(d["idx"]), B, i_d, None, 0.0, _hip.ptr(gtab), None, None, st))
+    _close(gtab.cpu().numpy(), tt[0].grad.numpy(), 2e-5)
+    # the row mask of the inference sweep: inactive rows keep their state
+    active = (rng.random(B) < 0.5).astype(np.uint8)
+    out2 = torch.empty((B, h), device="cuda")
+    d_act = to_dev(active)
+    _hip.check(L.skr_gru_cell_fwd(_hip.ptr(d["table"]), _hip.ptr(d["idx"]), _hip.ptr(d["h"]), _hip.ptr(d_act), B, i_d, h,
+                                  _hip.ptr(d["Wg"]), _hip.ptr(d["bg"]), _hip.ptr(d["Wc"]), _hip.ptr(d["bc"]), kind, None, None,
+                                  None, _hip.ptr(out2), st))
+    want = np.where(active[:, None] == 1, out.cpu().numpy(), hprev)
+    assert np.array_equal(out2.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("loss", ["bpr_max", "top1_max"])
+@pytest.mark.parametrize("fact", ["linear", "relu", "leaky_relu"])
+@pytest.mark.parametrize("B,S,h", [(128, 2048, 64), (7, 0, 32), (33, 100, 128)])
+def test_session_loss_and_grads(loss, fact, B, S, h):
+    rng = np.random.default_rng(B + S + h)
+    n_items, n_y = 500, B + S
+    E = (0.3 * rng.standard_normal((n_items, h))).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(n_items)).astype(np.float32)
+    out = (0.5 * rng.standard_normal((B, h))).astype(np.float32)
+    Y = rng.integers(0, n_items, n_y).astype(np.int32)          # repeated targets on purpose
+    reg, bpr_reg = 0.01, 0.7
+    tE, tb, to = (torch.tensor(a, requires_grad=True) for a in (E, bias, out))
+    Yl = torch.as_tensor(Y, dtype=torch.long)
+    items, bs = tE[Yl], tb[Yl]
+    logits = G.final_act(to @ items.t() + bs, fact)
+    main = G.bpr_max_loss(logits, bpr_reg) if loss == "bpr_max" else G.top1_max_loss(logits)
+    (main + reg * 0.5 * (items.pow(2).sum() + bs.pow(2).sum())).backward()
+    L, st = _hip.lib(), _hip.stream()
+    dE, db, do, dY = to_dev(E), to_dev(bias), to_dev(out), to_dev(Y)
+    dlog = torch.empty((B, n_y), device="cuda")
+    dout = torch.empty((B, h), device="cuda")
+    lossbuf = torch.zeros(1, device="cuda")
+    fk, lk = {"linear": 0, "relu": 1, "leaky_relu": 2}[fact], {"bpr_max": 0, "top1_max": 1}[loss]
+    _hip.check(L.skr_session_loss(_hip.ptr(do), B, h, _hip.ptr(dE), _hip.ptr(db), _hip.ptr(dY), n_y, fk, lk, bpr_reg,
+                                  _hip.ptr(dlog), _hip.ptr(dout), _hip.ptr(lossbuf), st))
+    assert abs(float(lossbuf) - float(main.detach())) <= 2e-5 * abs(float(main.detach())) + 1e-7
+    _close(dout.cpu().numpy(), to.grad.numpy(), 5e-5, 1e-7)
+    gE, gb = torch.zeros_like(dE), torch.zeros_like(db)
+    _hip.check(L.skr_session_out_grads(_hip.ptr(dlog), _hip.ptr(do), B, h, _hip.ptr(dY), n_y, _hip.ptr(dE), _hip.ptr(db), reg,
+                                       _hip.ptr(gE), _hip.ptr(gb), None, None, st))
+    _close(gE.cpu().numpy(), tE.grad.numpy(), 5e-5, 1e-7)
+    _close(gb.cpu().numpy(), tb.grad.numpy(), 5e-5, 1e-7)
+
+
+@pytest.mark.parametrize("layers,loss,fact,act,reg", [([64], "bpr_max", "linear", "tanh", 0.0),
+                                                       ([128], "bpr_max", "leaky_relu", "tanh", 1e-4),
+                                                       ([64, 32], "top1_max", "linear", "relu", 1e-3)])
+def test_training_trajectory_matches_oracle(layers, loss, fact, act, reg):
+    """20 session-parallel steps with carried states and occasional resets: per-step loss and the final
+    parameters against the oracle's autograd + TF-style Adam"""
+    from skrec.recommender.GRU4RecPlus import SessionGRU
+    rng = np.random.default_rng(len(layers) * 7 + layers[0])
+    n_items, b, S = 400, 32, 200
+    E_in = rng.normal(0, 0.1, (n_items, layers[0])).astype(np.float32)
+    E_out = rng.normal(0, 0.1, (n_items, layers[-1])).astype(np.float32)
+    b_out = rng.normal(0, 0.05, n_items).astype(np.float32)
+    cells, i_d = [], layers[0]
+    for h in layers:
+        cells.append(_cell(rng, i_d, h))
+        i_d = h
+    kw = dict(hidden_act=act, loss=loss, bpr_reg=0.8, reg=reg, lr=3e-3)
+    o = G.GRU4RecOracle(E_in, cells, E_out, b_out, final=fact, **kw)
+    net = SessionGRU(E_in, cells, E_out, b_out, final_act=fact, **kw)
+    st_o = [torch.zeros(b, h) for h in layers]
+    st_d = net.zero_states(b)
+    for step in range(20):
+        X = rng.integers(0, n_items, b).astype(np.int32)
+        Y = np.concatenate([rng.integers(0, n_items, b), rng.integers(0, n_items, S)]).astype(np.int32)
+        lo, st_o = o.train_step(X, Y, st_o)
+        st_d = net.train_step(to_dev(X), to_dev(Y), st_d)
+        assert abs(float(net.loss) - lo) <= 5e-5 * abs(lo) + 1e-6, (step, float(net.loss), lo)
+        for a, w in zip(st_d, st_o):
+            _close(a.cpu().numpy(), w.numpy(), 1e-4, 1e-6)
+        if step % 7 == 6:                    # sessions ending: their state rows are cleared (GRU4RecPlus.py:244-246)
+            mask = rng.choice(b, 5, replace=False)
+            st_o = [s.clone() for s in st_o]
+            for s in st_o:
+                s[mask] = 0
+            st_d = [s.index_fill(0, to_dev(mask.astype(np.int64)), 0.0) for s in st_d]
+    _close(net.E_in.cpu().numpy(), o.E_in.detach().numpy(), 2e-4, 2e-6)
+    _close(net.E_out.cpu().numpy(), o.E_out.detach().numpy(), 2e-4, 2e-6)
+    _close(net.b_out.cpu().numpy(), o.b_out.detach().numpy(), 2e-4, 2e-6)
+    for (Wg, bg, Wc, bc), oc in zip(net.cells, o.cells):
+        for a, w in zip((Wg, bg, Wc, bc), oc):
+            _close(a.cpu().numpy(), w.detach().numpy(), 2e-4, 2e-6)
+
+
+def test_user_embeddings_sweep_matches_oracle():
+    from skrec.recommender.GRU4RecPlus import SessionGRU
+    rng = np.random.default_rng(11)
+    n_items, n_users, layers = 300, 57, [64, 64]
+    E_in = rng.normal(0, 0.3, (n_items, 64)).astype(np.float32)
+    E_out = rng.normal(0, 0.3, (n_items, 64)).astype(np.float32)
+    cells = [_cell(rng, 64, 64), _cell(rng, 64, 64)]
+    lens = rng.integers(0, 9, n_users)
+    lens[3] = 0
+    rowptr = np.zeros(n_users + 1, np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    hist = rng.integers(0, n_items, int(rowptr[-1])).astype(np.int32)
+    o = G.GRU4RecOracle(E_in, cells, E_out, np.zeros(n_items, np.float32))
+    net = SessionGRU(E_in, cells, E_out, np.zeros(n_items, np.float32))
+    got = net.user_embeddings(to_dev(rowptr), to_dev(hist), int(lens.max())).cpu().numpy()
+    want = o.user_embeddings(rowptr, hist)
+    _close(got, want, 2e-5, 1e-6)
+    assert np.all(got[3] == 0)
+
+
+def test_gru4recplus_fit_through_the_api(tiny_dir, monkeypatch, tmp_path):
+    """the drop-in class: constructor, fit (session-parallel loop), evaluate, predict; losses fall, the
+    evaluator's fused and generic paths agree on the report"""
+    import random
+    from skrec import RunConfig
+    from skrec.recommender.GRU4RecPlus import GRU4RecPlus
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(2021); random.seed(2021); torch.manual_seed(2021)
+    rc = RunConfig(recommender="GRU4RecPlus", data_dir=tiny_dir, file_column="UIRT", sep="\t",
+                   metric=("Precision", "Recall", "MAP", "NDCG", "MRR"), top_k=(5, 10, 20), test_batch_size=16, seed=2021)
+    m = GRU4RecPlus(rc, dict(lr=0.01, layers=[64], batch_size=16, n_sample=64, epochs=3, early_stop=10))
+    first = None
+    losses = []
+    te = m.train_epoch
+
+    def train_epoch():
+        te()
+        losses.append(float(np.mean(m.step_losses)))
+    m.train_epoch = train_epoch
+    best = m.fit()
+    assert len(losses) == 3 and losses[-1] < losses[0] and np.isfinite(losses).all()
+    assert set(best.metrics()) == {f"{n}@{k}" for n in ("Precision", "Recall", "MAP", "NDCG", "MRR") for k in (5, 10, 20)}
+    fused = m.evaluate()
+    monkeypatch.setattr(GRU4RecPlus, "predict_factors", lambda self: None)
+    generic = m.evaluate()
+    np.testing.assert_allclose(np.array(list(fused.values())), np.array(list(generic.values())), rtol=1e-5, atol=2e-4)
+    p = m.predict([0, 5, 9])
+    assert p.shape == (3, m.items_num) and p.dtype == np.float32
+    ue = m.cur_user_embeddings.cpu().numpy()
+    want = ue[[0, 5, 9]] @ m.net.E_out.cpu().numpy().T + m.net.b_out.cpu().numpy()
+    np.testing.assert_allclose(p, want, rtol=1e-4, atol=1e-5)

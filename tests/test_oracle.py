@@ -221,3 +221,31 @@ def test_oracle_stream_reproduces_sequential_and_kg_iterators(golden):
     kc = [(int(h), len(tails[int(h)])) for h in heads]
     assert np.array_equal(epoch(kc, tails, 60, 1), g["kg_e0_c3"])
     assert np.array_equal(epoch(kc, tails, 60, 3), g["kg3_e0_c3"])
+
+
+def test_gru4rec_oracle_losses_against_a_float64_restatement():
+    """oracle/gru4rec.py's bpr_max / top1_max (torch fp32) against the same formulas of GRU4RecPlus.py:137-166
+    written out element by element in float64 numpy.  (PARITY UNPINNED against the reference itself: TensorFlow
+    is absent and the reference holds no recorded output for this model.)"""
+    import torch
+    from oracle import gru4rec as G
+    rng = np.random.default_rng(0)
+    b, n = 4, 9
+    lg = rng.normal(0, 1.5, (b, n))
+    hm = 1.0 - np.eye(b, n)
+    masked = lg * hm
+    e = np.exp(masked - masked.max(1, keepdims=True)) * hm
+    s = e / e.sum(1, keepdims=True)
+    pos = np.diag(lg)[:, None]
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))  # noqa: E731
+    bpr = (-np.log((sig(pos - lg) * s).sum(1) + 1e-24) + 0.6 * ((lg ** 2) * s).sum(1)).mean()
+    top1 = (((sig(-pos + lg) + sig(lg ** 2)) * s).sum(1)).mean()
+    t = torch.tensor(lg, dtype=torch.float32)
+    assert abs(float(G.bpr_max_loss(t, 0.6)) - bpr) < 1e-5 * abs(bpr)
+    assert abs(float(G.top1_max_loss(t)) - top1) < 1e-5 * abs(top1)
+    np.testing.assert_allclose(G.softmax_neg(t).numpy(), s, rtol=1e-5, atol=1e-7)
+    # GRUCell restatement: gate bias 1 and zero kernels give r = u = sigmoid(1), c = act(0) = 0 -> h' = u h
+    h = torch.tensor(rng.normal(0, 1, (3, 8)), dtype=torch.float32)
+    x = torch.zeros(3, 5)
+    out = G.gru_cell(x, h, torch.zeros(13, 16), torch.ones(16), torch.zeros(13, 8), torch.zeros(8), "tanh")
+    np.testing.assert_allclose(out.numpy(), sig(1.0) * h.numpy(), rtol=1e-6)
