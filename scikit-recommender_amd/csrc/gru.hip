@@ -2,8 +2,8 @@
 //
 // Replaces the TensorFlow-1.14 graph the reference builds (recommender/GRU4RecPlus.py:124-200):
 //   :168-178  embedding lookup + tf.nn.rnn_cell.GRUCell stack           -> gru_fwd_kernel / gru_bwd_*
-//   :180-186  logits against the batch's own positives + shared samples -> session_loss_kernel
-//   :137-166  _softmax_neg, _bpr_max_loss, _top1_max_loss (+ autograd)  -> session_loss_kernel
+//   :180-186  logits against the batch's own positives + shared samples -> session_logits_kernel
+//   :137-166  _softmax_neg, _bpr_max_loss, _top1_max_loss (+ autograd)  -> session_rowloss_kernel, session_dout_kernel
 //   :190-192  l2_loss + AdamOptimizer.minimize (dense update)           -> session_out_grads_kernel,
 //                                                                          scatter_add_rows_kernel, skr_adam_step
 // The recurrent state is fed through placeholders, so a training step is a one-step truncated BPTT:
@@ -18,7 +18,8 @@
 
 namespace {
 
-constexpr int G_ROWS = 16;     // sessions per workgroup
+constexpr int G_ROWS = 16;     // sessions per workgroup (4 when the batch is small)
+constexpr int G_SMALL_B = 2048;
 constexpr int G_T = 256;
 constexpr int G_KMAX = 256;    // in_dim + hid
 constexpr int G_HMAX = 128;
@@ -45,18 +46,19 @@ __device__ __forceinline__ const float* x_row(const GruIn& g, int row) {
 // 16 sessions per workgroup, their [x, h] rows staged in LDS; a thread owns one output column and
 // 16 / (256 / columns) of the rows, so each weight is read once per workgroup from L2.
 // ------------------------------------------------------------------------------------------------
+template <int ROWS>
 __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __restrict__ active,
                                                       const float* __restrict__ Wg, const float* __restrict__ bg,
                                                       const float* __restrict__ Wc, const float* __restrict__ bc, int act,
                                                       float* __restrict__ r_out, float* __restrict__ u_out,
                                                       float* __restrict__ c_out, float* __restrict__ h_new) {
-    __shared__ float a[G_ROWS][G_KMAX];
-    __shared__ float rh[G_ROWS][G_HMAX];
-    __shared__ float us[G_ROWS][G_HMAX];
+    __shared__ float a[ROWS][G_KMAX];
+    __shared__ float rh[ROWS][G_HMAX];
+    __shared__ float us[ROWS][G_HMAX];
     const int tid = threadIdx.x;
     const int IN = g.in_dim, H = g.hid, K = IN + H;
-    const int row0 = blockIdx.x * G_ROWS;
-    for (int idx = tid; idx < G_ROWS * K; idx += G_T) {
+    const int row0 = blockIdx.x * ROWS;
+    for (int idx = tid; idx < ROWS * K; idx += G_T) {
         const int r = idx / K, k = idx - r * K;
         const int row = row0 + r;
         float v = 0.0f;
@@ -66,19 +68,23 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
     __syncthreads();
     {   // gates
         const int C = 2 * H;
-        const int j = tid % C, g0 = tid / C, ng = G_T / C, per = G_ROWS / ng;
-        float acc[G_ROWS];
+        const int j = tid % C, g0 = tid / C, ng = G_T / C, per = ROWS / ng;   // ng <= 4 <= ROWS
+        float acc[ROWS];
 #pragma unroll
-        for (int i = 0; i < G_ROWS; ++i) acc[i] = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            const float w = Wg[static_cast<int64_t>(k) * C + j];
+        for (int i = 0; i < ROWS; ++i) acc[i] = 0.0f;
+        for (int k0 = 0; k0 < K; k0 += 16) {      // 16 weight loads in flight per thread; the tail is guarded
+            float w[16];
 #pragma unroll
-            for (int i = 0; i < G_ROWS; ++i)
-                if (i < per) acc[i] = fmaf(a[g0 + i * ng][k], w, acc[i]);
+            for (int q = 0; q < 16; ++q) w[q] = (k0 + q < K) ? Wg[static_cast<int64_t>(k0 + q) * C + j] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i)
+                    if (i < per && k0 + q < K) acc[i] = fmaf(a[g0 + i * ng][k0 + q], w[q], acc[i]);
         }
         const float b = bg[j];
 #pragma unroll
-        for (int i = 0; i < G_ROWS; ++i) {
+        for (int i = 0; i < ROWS; ++i) {
             if (i < per) {
                 const int r = g0 + i * ng, row = row0 + r;
                 const float s = sigmoidf_(acc[i] + b);
@@ -94,25 +100,34 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
     }
     __syncthreads();
     {   // candidate and new state
-        const int j = tid % H, g0 = tid / H, ng = G_T / H, per = G_ROWS / ng;
-        float acc[G_ROWS / 2];
+        const int j = tid % H, g0 = tid / H, ng = G_T / H;
+        const int per = (ROWS >= ng) ? ROWS / ng : (g0 < ROWS ? 1 : 0);   // more thread groups than rows: the rest idle
+        float acc[ROWS];
 #pragma unroll
-        for (int i = 0; i < G_ROWS / 2; ++i) acc[i] = 0.0f;
-        for (int k = 0; k < IN; ++k) {
-            const float w = Wc[static_cast<int64_t>(k) * H + j];
+        for (int i = 0; i < ROWS; ++i) acc[i] = 0.0f;
+        for (int k0 = 0; k0 < IN; k0 += 16) {
+            float w[16];
 #pragma unroll
-            for (int i = 0; i < G_ROWS / 2; ++i)
-                if (i < per) acc[i] = fmaf(a[g0 + i * ng][k], w, acc[i]);
+            for (int q = 0; q < 16; ++q) w[q] = (k0 + q < IN) ? Wc[static_cast<int64_t>(k0 + q) * H + j] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i)
+                    if (i < per && k0 + q < IN) acc[i] = fmaf(a[g0 + i * ng][k0 + q], w[q], acc[i]);
         }
-        for (int k = 0; k < H; ++k) {
-            const float w = Wc[static_cast<int64_t>(IN + k) * H + j];
+        for (int k0 = 0; k0 < H; k0 += 16) {       // H is a multiple of 16
+            float w[16];
 #pragma unroll
-            for (int i = 0; i < G_ROWS / 2; ++i)
-                if (i < per) acc[i] = fmaf(rh[g0 + i * ng][k], w, acc[i]);
+            for (int q = 0; q < 16; ++q) w[q] = Wc[static_cast<int64_t>(IN + k0 + q) * H + j];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i)
+                    if (i < per) acc[i] = fmaf(rh[g0 + i * ng][k0 + q], w[q], acc[i]);
         }
         const float b = bc[j];
 #pragma unroll
-        for (int i = 0; i < G_ROWS / 2; ++i) {
+        for (int i = 0; i < ROWS; ++i) {
             if (i < per) {
                 const int r = g0 + i * ng, row = row0 + r;
                 if (row < g.B) {
@@ -133,20 +148,21 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
 //   dc~ = dh' (1-u) act'(c) ;  du~ = dh' (h - c) u (1-u) ;  d(rh) = dc~ Wc[in:,:]^T ;  dr~ = d(rh) h r (1-r)
 //   dx  = dc~ Wc[:in,:]^T + [dr~ | du~] Wg[:in,:]^T
 // ------------------------------------------------------------------------------------------------
+template <int ROWS>
 __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float* __restrict__ Wg,
                                                            const float* __restrict__ Wc, int act,
                                                            const float* __restrict__ r_in, const float* __restrict__ u_in,
                                                            const float* __restrict__ c_in, const float* __restrict__ dh_new,
                                                            float* __restrict__ dcp_out, float* __restrict__ dg_out,
                                                            float* __restrict__ dx_out) {
-    __shared__ float dcp[G_ROWS][G_HMAX];
-    __shared__ float dg[G_ROWS][2 * G_HMAX];
-    __shared__ float hh[G_ROWS][G_HMAX];
-    __shared__ float rr[G_ROWS][G_HMAX];
+    __shared__ float dcp[ROWS][G_HMAX];
+    __shared__ float dg[ROWS][2 * G_HMAX];
+    __shared__ float hh[ROWS][G_HMAX];
+    __shared__ float rr[ROWS][G_HMAX];
     const int tid = threadIdx.x;
     const int IN = g.in_dim, H = g.hid;
-    const int row0 = blockIdx.x * G_ROWS;
-    for (int idx = tid; idx < G_ROWS * H; idx += G_T) {
+    const int row0 = blockIdx.x * ROWS;
+    for (int idx = tid; idx < ROWS * H; idx += G_T) {
         const int r = idx / H, j = idx - r * H, row = row0 + r;
         float vdc = 0.0f, vdu = 0.0f, vh = 0.0f, vr = 0.0f;
         if (row < g.B) {
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float*
         rr[r][j] = vr;
     }
     __syncthreads();
-    for (int idx = tid; idx < G_ROWS * H; idx += G_T) {
+    for (int idx = tid; idx < ROWS * H; idx += G_T) {
         const int r = idx / H, k = idx - r * H;
         const float* w = Wc + static_cast<int64_t>(IN + k) * H;
         float s = 0.0f;
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float*
         dg[r][k] = s * hh[r][k] * rv * (1.0f - rv);
     }
     __syncthreads();
-    for (int idx = tid; idx < G_ROWS * IN; idx += G_T) {
+    for (int idx = tid; idx < ROWS * IN; idx += G_T) {
         const int r = idx / IN, i = idx - r * IN, row = row0 + r;
         if (row >= g.B) continue;
         const float* wc = Wc + static_cast<int64_t>(i) * H;
@@ -182,7 +198,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float*
         for (int j = 0; j < 2 * H; ++j) s = fmaf(dg[r][j], wg[j], s);
         dx_out[static_cast<int64_t>(row) * IN + i] = s;
     }
-    for (int idx = tid; idx < G_ROWS * H; idx += G_T) {
+    for (int idx = tid; idx < ROWS * H; idx += G_T) {
         const int r = idx / H, j = idx - r * H, row = row0 + r;
         if (row >= g.B) continue;
         dcp_out[static_cast<int64_t>(row) * H + j] = dcp[r][j];
@@ -203,6 +219,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_weights_kernel(GruIn g, const flo
     if (t < n_g) {
         const int k = static_cast<int>(t / (2 * H)), j = static_cast<int>(t - static_cast<int64_t>(k) * 2 * H);
         float s = 0.0f;
+#pragma unroll 8
         for (int b = 0; b < g.B; ++b) {
             const float av = (k < IN) ? x_row(g, b)[k] : g.h[static_cast<int64_t>(b) * H + (k - IN)];
             s = fmaf(av, dgp[static_cast<int64_t>(b) * 2 * H + j], s);
@@ -212,6 +229,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_weights_kernel(GruIn g, const flo
         const int64_t q = t - n_g;
         const int k = static_cast<int>(q / H), j = static_cast<int>(q - static_cast<int64_t>(k) * H);
         float s = 0.0f;
+#pragma unroll 8
         for (int b = 0; b < g.B; ++b) {
             const int64_t o = static_cast<int64_t>(b) * H + (k - IN);
             const float av = (k < IN) ? x_row(g, b)[k] : r_in[o] * g.h[o];
@@ -232,8 +250,9 @@ __global__ __launch_bounds__(G_T) void gru_bwd_weights_kernel(GruIn g, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// loss: one workgroup per session b.  logits[y] = final_act(out[b] . E[Y[y]] + bias[Y[y]]); the
-// session's own positive is column b.  _softmax_neg masks that column, bpr_max / top1_max weigh the
+// loss, three launches: (a) logits[b, y] = final_act(out[b] . E[Y[y]] + bias[Y[y]]) as a small GEMM whose
+// target rows are read once; (b) per session b the row-wise loss and its gradient; (c) dL/dout, again
+// with every target row read once.  The session's own positive is column b.  _softmax_neg masks that column, bpr_max / top1_max weigh the
 // pairwise terms with it; the hand-derived gradient (checked against autograd in the tests):
 //   s_y = softmax over y != b of l_y (the masked column enters the max as 0, GRU4RecPlus.py:139-141)
 //   bpr_max : P = sum s_y sig(l_b - l_y), R = sum s_y l_y^2, L = -log(P + 1e-24) + lam R
@@ -266,29 +285,56 @@ __device__ __forceinline__ float final_act_grad(float l, int kind) {  // through
     return kind == 0 ? 1.0f : (kind == 1 ? (l > 0.0f ? 1.0f : 0.0f) : (l > 0.0f ? 1.0f : 0.2f));
 }
 
-__global__ __launch_bounds__(G_T) void session_loss_kernel(const float* __restrict__ out, int B, int H,
-                                                           const float* __restrict__ E, const float* __restrict__ bias,
-                                                           const int32_t* __restrict__ Y, int n_y, int fact, int loss_kind,
-                                                           float bpr_reg, float* __restrict__ dlogits,
-                                                           float* __restrict__ dout, float* __restrict__ loss) {
-    __shared__ float lg[L_NY_MAX];
-    __shared__ float hrow[G_HMAX];
-    __shared__ float red[G_T / 64];
-    __shared__ float part[G_T];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int d = tid; d < H; d += G_T) hrow[d] = out[static_cast<int64_t>(b) * H + d];
+// (a) logits[b, y] = final_act(out[b] . E[Y[y]] + bias[Y[y]]): one workgroup per 16 targets, whose rows are
+//     read ONCE (coalesced) into LDS and used by every session -- b * n_y dot products, n_y row reads.
+constexpr int L_TY = 16;
+
+__global__ __launch_bounds__(G_T) void session_logits_kernel(const float* __restrict__ out, int B, int H,
+                                                             const float* __restrict__ E, const float* __restrict__ bias,
+                                                             const int32_t* __restrict__ Y, int n_y, int fact,
+                                                             float* __restrict__ logits) {
+    __shared__ float et[L_TY][G_HMAX + 4];
+    __shared__ float bs[L_TY];
+    const int tid = threadIdx.x, y0 = blockIdx.x * L_TY;
+    for (int idx = tid; idx < L_TY * H; idx += G_T) {
+        const int y = idx / H, d = idx - y * H;
+        et[y][d] = (y0 + y < n_y) ? E[static_cast<int64_t>(Y[y0 + y]) * H + d] : 0.0f;
+    }
+    if (tid < L_TY) bs[tid] = (y0 + tid < n_y) ? bias[Y[y0 + tid]] : 0.0f;
     __syncthreads();
+    for (int idx = tid; idx < 2 * B; idx += G_T) {     // (session, half of the 16 targets)
+        const int b = idx >> 1, q0 = (idx & 1) * (L_TY / 2);
+        const float4* o = reinterpret_cast<const float4*>(out + static_cast<int64_t>(b) * H);
+        float acc[L_TY / 2];
+#pragma unroll
+        for (int q = 0; q < L_TY / 2; ++q) acc[q] = 0.0f;
+        for (int k4 = 0; k4 < H / 4; ++k4) {
+            const float4 v = o[k4];
+#pragma unroll
+            for (int q = 0; q < L_TY / 2; ++q) {
+                const float* e = &et[q0 + q][4 * k4];
+                acc[q] = fmaf(v.x, e[0], acc[q]); acc[q] = fmaf(v.y, e[1], acc[q]);
+                acc[q] = fmaf(v.z, e[2], acc[q]); acc[q] = fmaf(v.w, e[3], acc[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < L_TY / 2; ++q) {
+            const int y = y0 + q0 + q;
+            if (y < n_y) logits[static_cast<int64_t>(b) * n_y + y] = final_act_fwd(acc[q] + bs[q0 + q], fact);
+        }
+    }
+}
+
+// (b) per session: softmax over the other targets, loss, gradient w.r.t. the pre-activation logits (in place)
+__global__ __launch_bounds__(G_T) void session_rowloss_kernel(int B, int n_y, int fact, int loss_kind, float bpr_reg,
+                                                              float* __restrict__ dlogits, float* __restrict__ loss) {
+    __shared__ float lg[L_NY_MAX];
+    __shared__ float red[G_T / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* row = dlogits + static_cast<int64_t>(b) * n_y;
     float mx = 0.0f;   // the masked column contributes a 0 to the max
     for (int y = tid; y < n_y; y += G_T) {
-        const int item = Y[y];
-        const float4* e = reinterpret_cast<const float4*>(E + static_cast<int64_t>(item) * H);
-        float s = 0.0f;
-        for (int q = 0; q < H / 4; ++q) {
-            const float4 v = e[q];
-            s = fmaf(hrow[4 * q], v.x, s); s = fmaf(hrow[4 * q + 1], v.y, s);
-            s = fmaf(hrow[4 * q + 2], v.z, s); s = fmaf(hrow[4 * q + 3], v.w, s);
-        }
-        const float l = final_act_fwd(s + bias[item], fact);
+        const float l = row[y];
         lg[y] = l;
         if (y != b) mx = fmaxf(mx, l);
     }
@@ -327,7 +373,6 @@ __global__ __launch_bounds__(G_T) void session_loss_kernel(const float* __restri
         gpos = -a2;
     }
     if (tid == 0) atomicAdd(loss, lb * invB);
-    __syncthreads();
     for (int y = tid; y < n_y; y += G_T) {
         const float l = lg[y];
         float gy;
@@ -345,23 +390,46 @@ __global__ __launch_bounds__(G_T) void session_loss_kernel(const float* __restri
                 gy = s * (s1 * (1.0f - s1) + 2.0f * l * s2 * (1.0f - s2)) + s * ((s1 + s2) - a0);
             }
         }
-        gy *= invB * final_act_grad(l, fact);
-        dlogits[static_cast<int64_t>(b) * n_y + y] = gy;
-        lg[y] = gy;   // each y is owned by one thread in both loops
+        row[y] = gy * invB * final_act_grad(l, fact);
+    }
+}
+
+// (c) dL/dout[b] += sum over this workgroup's 64 targets of dlogits[b, y] E[Y[y]] for 16 sessions; target rows
+//     and gradient tile are staged in LDS, partial sums meet in dout through atomics (cleared by the caller)
+constexpr int L_CY = 64;
+constexpr int L_CB = 16;
+
+__global__ __launch_bounds__(G_T) void session_dout_kernel(const float* __restrict__ dlogits, int B, int H,
+                                                           const float* __restrict__ E, const int32_t* __restrict__ Y,
+                                                           int n_y, float* __restrict__ dout) {
+    __shared__ float et[L_CY][G_HMAX];
+    __shared__ float gl[L_CB][L_CY + 1];
+    const int tid = threadIdx.x, y0 = blockIdx.x * L_CY, b0 = blockIdx.y * L_CB;
+    const int ny = (n_y - y0) < L_CY ? (n_y - y0) : L_CY;
+    for (int idx = tid; idx < ny * H; idx += G_T) {
+        const int y = idx / H, d = idx - y * H;
+        et[y][d] = E[static_cast<int64_t>(Y[y0 + y]) * H + d];
+    }
+    for (int idx = tid; idx < L_CB * L_CY; idx += G_T) {
+        const int r = idx / L_CY, y = idx - r * L_CY;
+        gl[r][y] = (b0 + r < B && y < ny) ? dlogits[static_cast<int64_t>(b0 + r) * n_y + y0 + y] : 0.0f;
     }
     __syncthreads();
-    // dL/dout[b] = sum_y g_y E[Y[y]]: threads split into 256/H groups over y, lanes over the dimension
-    {
-        const int d = tid % H, grp = tid / H, ng = G_T / H;
-        float s = 0.0f;
-        for (int y = grp; y < n_y; y += ng) s = fmaf(lg[y], E[static_cast<int64_t>(Y[y]) * H + d], s);
-        part[tid] = s;
-        __syncthreads();
-        if (tid < H) {
-            float t = 0.0f;
-            for (int q = 0; q < ng; ++q) t += part[q * H + tid];
-            dout[static_cast<int64_t>(b) * H + tid] = t;
-        }
+    const int d = tid % H, grp = tid / H, ng = G_T / H;      // ng in {2, 4, 8}: L_CB / ng sessions per thread
+    float acc[L_CB / 2];
+#pragma unroll
+    for (int i = 0; i < L_CB / 2; ++i) acc[i] = 0.0f;
+    const int per = L_CB / ng;
+    for (int y = 0; y < ny; ++y) {
+        const float e = et[y][d];
+#pragma unroll
+        for (int i = 0; i < L_CB / 2; ++i)
+            if (i < per) acc[i] = fmaf(gl[grp + i * ng][y], e, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < L_CB / 2; ++i) {
+        const int b = b0 + grp + i * ng;
+        if (i < per && b < B) atomicAdd(&dout[static_cast<int64_t>(b) * H + d], acc[i]);
     }
 }
 
@@ -446,8 +514,14 @@ int skr_gru_cell_fwd(const float* d_x, const int32_t* d_x_index, const float* d_
     SKR_REQUIRE(B >= 0 && d_h != d_h_new, "skr_gru_cell_fwd: bad batch or in-place state");
     if (B == 0) return SKR_OK;
     GruIn g{d_x, d_x_index, d_h, B, in_dim, hid};
-    hipLaunchKernelGGL(gru_fwd_kernel, dim3((B + G_ROWS - 1) / G_ROWS), dim3(G_T), 0, skr::as_stream(stream), g, d_active,
-                       d_Wg, d_bg, d_Wc, d_bc, hidden_act_kind, d_r, d_u, d_c, d_h_new);
+    // few sessions (a training batch): 4 rows per workgroup so that more than a handful of CUs work;
+    // many (the inference sweep): 16 rows, each weight read once per 16 sessions
+    if (B <= G_SMALL_B)
+        hipLaunchKernelGGL(gru_fwd_kernel<4>, dim3((B + 3) / 4), dim3(G_T), 0, skr::as_stream(stream), g, d_active, d_Wg,
+                           d_bg, d_Wc, d_bc, hidden_act_kind, d_r, d_u, d_c, d_h_new);
+    else
+        hipLaunchKernelGGL(gru_fwd_kernel<G_ROWS>, dim3((B + G_ROWS - 1) / G_ROWS), dim3(G_T), 0, skr::as_stream(stream), g,
+                           d_active, d_Wg, d_bg, d_Wc, d_bc, hidden_act_kind, d_r, d_u, d_c, d_h_new);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
@@ -466,8 +540,12 @@ int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_
     GruIn g{d_x, d_x_index, d_h, B, in_dim, hid};
     float* dcp = d_work;                                   // [B, hid]
     float* dgp = d_work + static_cast<int64_t>(B) * hid;   // [B, 2 hid]
-    hipLaunchKernelGGL(gru_bwd_rows_kernel, dim3((B + G_ROWS - 1) / G_ROWS), dim3(G_T), 0, st, g, d_Wg, d_Wc,
-                       hidden_act_kind, d_r, d_u, d_c, d_dh_new, dcp, dgp, d_dx);
+    if (B <= G_SMALL_B)
+        hipLaunchKernelGGL(gru_bwd_rows_kernel<4>, dim3((B + 3) / 4), dim3(G_T), 0, st, g, d_Wg, d_Wc, hidden_act_kind, d_r,
+                           d_u, d_c, d_dh_new, dcp, dgp, d_dx);
+    else
+        hipLaunchKernelGGL(gru_bwd_rows_kernel<G_ROWS>, dim3((B + G_ROWS - 1) / G_ROWS), dim3(G_T), 0, st, g, d_Wg, d_Wc,
+                           hidden_act_kind, d_r, d_u, d_c, d_dh_new, dcp, dgp, d_dx);
     SKR_LAUNCH_CHECK();
     const int64_t n_out = static_cast<int64_t>(in_dim + hid) * 3 * hid + 3 * hid;
     hipLaunchKernelGGL(gru_bwd_weights_kernel, dim3(static_cast<unsigned>((n_out + G_T - 1) / G_T)), dim3(G_T), 0, st, g,
@@ -484,8 +562,16 @@ int skr_session_loss(const float* d_out, int B, int hid, const float* d_item_tab
     SKR_REQUIRE(B >= 1 && n_y >= B && n_y <= L_NY_MAX, "skr_session_loss: need B <= n_y <= %d (got %d, %d)", L_NY_MAX, B, n_y);
     SKR_REQUIRE(final_act_kind >= 0 && final_act_kind <= 2, "There is not final_act named '%d'.", final_act_kind);
     SKR_REQUIRE(loss_kind == 0 || loss_kind == 1, "There is not loss named '%d'.", loss_kind);
-    hipLaunchKernelGGL(session_loss_kernel, dim3(B), dim3(G_T), 0, skr::as_stream(stream), d_out, B, hid, d_item_table,
-                       d_item_bias, d_y, n_y, final_act_kind, loss_kind, bpr_reg, d_dlogits, d_dout, d_loss);
+    hipStream_t st = skr::as_stream(stream);
+    hipLaunchKernelGGL(session_logits_kernel, dim3((n_y + L_TY - 1) / L_TY), dim3(G_T), 0, st, d_out, B, hid, d_item_table,
+                       d_item_bias, d_y, n_y, final_act_kind, d_dlogits);
+    SKR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(session_rowloss_kernel, dim3(B), dim3(G_T), 0, st, B, n_y, final_act_kind, loss_kind, bpr_reg,
+                       d_dlogits, d_loss);
+    SKR_LAUNCH_CHECK();
+    SKR_HIP(hipMemsetAsync(d_dout, 0, static_cast<size_t>(B) * hid * sizeof(float), st));
+    hipLaunchKernelGGL(session_dout_kernel, dim3((n_y + L_CY - 1) / L_CY, (B + L_CB - 1) / L_CB), dim3(G_T), 0, st, d_dlogits,
+                       B, hid, d_item_table, d_y, n_y, d_dout);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
