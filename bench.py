@@ -263,8 +263,19 @@ def main():
     gU, gV, gb = grad[:nU * D].view(nU, D), grad[nU * D:(nU + nI) * D].view(nI, D), grad[(nU + nI) * D:]
     g_item = grad[nU * D:]                                  # [V | b] gradients: the all-reduced part
     touch = torch.zeros((n_par + 63) // 64, dtype=torch.uint8, device=dev)
-    if world > 1:
+    # N > 1, the path's one exchange step: the item table is replicated, its gradient has to be summed over
+    # the ranks.  A step touches at most 2*b of the I item rows, so by default the ranks exchange packed rows
+    # (skr_pack_grad_rows -> all-gather -> skr_unpack_grad_rows, ~0.54 MB per rank and step) instead of
+    # all-reducing the dense [I, 65] block (26 MB); SKR_EXCHANGE=dense keeps the all-reduce.
+    exchange = os.environ.get("SKR_EXCHANGE", "sparse") if world > 1 else "none"
+    assert exchange in ("none", "sparse", "dense")
+    if exchange == "dense":
         touch[nU:] = 2                                      # all-reduced item gradients are read every step
+    if exchange == "sparse":
+        from skrec.parallel import unique_padded_rows
+        pack_buf = torch.empty((2 * b, D + 2), device=dev)
+        gather_buf = torch.empty((world, 2 * b, D + 2), device=dev)
+        gather_views = [gather_buf[r] for r in range(world)]
     loss = torch.zeros(2, device=dev)
 
     # ---- the slice of the epoch these W+K steps consume: a user prefix of the local shard ---------
@@ -293,6 +304,9 @@ def main():
         # data_ptr() calls): keeps the launch rate above the kernel rate also at N = 8
         pu, pi, pj = uu.data_ptr(), ii.data_ptr(), jj.data_ptr()
         stream = st()
+        if exchange == "sparse":   # per step: the distinct item ids its 2*b gradient rows belong to (-1 = duplicate)
+            step_ids = unique_padded_rows(torch.cat([ii.view(n_steps, b), jj.view(n_steps, b)], dim=1))
+            pids = step_ids.data_ptr()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)] \
             if events is not None else None
         for s in range(n_steps):
@@ -301,12 +315,21 @@ def main():
                                 P["gU"], P["gV"], P["gb"], P["gU"], P["gV"], P["loss"], P["touch"], P["grad"], stream)
             run_slice.t += 1
             if world > 1:
-                # the path's one exchange step: replicated item table => sum its gradients over xGMI.
-                # It runs on RCCL's stream while Adam sweeps the (local) user part of the flat buffer.
-                work = dist.all_reduce(g_item, async_op=True)
+                # the exchange runs on RCCL's stream while Adam sweeps the (local) user part of the flat buffer
+                if exchange == "sparse":
+                    rc |= L.skr_pack_grad_rows(pids + s * 2 * b * 4, 2 * b, P["gV"], P["gb"], D, pack_buf.data_ptr(), stream)
+                    if gather_into:
+                        work = dist.all_gather_into_tensor(gather_buf, pack_buf, async_op=True)
+                    else:
+                        work = dist.all_gather(gather_views, pack_buf, async_op=True)
+                else:
+                    work = dist.all_reduce(g_item, async_op=True)
                 rc |= L.skr_adam_step(P["flat"], P["grad"], P["m1"], P["m2"], n_user_par, 1e-3, 0.9, 0.999, 1e-8,
                                       run_slice.t, 1, P["touch"], stream)
                 work.wait()
+                if exchange == "sparse":
+                    rc |= L.skr_unpack_grad_rows(gather_buf.data_ptr(), 2 * b, world, P["gV"], P["gb"], D, P["touch"],
+                                                 P["grad"], stream)
                 if ev is not None:
                     ev[s][0].record()
                 rc |= L.skr_adam_step(P["flat"] + 4 * n_user_par, P["grad"] + 4 * n_user_par, P["m1"] + 4 * n_user_par,
@@ -324,6 +347,7 @@ def main():
         if events is not None:
             events.extend(ev)
     n_user_par = nU * D
+    gather_into = world > 1 and dist.get_backend() == "nccl"    # gloo rehearsals use the list form
     P = {k: t.data_ptr() for k, t in dict(U=U, V=V, bias=bias, gU=gU, gV=gV, gb=gb, loss=loss, touch=touch, grad=grad,
                                           flat=flat, m1=m1, m2=m2).items()}
     run_slice.t = 0

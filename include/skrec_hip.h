@@ -235,6 +235,17 @@ int skr_gather_rows(const float* d_table, const int32_t* d_idx, int64_t n, int d
 int skr_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
 int skr_scale(float a, float* d_x, int64_t n, void* stream);                 /* x *= a */
 
+/* Sparse exchange of a replicated table's gradient between ranks (no reference counterpart -- the
+ * reference is single-process).  A BPR step touches at most 2*batch item rows, so instead of all-reducing the
+ * dense [I, 65] block each rank packs its touched rows, the ranks all-gather the packs, and every rank adds
+ * all packs to its dense gradient in rank order (replicas stay bit-identical).
+ *   skr_pack_grad_rows:   d_ids int32[n], unique or negative (empty slot); d_out float32[n, dim+2] rows
+ *                         [id bits | dV[id] | db[id]]; the packed dense rows are CLEARED.  d_g_bias may be NULL.
+ *   skr_unpack_grad_rows: d_in float32[n_ranks, n_per_rank, dim+2]; dense += every valid row, rank 0 first. */
+int skr_pack_grad_rows(const int32_t* d_ids, int n, float* d_g_table, float* d_g_bias, int dim, float* d_out, void* stream);
+int skr_unpack_grad_rows(const float* d_in, int n_per_rank, int n_ranks, float* d_g_table, float* d_g_bias, int dim,
+                         uint8_t* d_touch, const float* d_touch_base, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * G rows: GRU4RecPlus, recommender/GRU4RecPlus.py.  PARITY UNPINNED -- the reference runs this
  * model on TensorFlow 1.14, absent here; these entry points follow the graph of GRU4RecPlus.py:124-200 and

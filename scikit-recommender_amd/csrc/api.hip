@@ -59,7 +59,7 @@ int skr_csr_max_row_len(const int64_t* d_rowptr, int n_rows, int* out_max, void*
     int* d_scratch = nullptr;
     SKR_HIP(hipMalloc(&d_scratch, sizeof(int)));
     int rc = skr::max_row_len(d_rowptr, n_rows, d_scratch, skr::as_stream(stream), out_max);
-    hipFree(d_scratch);
+    (void)hipFree(d_scratch);
     return rc;
 }
 

@@ -661,11 +661,11 @@ int skr_sampler_create(uint32_t seed, skr_sampler** out) {
 
 int skr_sampler_destroy(skr_sampler* s) {
     if (!s) return SKR_OK;
-    hipFree(s->d_state);
-    hipFree(s->d_pos);
-    hipFree(s->d_draws);
-    hipFree(s->d_ctl);
-    hipFree(s->d_raw);
+    (void)hipFree(s->d_state);
+    (void)hipFree(s->d_pos);
+    (void)hipFree(s->d_draws);
+    (void)hipFree(s->d_ctl);
+    (void)hipFree(s->d_raw);
     delete s;
     return SKR_OK;
 }

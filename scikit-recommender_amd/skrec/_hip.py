@@ -32,6 +32,8 @@ SIGNATURES = {
     "skr_sample_epoch_exact": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, vp]),
     "skr_sample_epoch_exact_counts": (i32, [vp, i32, i32, vp, vp, i64, vp, i64, vp, vp]),
     "skr_sample_epoch_fast": (i32, [u64, u64, i64, i32, i32, vp, vp, i64, i32, vp, vp]),
+    "skr_pack_grad_rows": (i32, [vp, i32, vp, vp, i32, vp, vp]),
+    "skr_unpack_grad_rows": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp]),
     "skr_gru_cell_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "skr_gru_cell_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "skr_session_loss": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]),

@@ -28,7 +28,8 @@ from . import _hip
 from .recommender.base import DenseAdam
 from .recommender.LightGCN import DeviceCSR
 
-__all__ = ["DistContext", "ShardedBPRMF", "ShardedLightGCN", "ShardedLayerGCN", "init_from_env", "sharded_evaluate"]
+__all__ = ["DistContext", "ShardedBPRMF", "ShardedLightGCN", "ShardedLayerGCN", "init_from_env", "sharded_evaluate",
+           "unique_padded_rows"]
 
 
 class DistContext(object):
@@ -50,6 +51,15 @@ class DistContext(object):
             dist.all_reduce(t)
         return t
 
+    def all_gather_rows(self, out, inp):
+        """out [world, ...] <- every rank's inp (same shape on every rank)"""
+        import torch.distributed as dist
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(out, inp)
+        else:
+            dist.all_gather([out[r] for r in range(self.world)], inp)
+        return out
+
     def barrier(self):
         if self.active:
             import torch.distributed as dist
@@ -70,6 +80,15 @@ def init_from_env():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return DistContext(rank, world)
+
+
+def unique_padded_rows(ids):
+    """[S, C] integer ids -> int32 [S, C]: every row sorted, repeated ids replaced by -1 (an empty slot of
+    skr_pack_grad_rows)"""
+    srt = torch.sort(ids, dim=1).values
+    dup = torch.zeros_like(srt, dtype=torch.bool)
+    dup[:, 1:] = srt[:, 1:] == srt[:, :-1]
+    return torch.where(dup, torch.full_like(srt, -1), srt).int().contiguous()
 
 
 def _csr_from_device_coo(rows, cols, vals, n_rows, n_cols):
@@ -388,8 +407,13 @@ def sharded_evaluate(ctx, evaluator, model, test_users, device):
 class ShardedBPRMF(object):
     """BPRMF step for one rank: flat parameter buffer [U_local | V | b], item part replicated."""
 
-    def __init__(self, ctx, user0, item0, bias0, lr, reg, device=None):
+    def __init__(self, ctx, user0, item0, bias0, lr, reg, device=None, exchange=None):
         self.ctx = ctx
+        # how the item gradient is summed over the ranks: "dense" all-reduces the [I, 65] block, "sparse" all-gathers
+        # the touched rows (at most 2 * largest local batch), "auto" picks the smaller message per step
+        self.exchange = exchange or os.environ.get("SKR_EXCHANGE", "auto")
+        if self.exchange not in ("auto", "dense", "sparse"):
+            raise ValueError("exchange must be 'auto', 'dense' or 'sparse'")
         self.device = device if device is not None else _hip.require_gpu()
         user0 = torch.as_tensor(np.asarray(user0), dtype=torch.float32)
         item0 = torch.as_tensor(np.asarray(item0), dtype=torch.float32)
@@ -408,9 +432,36 @@ class ShardedBPRMF(object):
         g = self.optimizer.grad
         self._gU, self._gV, self._gb = g[:nl * 64].view(nl, 64), g[nl * 64:(nl + ni) * 64].view(ni, 64), g[(nl + ni) * 64:]
         self._g_item = g[nl * 64:]                      # [V | b]: what the ranks exchange
-        if ctx.active:
-            self.optimizer.touch[nl:] = 2               # summed gradients are dense: always read them
+        self._dense_marked = False
         self.loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+
+    def _exchange_item_grads(self, users, il, jl):
+        """sum the [V | b] gradient over the ranks; every replica ends with bit-identical values"""
+        world, ni = self.ctx.world, self.num_items
+        opt = self.optimizer
+        cap = 2 * int(torch.bincount(users.long() % world, minlength=world).max())   # same number on every rank
+        sparse = self.exchange == "sparse" or (self.exchange == "auto" and world * cap * 66 < ni * 65)
+        if not sparse:
+            if not self._dense_marked:
+                opt.touch[self.n_local:] = 2            # summed gradients are dense: always read them
+                self._dense_marked = True
+            self.ctx.all_reduce(self._g_item)
+            return
+        if self._dense_marked:
+            opt.touch[self.n_local:] = 0
+            opt.grad[self.n_local * 64:].zero_()
+            self._dense_marked = False
+        ids = torch.full((1, max(cap, 1)), -1, dtype=torch.int32, device=self.device)
+        n = il.numel()
+        ids[0, :n], ids[0, n:2 * n] = il, jl
+        ids = unique_padded_rows(ids)
+        pack = torch.empty((cap, 66), dtype=torch.float32, device=self.device)
+        gathered = torch.empty((world, cap, 66), dtype=torch.float32, device=self.device)
+        L, st = _hip.lib(), _hip.stream()
+        _hip.check(L.skr_pack_grad_rows(_hip.ptr(ids), cap, _hip.ptr(self._gV), _hip.ptr(self._gb), 64, _hip.ptr(pack), st))
+        self.ctx.all_gather_rows(gathered, pack)
+        _hip.check(L.skr_unpack_grad_rows(_hip.ptr(gathered), cap, world, _hip.ptr(self._gV), _hip.ptr(self._gb), 64,
+                                          _hip.ptr(opt.touch), _hip.ptr(opt.grad), st))
 
     def train_step(self, users, pos, neg):
         """users/pos/neg: int32 device tensors of the GLOBAL batch, identical on every rank"""
@@ -429,7 +480,8 @@ class ShardedBPRMF(object):
                 _hip.ptr(self.item_rows), _hip.ptr(ul), _hip.ptr(il), _hip.ptr(jl), ul.numel(), 1.0, self.reg, 1.0,
                 _hip.ptr(self._gU), _hip.ptr(self._gV), _hip.ptr(self._gb), _hip.ptr(self._gU), _hip.ptr(self._gV),
                 _hip.ptr(self.loss), _hip.ptr(opt.touch), _hip.ptr(opt.grad), _hip.stream()))
-        self.ctx.all_reduce(self._g_item)               # the one exchange step
+        if world > 1:
+            self._exchange_item_grads(users, il, jl)    # the one exchange step
         self.ctx.all_reduce(self.loss)
         opt.step()
 

@@ -140,9 +140,9 @@ def test_lightgcn_fit_under_torchrun_contract(tiny_dir, tmp_path):
     assert np.array_equal(res[0]["reports"], res[1]["reports"])
 
 
-def _bprmf_worker(rank, world, port, data_dir, workdir, ret):
+def _bprmf_worker(rank, world, port, data_dir, workdir, exchange, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
-                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo")
+                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo", SKR_EXCHANGE=exchange)
     os.chdir(workdir)
     import random
     from skrec import RunConfig
@@ -175,14 +175,14 @@ def _bprmf_worker(rank, world, port, data_dir, workdir, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_bprmf_fit_under_torchrun_contract(world, tiny_dir, tmp_path):
-    """BPRMF.fit() on N ranks (global batch 256 split by user ownership, item gradients all-reduced)
-    == the reference's single-process run"""
+@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "sparse"), (3, "sparse"), (3, "auto")])
+def test_bprmf_fit_under_torchrun_contract(world, exchange, tiny_dir, tmp_path):
+    """BPRMF.fit() on N ranks (global batch 256 split by user ownership; item gradients summed either by a
+    dense all-reduce or by the packed-row all-gather) == the reference's single-process run"""
     g = np.load(os.path.join(GOLDEN, "golden_bprmf.npz"))
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_bprmf_worker, args=(world, _free_port(), tiny_dir, str(tmp_path), ret), nprocs=world, join=True)
+        mp.spawn(_bprmf_worker, args=(world, _free_port(), tiny_dir, str(tmp_path), exchange, ret), nprocs=world, join=True)
         res = {k: ret[k] for k in range(world)}
     for r in res.values():
         np.testing.assert_allclose(r["losses"][:, 0], g["bpr_sum"], rtol=1e-5)

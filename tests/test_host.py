@@ -153,3 +153,14 @@ def test_knowledge_graph_head_dict_order():
     d = kg.to_head_dict()
     assert list(d) == [0, 1, 3] and kg.num_entities == 10 and kg.num_relations == 2
     assert d[3]["tail"].tolist() == [5, 5] and d[3]["relation"].tolist() == [0, 1] and d[1]["tail"].tolist() == [2, 9]
+
+
+def test_unique_padded_rows():
+    import torch
+    from skrec.parallel import unique_padded_rows
+    ids = torch.tensor([[5, 3, 5, -1, 3, 9], [7, 7, 7, 7, 7, 7], [0, 1, 2, 3, 4, 5]], dtype=torch.int32)
+    got = unique_padded_rows(ids)
+    assert got.dtype == torch.int32
+    for row, src in zip(got.tolist(), ids.tolist()):
+        real = [x for x in row if x >= 0]
+        assert sorted(real) == sorted(set(x for x in src if x >= 0)) and len(real) == len(set(real))
