@@ -80,6 +80,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise HipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            f"(there is no CPU fallback for the hot path)")
+        # torch first: it ships its own libamdhip64; if this library pulled in /opt/rocm's copy before torch
+        # loaded, the process would hold two HIP runtimes and torch.cuda would report no device afterwards
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = the .so and the header disagree
