@@ -348,6 +348,21 @@ def main():
             events.extend(ev)
     n_user_par = nU * D
     gather_into = world > 1 and dist.get_backend() == "nccl"    # gloo rehearsals use the list form
+    if exchange == "sparse":
+        # probe the collective once outside the timed region; every rank takes the same branch because a
+        # failing collective fails on all of them
+        try:
+            if gather_into:
+                dist.all_gather_into_tensor(gather_buf, pack_buf.zero_())
+            else:
+                dist.all_gather(gather_views, pack_buf.zero_())
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- fall back to the dense all-reduce rather than lose the run
+            if rank == 0:
+                print(f"[bench] sparse exchange unavailable ({type(e).__name__}: {e}); using the dense all-reduce",
+                      file=sys.stderr)
+            exchange = "dense"
+            touch[nU:] = 2
     P = {k: t.data_ptr() for k, t in dict(U=U, V=V, bias=bias, gU=gU, gV=gV, gb=gb, loss=loss, touch=touch, grad=grad,
                                           flat=flat, m1=m1, m2=m2).items()}
     run_slice.t = 0
@@ -386,7 +401,8 @@ def main():
                                f"step + dense Adam; eval = fused MFMA top-{args.top_k}",
                    "users": args.users, "items": args.items, "train_interactions": n_inter_total,
                    "batch_per_gpu": b, "global_batch": b * world, "sharding": f"users u%{world}, item table replicated"
-                   + (" + RCCL all-reduce of item grads per step" if world > 1 else "")},
+                   + ({"sparse": f" + RCCL all-gather of the touched item-gradient rows per step ({2 * b * 66 * 4 / 1e6:.2f} MB per rank)",
+                       "dense": " + RCCL all-reduce of the dense item gradient per step (26 MB)", "none": ""}[exchange])},
     }
     # HBM traffic per launch comes from the rocprofv3 PMC passes of this same command (separate runs:
     # tools/profile_bench.sh -> tools/summarize_profiles.py -> profiles/<round>_pmc_summary.json)
