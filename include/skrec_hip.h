@@ -120,8 +120,10 @@ int skr_sample_epoch_fast(uint64_t seed, uint64_t epoch, int64_t slot_offset, in
  *           (utils/py/cython/pyx_eval_matrix.pyx:22-37), and -- in the fused form -- also
  *           _MF.predict / _LightGCN.predict's U[b] @ V.T (+bias) (recommender/BPRMF.py:84-88,
  *           LightGCN.py:102-107) and the -inf train masking loop (utils/py/evaluator.py:197-200).
- * Tie rule (documented deviation): equal scores rank by ascending item id; the reference's order
- * among exact ties is whatever libstdc++'s heap leaves (evaluate.h:42-43).
+ * Equal scores: skr_eval_scores reproduces the reference's order, which is whatever libstdc++'s
+ * partial_sort_copy heap leaves (evaluate.h:42-43) -- rows with ties among their best K+1 scores are
+ * re-ranked by that very algorithm.  The fused form ranks equal scores by ascending item id (its fp32
+ * summation order differs from any host GEMM's anyway, so score ties are not reproducible there).
  * ========================================================================================== */
 
 /* Drop-in for cpp_evaluate_matrix (evaluate.h:57): d_scores [n_users, ld] row-major fp32 (first

@@ -76,6 +76,78 @@ __device__ inline void metric_row(int metric_id, RankP rank, int k, const int32_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The reference's order among EQUAL scores.  eval_one_user (evaluate.h:24-45) ranks with
+// std::partial_sort_copy(index.begin(), index.end(), topk.begin(), topk.begin() + min(2K, I), ratings[a] > ratings[b]):
+// libstdc++ copies the first 2K indices, make_heap, then for every later index x with
+// ratings[x] > ratings[heap top] replaces the top (__adjust_heap), finally sort_heap.  The order of equal
+// scores is whatever these heap moves produce, so rows with ties inside their top-(K+1) are re-ranked by
+// running exactly that algorithm (published libstdc++ semantics: bits/stl_algo.h __partial_sort_copy,
+// bits/stl_heap.h __adjust_heap / __push_heap / __make_heap / __sort_heap).  `val` caches the rating of
+// every heap slot.  One lane executes these; heaps of at most 2 * SKR_MAX_TOPK entries live in LDS.
+// ------------------------------------------------------------------------------------------------
+struct RefHeap {
+    int* id;      // [len]
+    float* val;   // [len]
+    int len;
+};
+
+// comp(a, b) = ratings[a] > ratings[b]: the heap's top is the SMALLEST rating kept
+__device__ inline void ref_push_heap(RefHeap& h, int hole, int top, int v_id, float v_val) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && h.val[parent] > v_val) {
+        h.id[hole] = h.id[parent];
+        h.val[hole] = h.val[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    h.id[hole] = v_id;
+    h.val[hole] = v_val;
+}
+
+__device__ inline void ref_adjust_heap(RefHeap& h, int hole, int len, int v_id, float v_val) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (h.val[child] > h.val[child - 1]) child--;
+        h.id[hole] = h.id[child];
+        h.val[hole] = h.val[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        h.id[hole] = h.id[child - 1];
+        h.val[hole] = h.val[child - 1];
+        hole = child - 1;
+    }
+    ref_push_heap(h, hole, top, v_id, v_val);
+}
+
+__device__ inline void ref_make_heap(RefHeap& h) {
+    if (h.len < 2) return;
+    int parent = (h.len - 2) / 2;
+    for (;;) {
+        const int v_id = h.id[parent];
+        const float v_val = h.val[parent];
+        ref_adjust_heap(h, parent, h.len, v_id, v_val);
+        if (parent == 0) return;
+        parent--;
+    }
+}
+
+__device__ inline void ref_sort_heap(RefHeap& h) {
+    int last = h.len;
+    while (last > 1) {
+        --last;
+        const int v_id = h.id[last];
+        const float v_val = h.val[last];
+        h.id[last] = h.id[0];
+        h.val[last] = h.val[0];
+        ref_adjust_heap(h, 0, last, v_id, v_val);
+    }
+}
+
 // Descending bitonic sort of N (power of two) 64-bit keys in LDS by a workgroup of T threads.
 template <int N, int T>
 __device__ inline void bitonic_sort_desc_lds(uint64_t* keys) {

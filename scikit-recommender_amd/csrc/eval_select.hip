@@ -43,6 +43,11 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
     __shared__ uint64_t s_thr;
     __shared__ int s_rank[SKR_MAX_TOPK];
     __shared__ double s_inv[SKR_MAX_TOPK];
+    __shared__ int s_hid[2 * SKR_MAX_TOPK];
+    __shared__ float s_hval[2 * SKR_MAX_TOPK];
+    __shared__ int s_cand[TK_TILE];
+    __shared__ int s_wsum[TK_T / 64];
+    __shared__ int s_tie;
     const int tid = threadIdx.x;
     const int64_t row = blockIdx.x;
     const float* r = scores + row * ld;
@@ -58,10 +63,10 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
         for (int i = cnt + tid; i < TK_CAP; i += TK_T) keys[i] = SKR_KEY_MIN;
         __syncthreads();
         skr::bitonic_sort_desc_lds<TK_CAP, TK_T>(keys);
-        if (tid == 0) {
-            const int keep = cnt < top_k ? cnt : top_k;
+        if (tid == 0) {   // one key beyond the K-th is kept: the tie test below needs the true (K+1)-th best
+            const int keep = cnt < top_k + 1 ? cnt : top_k + 1;
             s_cnt = keep;
-            s_thr = keep == top_k ? keys[top_k - 1] : SKR_KEY_MIN;
+            s_thr = keep == top_k + 1 ? keys[top_k] : SKR_KEY_MIN;
         }
         __syncthreads();
     };
@@ -91,13 +96,70 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
         __syncthreads();
     }
     compact();
-    // rank list (top_k <= n_items guarantees s_cnt == top_k here)
-    for (int i = tid; i < top_k; i += TK_T) {
-        const int id = skr::key_id(keys[i]);
-        s_rank[i] = id;
-        if (o.ids) o.ids[row * top_k + i] = id;
+    // rank list (top_k <= n_items guarantees s_cnt >= top_k here)
+    if (tid == 0) s_tie = 0;
+    __syncthreads();
+    {   // equal scores among the best K+1?  Then the reference's order is heap-defined (see eval_common.h)
+        const int n_chk = s_cnt - 1 < top_k ? s_cnt - 1 : top_k;
+        for (int i = tid; i < n_chk; i += TK_T)
+            if ((keys[i] >> 32) == (keys[i + 1] >> 32)) s_tie = 1;
     }
     __syncthreads();
+    if (!s_tie) {
+        for (int i = tid; i < top_k; i += TK_T) s_rank[i] = skr::key_id(keys[i]);
+    } else {
+        // second pass over the row, libstdc++'s partial_sort_copy step for step.  All threads scan a tile for
+        // elements above the heap's current top (a superset of those that will enter: the top only rises),
+        // compact them in index order, then one lane feeds them to the heap.
+        const int sort_len = 2 * top_k < n_items ? 2 * top_k : n_items;   // evaluate.h:39
+        skr::RefHeap h{s_hid, s_hval, sort_len};
+        for (int i = tid; i < sort_len; i += TK_T) {
+            s_hid[i] = i;
+            s_hval[i] = r[i];
+        }
+        __syncthreads();
+        if (tid == 0) skr::ref_make_heap(h);
+        __syncthreads();
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int base = sort_len; base < n_items; base += TK_TILE) {
+            const float topv = s_hval[0];
+            const int i0 = base + tid * 4;
+            float v[4];
+            int flags = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (i0 + e < n_items) ? r[i0 + e] : 0.0f;
+                if (i0 + e < n_items && v[e] > topv) flags |= 1 << e;
+            }
+            const int mine = __popc(flags);
+            const int incl = skr::wave_incl_scan(mine);
+            if (lane == 63) s_wsum[wv] = incl;
+            __syncthreads();
+            int off = incl - mine, total = 0;
+            for (int w = 0; w < TK_T / 64; ++w) {
+                if (w < wv) off += s_wsum[w];
+                total += s_wsum[w];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (flags & (1 << e)) s_cand[off++] = i0 + e;
+            __syncthreads();
+            if (tid == 0) {
+                for (int c = 0; c < total; ++c) {
+                    const int x = s_cand[c];
+                    const float xv = r[x];
+                    if (xv > s_hval[0]) skr::ref_adjust_heap(h, 0, sort_len, x, xv);
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) skr::ref_sort_heap(h);
+        __syncthreads();
+        for (int i = tid; i < top_k; i += TK_T) s_rank[i] = s_hid[i];
+    }
+    __syncthreads();
+    if (o.ids)
+        for (int i = tid; i < top_k; i += TK_T) o.ids[row * top_k + i] = s_rank[i];
     if (o.rows && tid < margs.n_metric) {
         const int64_t tb = test_rowptr[row], te = test_rowptr[row + 1];
         float* out = o.rows + (row * margs.n_metric + tid) * top_k;

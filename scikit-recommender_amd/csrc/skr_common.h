@@ -73,10 +73,11 @@ __device__ __forceinline__ bool contains_sorted(P a, int64_t beg, int64_t end, i
 }
 
 // Total order used everywhere a top-K is taken: score descending, then item id ascending.
-// Packed so that a plain unsigned 64-bit "greater" implements it.  (-0.0 ranks below +0.0;
-// NaN scores are not supported -- the reference's comparator is undefined on them as well.)
+// Packed so that a plain unsigned 64-bit "greater" implements it.  (-0.0 is folded into +0.0, as the
+// reference's float comparison sees them; NaN scores are not supported -- the reference's comparator is
+// undefined on them as well.)
 __device__ __forceinline__ uint64_t rank_key(float score, int id) {
-    uint32_t u = __float_as_uint(score);
+    uint32_t u = __float_as_uint(score == 0.0f ? 0.0f : score);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return (static_cast<uint64_t>(u) << 32) | static_cast<uint32_t>(~static_cast<uint32_t>(id));
 }

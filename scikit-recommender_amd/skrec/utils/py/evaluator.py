@@ -175,6 +175,33 @@ class RankingEvaluator(object):
         final = final.reshape(self.metrics_num, self.max_top)[:, self.top_show - 1].reshape(-1)
         return MetricReport(self.metrics_list, final)
 
+    _TIE_CHUNK = 2048
+
+    def _rerank_tied_rows(self, st, ut, it, bias, d_users, ids, top_sc):
+        """Users whose fused top-K holds EQUAL scores (structural ties: cold users with an all-zero row,
+        duplicated items) are ranked again from their dense score row by skr_eval_scores, which reproduces the
+        order the reference's partial_sort_copy gives equal scores (evaluate.h:39-45); the fused kernel itself
+        orders them by item id.  Tie-free rows -- all of them, normally -- cost one comparison pass."""
+        import torch
+        tied = _tied_rows(top_sc)
+        if tied.numel() == 0:
+            return
+        K = ids.shape[1]
+        n_items = int(it.shape[0])
+        for s in range(0, tied.numel(), self._TIE_CHUNK):
+            sel = tied[s:s + self._TIE_CHUNK]
+            du = d_users[sel].contiguous()
+            sc = torch.empty((du.numel(), n_items), dtype=torch.float32, device=ids.device)
+            L = _hip.lib()
+            _hip.check(L.skr_score_matrix(_hip.ptr(ut), _hip.ptr(du), du.numel(), _hip.ptr(it), _hip.ptr(bias), n_items, 64,
+                                          _hip.ptr(sc), n_items, _hip.stream()))
+            _hip.check(L.skr_mask_train(_hip.ptr(sc), du.numel(), n_items, n_items, _hip.ptr(du), _hip.ptr(st["tr_ptr"]),
+                                        _hip.ptr(st["tr_items"]), _hip.stream()))
+            fixed = torch.empty((du.numel(), K), dtype=torch.int32, device=ids.device)
+            _hip.check(L.skr_eval_scores(_hip.ptr(sc), du.numel(), n_items, n_items, None, None, None, 0, K, None,
+                                         _hip.ptr(fixed), None, _hip.stream()))
+            ids[sel] = fixed
+
     def per_user_rows(self, model, test_users):
         """-> (rows float32 [n, n_metric*max_top] on the host or None, fp64 column sums, n)."""
         import torch
@@ -199,10 +226,13 @@ class RankingEvaluator(object):
                 b = min(_FUSED_CHUNK, n - s)
                 du = d_users[s:s + b]
                 ids = torch.empty((b, K), dtype=torch.int32, device=dev)
+                top_sc = torch.empty((b, K), dtype=torch.float32, device=dev)
                 rows = torch.empty((b, nm * K), dtype=torch.float32, device=dev)
                 _hip.check(_hip.lib().skr_eval_fused_topk(
                     _hip.ptr(ut), _hip.ptr(du), b, _hip.ptr(it), _hip.ptr(bias), n_items, 64, _hip.ptr(st["tr_ptr"]),
-                    _hip.ptr(st["tr_items"]), K, _hip.ptr(ids), None, _hip.ptr(work), work.numel(), _hip.stream()))
+                    _hip.ptr(st["tr_items"]), K, _hip.ptr(ids), _hip.ptr(top_sc), _hip.ptr(work), work.numel(),
+                    _hip.stream()))
+                self._rerank_tied_rows(st, ut, it, bias, du, ids, top_sc)
                 _hip.check(_hip.lib().skr_rank_metrics(
                     _hip.ptr(ids), b, K, _hip.ptr(du), _hip.ptr(st["te_ptr"]), _hip.ptr(st["te_items"]), margs, nm,
                     _hip.ptr(rows), _hip.ptr(d_sums), _hip.stream()))
@@ -231,6 +261,14 @@ class RankingEvaluator(object):
         sums = d_sums.cpu().numpy()
         rows = np.concatenate(host_rows, axis=0) if keep_rows and host_rows else None
         return rows, sums, n
+
+
+def _tied_rows(top_sc):
+    """indices of the rows whose top-K scores contain equal neighbours (device tensor, host-synchronising)"""
+    import torch
+    if top_sc.shape[1] < 2:
+        return torch.zeros(0, dtype=torch.int64, device=top_sc.device)
+    return torch.nonzero((top_sc[:, 1:] == top_sc[:, :-1]).any(dim=1)).reshape(-1)
 
 
 def _batch_truth(st, d_users):

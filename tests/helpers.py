@@ -37,19 +37,3 @@ def tiny_arrays(golden):
 def lists_from_csr(rowptr, items):
     return [items[rowptr[i]:rowptr[i + 1]] for i in range(len(rowptr) - 1)]
 
-
-def layergcn_tie_adjust(tiny, n_items, n_test):
-    """LayerGCN's output excludes E0 (LayerGCN.py:218), so the zero-degree test user 63 of the tiny dataset
-    gets an all-zero score row: 96 exact ties.  The reference ranks them in libstdc++'s heap order, the HIP
-    path by ascending id (documented deviation).  Returns what to add to the reference's recorded report
-    (5 metrics x top_k (5, 10, 20)) to account for exactly that one row."""
-    import numpy as np
-    from oracle import oracle as O
-    truth63 = [tiny["test"][tiny["test"][:, 0] == 63][:, 1]]
-    zeros = np.zeros((1, n_items), np.float32)
-    heap_rows = O.eval_score_matrix(zeros, truth63, [1, 2, 3, 4, 5], 20)
-    tie = np.full((1, n_items), -1e9, np.float32)
-    tie[0, :20] = np.arange(20, 0, -1)
-    lowid_rows = O.eval_score_matrix(tie, truth63, [1, 2, 3, 4, 5], 20)
-    cols = (np.arange(5)[:, None] * 20 + (np.array([5, 10, 20]) - 1)[None, :]).reshape(-1)
-    return (lowid_rows[0, cols] - heap_rows[0, cols]) / n_test

@@ -37,17 +37,33 @@ def test_eval_scores_vs_oracle(B, I, K):
     assert np.array_equal(rows.view(np.uint32), want.view(np.uint32))
 
 
-def test_eval_scores_tie_rule_and_errors():
-    """exact ties rank by ascending item id (documented deviation from the heap order)"""
+@pytest.mark.parametrize("K,I", [(25, 3000), (1, 77), (10, 15), (128, 5000), (50, 100), (64, 64)])
+def test_eval_scores_ties_follow_the_reference_heap_order(K, I):
+    """equal scores: the ids AND the metric rows are those of the reference's partial_sort_copy
+    (libstdc++ heap order, evaluate.h:39-45) -- quantised scores, all-equal rows, ascending and descending
+    rows (every element enters / none enters the heap), -inf masked prefixes, signed zeros"""
     from gpu_utils import eval_scores
-    from skrec import _hip
+    rng = np.random.default_rng(3 + K)
+    sc = np.round(rng.standard_normal((12, I)).astype(np.float32) * 4) / 4
+    sc[0, :] = 1.0                                        # an all-equal row
+    sc[1, :] = np.arange(I, dtype=np.float32) // 3        # ascending with runs of three
+    sc[2, :] = -(np.arange(I, dtype=np.float32) // 5)     # descending with runs of five
+    sc[3, :] = 0.0
+    sc[3, ::2] = -0.0                                     # signed zeros compare equal
+    sc[4, : I // 2] = -np.inf                             # masked prefix
+    sc[5, :] = rng.integers(0, 3, I)                      # three distinct values only
+    sc[6, :] = rng.standard_normal(I).astype(np.float32)  # tie-free control row
+    truth = [rng.choice(I, size=min(I, 7), replace=False) for _ in range(12)]
+    rows, ids, _ = eval_scores(sc, truth, [1, 2, 3, 4, 5], K)
+    for b in range(12):
+        assert np.array_equal(ids[b], O.topk_ids_heap(sc[b], K)), b
+    assert np.array_equal(rows, O.eval_score_matrix(sc, truth, [1, 2, 3, 4, 5], K))
+
+
+def test_eval_scores_argument_errors():
+    from gpu_utils import eval_scores
     rng = np.random.default_rng(3)
-    sc = np.round(rng.standard_normal((6, 3000)).astype(np.float32) * 4) / 4
-    sc[0, :] = 1.0  # an all-equal row
-    _, ids, _ = eval_scores(sc, [[] for _ in range(6)], [2], 25)
-    for b in range(6):
-        assert np.array_equal(ids[b], O.topk_ids_lowid(sc[b], 25))
-    assert list(ids[0]) == list(range(25))
+    sc = rng.standard_normal((6, 3000)).astype(np.float32)
     with pytest.raises(ValueError):
         eval_scores(sc, [[] for _ in range(6)], [6], 5)        # unknown metric id
     with pytest.raises(ValueError):
@@ -183,3 +199,33 @@ def test_ranking_evaluator_end_to_end(golden):
         assert np.array_equal(got2.view(np.uint32), e[f"e2e_{tag}_sub_values"].view(np.uint32))
     with pytest.raises(AssertionError):
         ev.evaluate(object())
+
+
+def test_fused_evaluator_reranks_structural_ties_in_reference_order():
+    """RankingEvaluator's fused path on factors with structural ties -- cold users (all-zero rows) and
+    duplicated items -- returns the reference's MetricReport: tied rows are re-ranked from their dense score
+    row in libstdc++'s heap order (oracle = the reference's evaluator restated, pinned on its own build)"""
+    import torch
+    from skrec.utils.py import RankingEvaluator
+    rng = np.random.default_rng(8)
+    nU, nI = 150, 400
+    Ut = rng.integers(-2, 3, (nU, 64)).astype(np.float32)      # integer factors: exact scores on every path
+    It = rng.integers(-2, 3, (nI, 64)).astype(np.float32)
+    Ut[::7] = 0.0                                              # cold users
+    It[10:20] = It[30:40]                                      # duplicated items
+    train = {u: np.sort(rng.choice(nI, rng.integers(1, 30), replace=False)) for u in range(nU) if u % 11}
+    test = {u: rng.choice(nI, rng.integers(1, 6), replace=False) for u in range(nU) if u % 5}
+    dU, dI = torch.from_numpy(Ut).cuda(), torch.from_numpy(It).cuda()
+
+    class M(object):
+        def predict_factors(self):
+            return dU, dI, None
+
+        def predict(self, users):
+            return Ut[np.asarray(users)] @ It.T
+
+    ev = RankingEvaluator(train, test, metric=["Precision", "Recall", "MAP", "NDCG", "MRR"], top_k=[5, 10, 20], batch_size=32)
+    got = ev.evaluate(M())
+    _, want, _ = O.ranking_evaluate(M().predict, train, test, metric=["Precision", "Recall", "MAP", "NDCG", "MRR"],
+                                    top_k=[5, 10, 20], batch_size=32)
+    np.testing.assert_allclose(np.array(list(got.values()), np.float32), want, rtol=1e-6, atol=0)   # fp32 mean order

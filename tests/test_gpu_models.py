@@ -119,9 +119,10 @@ def test_layergcn_replays_reference(golden, tiny_dir, monkeypatch, tmp_path):
     reports, losses, best = _fit_and_record(m)
     total = losses[:, 0] + np.float32(1e-2) * losses[:, 1]
     np.testing.assert_allclose(total, g["loss"], rtol=1e-5)
-    from helpers import layergcn_tie_adjust
-    adjust = layergcn_tie_adjust(golden("tiny_dataset"), m.num_items, len(m.evaluator.user_pos_test))
-    _check_reports(reports, g["reports"] + adjust[None, :], g["names"])
+    # LayerGCN's output excludes E0 (LayerGCN.py:218), so the zero-degree test user 63 gets an all-zero score
+    # row: 96 exact ties.  The evaluator re-ranks such rows in the reference's heap order, so the reports
+    # match the reference's without any allowance.
+    _check_reports(reports, g["reports"], g["names"])
     np.testing.assert_allclose(m.user_embeddings.cpu().numpy(), g["U1"], rtol=0, atol=3e-6)
     m.forward()
     np.testing.assert_allclose(m.out[:m.num_users].cpu().numpy(), g["Uf"], rtol=0, atol=6e-6)
