@@ -43,9 +43,6 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
     __shared__ uint64_t s_thr;
     __shared__ int s_rank[SKR_MAX_TOPK];
     __shared__ double s_inv[SKR_MAX_TOPK];
-    __shared__ int s_hid[2 * SKR_MAX_TOPK];
-    __shared__ float s_hval[2 * SKR_MAX_TOPK];
-    __shared__ int s_cand[TK_TILE];
     __shared__ int s_wsum[TK_T / 64];
     __shared__ int s_tie;
     const int tid = threadIdx.x;
@@ -112,6 +109,12 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
         // elements above the heap's current top (a superset of those that will enter: the top only rises),
         // compact them in index order, then one lane feeds them to the heap.
         const int sort_len = 2 * top_k < n_items ? 2 * top_k : n_items;   // evaluate.h:39
+        // the key buffer is free from here on: its 16 KB hold the heap and the per-tile candidate list, so that
+        // the tie path costs the common (tie-free) case no LDS and no occupancy
+        int* s_hid = reinterpret_cast<int*>(keys);
+        float* s_hval = reinterpret_cast<float*>(s_hid + 2 * SKR_MAX_TOPK);
+        int* s_cand = s_hid + 4 * SKR_MAX_TOPK;
+        static_assert((4 * SKR_MAX_TOPK + TK_TILE) * 4 <= TK_CAP * 8, "tie-path scratch must fit the key buffer");
         skr::RefHeap h{s_hid, s_hval, sort_len};
         for (int i = tid; i < sort_len; i += TK_T) {
             s_hid[i] = i;
