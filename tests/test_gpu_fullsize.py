@@ -47,8 +47,9 @@ def test_exact_epoch_full_size(big):
     assert float(hist.std() / hist.mean()) < 0.1
 
 
-def test_fused_eval_full_size_against_independent_path(big):
-    """fused MFMA top-K over all 1 M users vs the dense path (skr_score_matrix -> skr_mask_train ->
+@pytest.mark.parametrize("K,n_eval", [(10, 1_000_000), (100, 262_144)])
+def test_fused_eval_full_size_against_independent_path(big, K, n_eval):
+    """fused MFMA top-K over 1 M users (top-10) / 262 144 users (top-100) vs the dense path (skr_score_matrix -> skr_mask_train ->
     skr_eval_scores) on a random sample of users: same ids except where fp32 summation order flips a
     near-tie; every fused list is sorted, masked and duplicate-free; metric sums add up."""
     import torch
@@ -59,16 +60,16 @@ def test_fused_eval_full_size_against_independent_path(big):
     Ut = torch.randn(U, 64, generator=g, device=dev) * 0.1
     Vt = torch.randn(I, 64, generator=g, device=dev) * 0.1
     bias = torch.randn(I, generator=g, device=dev) * 0.05
-    K = 10
+    nu = n_eval                     # the first n_eval users of the data set
     rowptr, items = big["rowptr"], big["items"]
-    users = torch.arange(U, dtype=torch.int32, device=dev)
-    ids = torch.empty((U, K), dtype=torch.int32, device=dev)
-    sc = torch.empty((U, K), dtype=torch.float32, device=dev)
+    users = torch.arange(nu, dtype=torch.int32, device=dev)
+    ids = torch.empty((nu, K), dtype=torch.int32, device=dev)
+    sc = torch.empty((nu, K), dtype=torch.float32, device=dev)
     chunk = 1 << 18
     ws = int(L.skr_eval_fused_workspace(chunk, K))
     work = torch.empty(ws, dtype=torch.uint8, device=dev)
-    for s in range(0, U, chunk):
-        b = min(chunk, U - s)
+    for s in range(0, nu, chunk):
+        b = min(chunk, nu - s)
         _hip.check(L.skr_eval_fused_topk(_hip.ptr(Ut), _hip.ptr(users[s:s + b]), b, _hip.ptr(Vt), _hip.ptr(bias), I, 64,
                                          _hip.ptr(rowptr), _hip.ptr(items), K, _hip.ptr(ids[s:s + b]), _hip.ptr(sc[s:s + b]),
                                          _hip.ptr(work), ws, _hip.stream()))
@@ -82,7 +83,7 @@ def test_fused_eval_full_size_against_independent_path(big):
     idx = torch.searchsorted(key_pos, key_top).clamp(max=len(key_pos) - 1)
     assert not bool((key_pos[idx] == key_top).any())                         # train items never ranked
     # independent dense path on a sample
-    sample = torch.randperm(U, generator=g, device=dev)[:2048].int().contiguous()
+    sample = torch.randperm(nu, generator=g, device=dev)[:2048].int().contiguous()
     dense = _hip.score_matrix(Ut, sample.cpu().numpy(), Vt, bias)
     _hip.check(L.skr_mask_train(_hip.ptr(dense), 2048, I, I, _hip.ptr(sample), _hip.ptr(rowptr), _hip.ptr(items), _hip.stream()))
     ids2 = torch.empty((2048, K), dtype=torch.int32, device=dev)
@@ -90,18 +91,18 @@ def test_fused_eval_full_size_against_independent_path(big):
     torch.cuda.synchronize()
     a, b2 = ids[sample.long()].cpu().numpy(), ids2.cpu().numpy()
     agree = (a == b2).all(1)
-    assert agree.mean() > 0.97
+    assert agree.mean() > (0.97 if K <= 10 else 0.5)     # with 100 ranks some neighbouring pair is within fp32 noise more often
     sa, sb = sc[sample.long()].cpu().numpy(), np.take_along_axis(dense.cpu().numpy(), b2.astype(np.int64), 1)
     np.testing.assert_allclose(sa, sb, rtol=2e-5, atol=2e-6)                 # even where ids swap, scores tie
     for r in np.flatnonzero(~agree):
         assert set(a[r]) == set(b2[r]) or abs(sa[r, -1] - sb[r, -1]) < 2e-6
     # metrics: HR@10 from the fused lists == HR computed on the host from the same lists
-    test_ptr = torch.arange(U + 1, dtype=torch.long, device=dev)
-    rows = torch.empty((U, 2 * K), dtype=torch.float32, device=dev)
+    test_ptr = torch.arange(nu + 1, dtype=torch.long, device=dev)
+    rows = torch.empty((nu, 2 * K), dtype=torch.float32, device=dev)
     sums = torch.zeros(2 * K, dtype=torch.float64, device=dev)
-    _hip.check(L.skr_rank_metrics(_hip.ptr(ids), U, K, _hip.ptr(users), _hip.ptr(test_ptr), _hip.ptr(big["test_item"]),
+    _hip.check(L.skr_rank_metrics(_hip.ptr(ids), nu, K, _hip.ptr(users), _hip.ptr(test_ptr), _hip.ptr(big["test_item"]),
                                   _hip.metric_array([2, 4]), 2, _hip.ptr(rows), _hip.ptr(sums), _hip.stream()))
     torch.cuda.synchronize()
-    hit = (ids == big["test_item"][:, None]).any(1).double().sum()
+    hit = (ids == big["test_item"][:nu, None]).any(1).double().sum()
     assert abs(float(sums[K - 1]) - float(hit)) < 0.5                        # Recall@10 == HR@10 on leave-one-out
     np.testing.assert_allclose(sums.cpu().numpy(), rows.double().sum(0).cpu().numpy(), rtol=1e-9)
