@@ -164,8 +164,10 @@ class RankingEvaluator(object):
         assert hasattr(model, "predict"), "the model must have attribute 'predict'."
         if test_users is not None:
             test_users = [u for u in test_users if u in self.user_pos_test]
-        else:
-            test_users = list(self.user_pos_test.keys())
+        else:   # all test users, in the dict's order; the int32 array is built once (1 M keys cost ~0.1 s per call)
+            if getattr(self, "_all_test_users", None) is None:
+                self._all_test_users = np.fromiter(self.user_pos_test.keys(), dtype=np.int32, count=len(self.user_pos_test))
+            test_users = self._all_test_users
         assert isinstance(test_users, Iterable), "'test_user' must be iterable."
         rows, sums, n = self.per_user_rows(model, test_users)
         if rows is not None:
@@ -207,7 +209,8 @@ class RankingEvaluator(object):
         import torch
         st = self._device_state()
         dev, K, nm = st["dev"], self.max_top, self.metrics_num
-        users = np.asarray(list(test_users), dtype=np.int32)
+        users = test_users if isinstance(test_users, np.ndarray) and test_users.dtype == np.int32 \
+            else np.asarray(list(test_users), dtype=np.int32)
         n = len(users)
         d_sums = torch.zeros(nm * K, dtype=torch.float64, device=dev)
         keep_rows = n <= _HOST_MEAN_MAX
