@@ -25,6 +25,7 @@
 #include "eval_common.h"
 
 #include <cstdlib>
+#include <string>
 
 namespace {
 
@@ -105,7 +106,8 @@ struct WaveCtx {
     uint64_t* my_cand;   // HBM: the wave's 64 candidate lists
     int64_t* row_beg;    // LDS: start of each user's train row
     int* row_len;        // LDS: its length (0 when no train mask was given)
-    int* rowbuf;         // LDS: FE_ROWBUF ints of scratch for one staged row
+    int* rowbuf;         // LDS: scratch for one staged row
+    int rowbuf_len;      // its capacity in ints (a multiple of 64, at most FE_ROWBUF)
 };
 
 // Drop the user's train items from the NR keys each lane holds: NR binary searches per lane advance in
@@ -123,13 +125,13 @@ __device__ __forceinline__ void mask_train_lockstep(const FusedArgs& a, const Wa
         v[e] = skr::key_id(k[e]);
     }
     const int steps = 32 - __clz(len);
-    if (len <= FE_ROWBUF) {
+    if (len <= w.rowbuf_len) {
         // one coalesced read of the row into LDS, then the searches run at LDS latency
         int* __restrict__ buf = w.rowbuf;
 #pragma unroll
         for (int e = 0; e < FE_ROWBUF / 64; ++e) {
             const int idx = e * 64 + w.lane;
-            if (idx < len) buf[idx] = row[idx];
+            if (idx < len) buf[idx] = row[idx];   // len <= rowbuf_len bounds the writes
         }
         __threadfence_block();   // the wave's own LDS writes, ordered before its reads
         for (int s = 0; s < steps; ++s) {
@@ -451,6 +453,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v3(FusedAr
     w.row_beg = s_row_beg[wv];
     w.row_len = s_row_len[wv];
     w.rowbuf = s_rowbuf[wv];
+    w.rowbuf_len = FE_ROWBUF;
     {   // lane l caches the train-row extent of the wave's l-th user
         const int64_t row = w.ubase + lane;
         int64_t rb = 0;
@@ -621,6 +624,328 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v3(FusedAr
     }
 }
 
+// ================================================================================================
+// bf16x3 sweep (the default; SKR_FUSED_MODE=fp32 selects the kernel above): the same sweep with every fp32 operand split into three
+// bf16 pieces x = hi + mid + lo (exact: 3 x 8 significand bits) and the product formed from the six piece
+// products of weight >= 2^-16 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped mid*lo, lo*mid,
+// lo*lo are <= 2^-23 relative) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Six bf16 MFMAs of
+// 16x the fp32 MFMA rate replace one fp32 MFMA chain: 2.7x less matrix-pipe time per tile at fp32-level
+// accuracy (products are exact in fp32; the error is the dropped terms plus fp32 accumulation).  Measured
+// against float64 (tools/fused_accuracy.py, error / sum|u_i v_i| over the returned top-50 scores of 512 users x
+// 20 000 items, factor scales 1e-3 .. 30): max 2.9e-7 / mean 3.8e-8, the FP32-MFMA kernel: max 3.5e-7 / mean
+// 5.1e-8 -- the split form rounds 24 times per dot product (once per MFMA), the fp32 chain 64 times.
+//   * split_items_kernel writes the item table once per call in FRAGMENT order: tile (32 items) x chunk
+//     (16 dims) x piece -> 1 KB blocks in which lane l's 16 bytes are the 8 bf16 the MFMA wants from it
+//     (A[row l&31][k = 8 (l>>5) + j]), so LDS-DMA copies blocks verbatim and ds_read_b128 at lane*16 is
+//     conflict-free without a swizzle;
+//   * the user fragments are split in registers at kernel start (96 VGPRs);
+//   * one 12 KB LDS buffer per wave: the 12 A fragments of a tile are read into registers at the top of the
+//     step, after which the buffer is free and the next tile's DMA is issued behind the MFMAs.
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t bf16_rne(float x) {   // round-to-nearest-even on the bits (finite input)
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = bf16_rne(x);
+    const float r1 = x - __uint_as_float(hi << 16);
+    mid = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(mid << 16);
+    lo = bf16_rne(r2);
+}
+// eight consecutive floats -> three uint4 of packed bf16 (element j in bits [16 (j&1), +16) of word j>>1)
+__device__ __forceinline__ void split3x8(const float* v, uint4& hi, uint4& mid, uint4& lo) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    mid = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+constexpr int F4_FRAGS = 12;                 // 4 chunks of 16 dims x 3 pieces
+constexpr int F4_TILE_U4 = F4_FRAGS * 64;    // uint4 per tile (12 KB): fragments q*3+p, i.e. two 6 KB halves
+
+__global__ __launch_bounds__(256) void split_items_kernel(const float* __restrict__ table, int n_items, int n_tiles,
+                                                          uint4* __restrict__ frags) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;   // (tile, chunk, lane)
+    if (g >= static_cast<int64_t>(n_tiles) * 4 * 64) return;
+    const int lane = static_cast<int>(g & 63), q = static_cast<int>((g >> 6) & 3);
+    const int64_t T = g >> 8;
+    int64_t item = T * FE_TI + (lane & 31);
+    if (item >= n_items) item = n_items - 1;
+    const float4* src = reinterpret_cast<const float4*>(table + item * FE_D + q * 16 + 8 * (lane >> 5));
+    const float4 v0 = src[0], v1 = src[1];
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    uint4 hi, mid, lo;
+    split3x8(v, hi, mid, lo);
+    uint4* dst = frags + T * F4_TILE_U4 + (q * 3) * 64 + lane;
+    dst[0] = hi;
+    dst[64] = mid;
+    dst[128] = lo;
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const uint4& u) {
+    union { uint4 u; bf16x8 b; } c;
+    c.u = u;
+    return c.b;
+}
+#define F4_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A), as_bf16x8(B), C, 0, 0, 0)
+
+// Candidate path of the bf16x3 sweep.  With the matrix work 2.7x shorter the fp32 kernel's append path (LDS
+// atomics, a 16-iteration predicated store loop per fragment) would dominate, so here the list lengths of a
+// wave's 64 users live in REGISTERS (replicated in lanes c and c+32, which hold the two row halves of user c),
+// a lane walks only its own passing rows, and LDS / the compaction code are involved only when a list
+// actually crosses the trigger.
+struct CandRegs {
+    int cnt[2];
+};
+
+__device__ __forceinline__ float select16(const f32x16& v, int r) {
+    const float a0 = (r & 1) ? v[1] : v[0], a1 = (r & 1) ? v[3] : v[2], a2 = (r & 1) ? v[5] : v[4], a3 = (r & 1) ? v[7] : v[6];
+    const float a4 = (r & 1) ? v[9] : v[8], a5 = (r & 1) ? v[11] : v[10], a6 = (r & 1) ? v[13] : v[12], a7 = (r & 1) ? v[15] : v[14];
+    const float b0 = (r & 2) ? a1 : a0, b1 = (r & 2) ? a3 : a2, b2 = (r & 2) ? a5 : a4, b3 = (r & 2) ? a7 : a6;
+    const float c0 = (r & 4) ? b1 : b0, c1 = (r & 4) ? b3 : b2;
+    return (r & 8) ? c1 : c0;
+}
+
+__device__ __forceinline__ void cand_sync_to_lds(const WaveCtx& w, const CandRegs& cr) {
+    if (w.h == 0) {
+        w.cnt[w.c] = cr.cnt[0];
+        w.cnt[32 + w.c] = cr.cnt[1];
+    }
+    __threadfence_block();
+}
+
+__device__ __forceinline__ void tile_candidates_v4(const FusedArgs& a, const WaveCtx& w, const f32x16& acc0,
+                                                   const f32x16& acc1, int tile_base, float (&thr)[2], CandRegs& cr) {
+    // m = 2*m + (score > threshold), rows 15..0: one compare and one add-with-carry per row
+    uint32_t m0, m1;
+    // Row 15 in plain C: hipcc's hazard recogniser then inserts the wait states an MFMA result needs before a
+    // VALU may read it (it does not look inside inline asm; without this the asm below read accumulators that
+    // the last MFMAs had not written yet).  Rows 14..1 in asm, two rows of both fragments interleaved so that
+    // every carry consumer sits three instructions behind its producer (VALU write of VCC / an SGPR pair ->
+    // VALU carry-in needs two wait states; hipcc puts `s_nop 1` there), row 0 in C again.
+    m0 = (acc0[15] > thr[0]) ? 1u : 0u;
+    m1 = (acc1[15] > thr[1]) ? 1u : 0u;
+#pragma unroll
+    for (int r = 14; r >= 2; r -= 2) {
+        uint64_t c1, c2, c3;
+        asm volatile("v_cmp_gt_f32 vcc, %5, %6\n\t"
+                     "v_cmp_gt_f32 %2, %7, %8\n\t"
+                     "v_cmp_gt_f32 %3, %9, %6\n\t"
+                     "v_cmp_gt_f32 %4, %10, %8\n\t"
+                     "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                     "v_addc_co_u32 %1, %2, %1, %1, %2\n\t"
+                     "v_addc_co_u32 %0, %3, %0, %0, %3\n\t"
+                     "v_addc_co_u32 %1, %4, %1, %1, %4"
+                     : "+v"(m0), "+v"(m1), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+                     : "v"(acc0[r]), "v"(thr[0]), "v"(acc1[r]), "v"(thr[1]), "v"(acc0[r - 1]), "v"(acc1[r - 1])
+                     : "vcc");
+    }
+    m0 = 2u * m0 + ((acc0[0] > thr[0]) ? 1u : 0u);
+    m1 = 2u * m1 + ((acc1[0] > thr[1]) ? 1u : 0u);
+    if (tile_base + FE_TI > a.n_items) {   // only the last, partial tile has rows that are not items
+        uint32_t valid = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (tile_base + (r & 3) + 8 * (r >> 2) + 4 * w.h < a.n_items) valid |= 1u << r;
+        m0 &= valid;
+        m1 &= valid;
+    }
+    if (!__any((m0 | m1) != 0u)) return;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        uint32_t mm = f ? m1 : m0;
+        const f32x16& acc = f ? acc1 : acc0;
+        const int n = __popc(mm);
+        const int other = __shfl_xor(n, 32, 64);
+        uint64_t* list = w.my_cand + static_cast<int64_t>(32 * f + w.c) * a.cap + cr.cnt[f] + (w.h ? other : 0);
+        cr.cnt[f] += n + other;          // <= trigger + 32 <= cap by the compaction rule
+        while (mm) {
+            const int r = __ffs(static_cast<int>(mm)) - 1;
+            mm &= mm - 1;
+            *list++ = skr::rank_key(select16(acc, r), tile_base + (r & 3) + 8 * (r >> 2) + 4 * w.h);
+        }
+    }
+    uint64_t need = (__ballot(cr.cnt[0] > a.trigger) & 0xffffffffull) | (__ballot(cr.cnt[1] > a.trigger) << 32);
+    if (need) {
+        cand_sync_to_lds(w, cr);
+        while (need) {
+            const int ul = __ffsll(static_cast<long long>(need)) - 1;
+            need &= need - 1;
+            const float nt = compact_user(a, w, ul, -1);
+            if (w.c == (ul & 31)) {
+                if (ul >> 5) thr[1] = nt; else thr[0] = nt;
+            }
+        }
+        cr.cnt[0] = w.cnt[w.c];
+        cr.cnt[1] = w.cnt[32 + w.c];
+        // A wait the COMPILER can see: without it hipcc's waitcnt pass carries the compaction's loads as
+        // "possibly outstanding" around the loop and puts an s_waitcnt vmcnt(0) in front of the first MFMA of
+        // every tile, which also drains the hand-issued LDS-DMA ring (measured: +2.5 ms per 262 144 users).
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), gfx9 encoding
+    }
+}
+
+constexpr int F4_HALF_U4 = 6 * 64;      // uint4 per half tile (two 16-dim chunks x 3 pieces = 6 KB)
+constexpr int F4_RING = 3;              // half tiles resident per wave (18 KB)
+constexpr int F4_ROWBUF = 128;
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v4(FusedArgs a, const uint4* __restrict__ frags) {
+    __shared__ uint4 s_tile[FE_WAVES][F4_RING * F4_HALF_U4];   // wave-private ring of three half tiles
+    __shared__ float4 s_bias[FE_WAVES][2][16];                 // the bias DMA writes 4 B for each of the 64 lanes
+    __shared__ int s_cnt[FE_WAVES][FE_UW];
+    __shared__ int64_t s_row_beg[FE_WAVES][FE_UW];
+    __shared__ int s_row_len[FE_WAVES][FE_UW];
+    __shared__ int s_rowbuf[FE_WAVES][F4_ROWBUF];
+    WaveCtx w;
+    w.lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    w.c = w.lane & 31;
+    w.h = w.lane >> 5;
+    const int lane = w.lane, c = w.c, h = w.h;
+    w.ubase = (static_cast<int64_t>(blockIdx.x) * FE_WAVES + wv) * FE_UW;
+    if (w.ubase >= a.B) return;
+    w.cnt = s_cnt[wv];
+    w.cnt[lane] = 0;
+    w.my_cand = a.cand + w.ubase * a.cap;
+    w.row_beg = s_row_beg[wv];
+    w.row_len = s_row_len[wv];
+    w.rowbuf = s_rowbuf[wv];
+    w.rowbuf_len = F4_ROWBUF;
+    {
+        const int64_t row = w.ubase + lane;
+        int64_t rb = 0;
+        int len = 0;
+        if (a.train_rowptr && row < a.B) {
+            const int u = a.users[row];
+            rb = a.train_rowptr[u];
+            len = static_cast<int>(a.train_rowptr[u + 1] - rb);
+        }
+        w.row_beg[lane] = rb;
+        w.row_len[lane] = len;
+    }
+    // user fragments: B[k = 8h + j][col c] of chunk q, three pieces each
+    uint4 bh[2][4], bm[2][4], bl[2][4];
+    float thr[2];
+    int uid[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int64_t row = w.ubase + 32 * f + c;
+        const bool ok = row < a.B;
+        uid[f] = a.users[ok ? row : (a.B - 1)];
+        thr[f] = (ok && a.ablate != 1 && a.ablate != 7) ? -INFINITY : INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid[f]) * FE_D + q * 16 + 8 * h);
+            const float4 v0 = up[0], v1 = up[1];
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            split3x8(v, bh[f][q], bm[f][q], bl[f][q]);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // retire the loads here (see the fp32 kernel: hidden DMA vs counted vmcnt)
+            asm volatile("" : "+v"(bh[f][q].x), "+v"(bh[f][q].y), "+v"(bh[f][q].z), "+v"(bh[f][q].w));
+            asm volatile("" : "+v"(bm[f][q].x), "+v"(bm[f][q].y), "+v"(bm[f][q].z), "+v"(bm[f][q].w));
+            asm volatile("" : "+v"(bl[f][q].x), "+v"(bl[f][q].y), "+v"(bl[f][q].z), "+v"(bl[f][q].w));
+        }
+    const int n_tiles = (a.n_items + FE_TI - 1) / FE_TI;
+    const int n_half = 2 * n_tiles;
+    const uint32_t lt = lds_addr_of(&s_tile[wv][0]);
+    const uint32_t lb0 = lds_addr_of(&s_bias[wv][0][0]), lb1 = lds_addr_of(&s_bias[wv][1][0]);
+    // half tile `hs` (tile hs>>1, chunks 2*(hs&1) and 2*(hs&1)+1) -> ring slot `slot`; with the first half of a
+    // tile travels its bias row.  7 (6) DMA instructions per even (odd) half with a bias, 6 without.
+    const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+    auto issue_half = [&](int hs, int slot) {
+        const char* sbase = reinterpret_cast<const char*>(frags) + static_cast<int64_t>(hs) * (F4_HALF_U4 * 16);   // wave-uniform
+        const uint32_t dst = lt + slot * (F4_HALF_U4 * 16);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) glds_b128_s(lane16, sbase + i * 1024, dst + i * 1024);
+        if (HAS_BIAS && !(hs & 1)) {
+            int bi = (hs >> 1) * FE_TI + (lane & 31);
+            bi = bi < a.n_items ? bi : a.n_items - 1;
+            glds_b32(a.item_bias + bi, ((hs >> 1) & 1) ? lb1 : lb0);
+        }
+    };
+    issue_half(0, 0);
+    issue_half(1, 1);                               // n_half >= 2 always
+    if (n_half > 2) issue_half(2, 2);
+    FE2_WAIT();
+    uint4 afA[6], afB[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) afA[i] = s_tile[wv][i * 64 + lane];
+    f32x16 acc0, acc1;
+    CandRegs cr{{0, 0}};
+    int slot = 0;                                   // ring slot of the half held in afA at an even step
+    // one step = one half tile.  At its start the fragments of half hs are in registers, so its ring slot
+    // is free: the DMA of half hs+3 goes there, then the fragments of half hs+1 are fetched (its DMA was
+    // issued two steps ago: a counted wait leaves the two younger DMAs in flight) while the 24 MFMAs run.
+#define F4_STEP(CUR, NXT, HS, EVEN)                                                                           \
+    {                                                                                                         \
+        const int hs_ = (HS);                                                                                 \
+        /* pinned: left to itself hipcc hoists this wait above the previous step's MFMAs (an asm volatile is  \
+           only ordered against memory operations), i.e. right behind the reads it waits for */               \
+        FE3_PIN();                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* CUR has landed in registers */                \
+        FE3_PIN();                                                                                            \
+        const bool more3_ = hs_ + 3 < n_half && a.ablate != 7;                                                \
+        if (more3_) issue_half(a.ablate == 8 ? ((hs_ + 3) & 31) : hs_ + 3, slot);                             \
+        const int nslot_ = slot == 2 ? 0 : slot + 1;                                                          \
+        if (hs_ + 1 < n_half) {                                                                               \
+            /* younger DMAs: half hs+2 (if it exists) and half hs+3 (if just issued) */                       \
+            if (hs_ + 2 >= n_half) FE2_WAIT();                                                                \
+            else if (!more3_) { if (HAS_BIAS && (EVEN)) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");      \
+                                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }                       \
+            else if (HAS_BIAS) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");                              \
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                            \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i) NXT[i] = s_tile[wv][nslot_ * F4_HALF_U4 + i * 64 + lane]; \
+        }                                                                                                     \
+        FE3_PIN();                                                                                            \
+        if (EVEN) {                                                                                           \
+            if (HAS_BIAS) {                                                                                   \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
+                    const float4 b4 = s_bias[wv][(hs_ >> 1) & 1][2 * g + h];                                  \
+                    acc0[4 * g + 0] = b4.x; acc0[4 * g + 1] = b4.y; acc0[4 * g + 2] = b4.z; acc0[4 * g + 3] = b4.w; \
+                }                                                                                             \
+            } else {                                                                                          \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;                                \
+            }                                                                                                 \
+            acc1 = acc0;                                                                                      \
+        }                                                                                                     \
+        _Pragma("unroll") for (int qq = 0; qq < 2; ++qq) {   /* small terms first */                          \
+            const int q = ((EVEN) ? 0 : 2) + qq;                                                              \
+            const uint4 &ah = CUR[3 * qq], &am = CUR[3 * qq + 1], &al = CUR[3 * qq + 2];                      \
+            acc0 = F4_MFMA(al, bh[0][q], acc0);  acc1 = F4_MFMA(al, bh[1][q], acc1);                          \
+            acc0 = F4_MFMA(ah, bl[0][q], acc0);  acc1 = F4_MFMA(ah, bl[1][q], acc1);                          \
+            acc0 = F4_MFMA(am, bm[0][q], acc0);  acc1 = F4_MFMA(am, bm[1][q], acc1);                          \
+            acc0 = F4_MFMA(am, bh[0][q], acc0);  acc1 = F4_MFMA(am, bh[1][q], acc1);                          \
+            acc0 = F4_MFMA(ah, bm[0][q], acc0);  acc1 = F4_MFMA(ah, bm[1][q], acc1);                          \
+            acc0 = F4_MFMA(ah, bh[0][q], acc0);  acc1 = F4_MFMA(ah, bh[1][q], acc1);                          \
+        }                                                                                                     \
+        if (!(EVEN)) {                                                                                        \
+            tile_candidates_v4(a, w, acc0, acc1, (hs_ >> 1) * FE_TI, thr, cr);                                \
+        }                                                                                                     \
+        slot = nslot_;                                                                                        \
+    }
+    for (int t = 0; t < n_tiles; ++t) {
+        F4_STEP(afA, afB, 2 * t, true)
+        F4_STEP(afB, afA, 2 * t + 1, false)
+    }
+#undef F4_STEP
+    cand_sync_to_lds(w, cr);
+    for (int ul = 0; ul < FE_UW; ++ul) {
+        const int64_t row = w.ubase + ul;
+        if (row >= a.B) break;
+        compact_user(a, w, ul, row);
+    }
+}
+
 // list capacity per user.  Measured on MI355X (K = 10..100, 262 144 users): 512-entry lists with a
 // trigger of 480 were no faster than 256 / 224 once the mid-sweep compaction selects instead of sorting
 // (profiles/r01_eval_history.txt), so the smaller scratch footprint stays.
@@ -668,6 +993,39 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     const int64_t waves = (static_cast<int64_t>(B) + FE_UW - 1) / FE_UW;
     const unsigned blocks = static_cast<unsigned>((waves + FE_WAVES - 1) / FE_WAVES);
     hipStream_t st = skr::as_stream(stream);
+    // arithmetic mode, read per call: "bf16x3" (default) or "fp32" (the FP32-MFMA kernel)
+    const char* mode_env = getenv("SKR_FUSED_MODE");
+    const bool mode_bf16x3 = !(mode_env && std::string(mode_env) == "fp32");
+    SKR_REQUIRE(!mode_env || std::string(mode_env) == "fp32" || std::string(mode_env) == "bf16x3",
+                "SKR_FUSED_MODE must be 'bf16x3' or 'fp32' (got '%s')", mode_env);
+    if (mode_bf16x3) {
+        // library-owned scratch for the split item table (38 MB at 100 k items), grown on demand
+        static uint4* frag_buf = nullptr;
+        static size_t frag_cap = 0;
+        const int n_tiles = (n_items + FE_TI - 1) / FE_TI;
+        const size_t need = static_cast<size_t>(n_tiles) * F4_TILE_U4 * sizeof(uint4);
+        if (need > frag_cap) {
+            if (frag_buf) {
+                SKR_HIP(hipStreamSynchronize(st));
+                SKR_HIP(hipFree(frag_buf));
+            }
+            frag_buf = nullptr;
+            frag_cap = 0;
+            SKR_HIP(hipMalloc(&frag_buf, need));
+            frag_cap = need;
+        }
+        const int64_t nthr = static_cast<int64_t>(n_tiles) * 256;
+        hipLaunchKernelGGL(split_items_kernel, dim3(static_cast<unsigned>((nthr + 255) / 256)), dim3(256), 0, st, d_item_table,
+                           n_items, n_tiles, frag_buf);
+        SKR_LAUNCH_CHECK();
+        static const unsigned dyn_lds = [] { const char* e = getenv("SKR_FUSED_DYN_LDS"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();   // occupancy experiments
+        if (d_item_bias)
+            hipLaunchKernelGGL(fused_topk_kernel_v4<true>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
+        else
+            hipLaunchKernelGGL(fused_topk_kernel_v4<false>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
+        SKR_LAUNCH_CHECK();
+        return SKR_OK;
+    }
     if (d_item_bias)
         hipLaunchKernelGGL(fused_topk_kernel_v3<true>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a);
     else

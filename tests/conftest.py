@@ -37,3 +37,10 @@ def tiny_dir(tmp_path, golden):
             for u, i, t in rows:
                 f.write(f"{int(u)}\t{int(i)}\t1.0\t{int(t)}\n")
     return str(root)
+
+
+@pytest.fixture(params=["bf16x3", "fp32"])
+def fused_mode(request, monkeypatch):
+    """both arithmetic modes of skr_eval_fused_topk (read per call from SKR_FUSED_MODE)"""
+    monkeypatch.setenv("SKR_FUSED_MODE", request.param)
+    return request.param

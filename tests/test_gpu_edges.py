@@ -14,7 +14,7 @@ from helpers import random_csr
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 
 
-def test_fused_tiny_catalogues_and_duplicate_users():
+def test_fused_tiny_catalogues_and_duplicate_users(fused_mode):
     from gpu_utils import fused_topk
     rng = np.random.default_rng(0)
     for I, K, B in ((10, 10, 3), (31, 7, 70), (64, 64, 5), (65, 1, 129), (97, 33, 64)):

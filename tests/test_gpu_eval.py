@@ -117,7 +117,7 @@ NOISE = 2e-5  # >> 64 * 2^-24 * sum|a*b| for the factor scales used here
                                                        (65, 1000, 20, True, True), (200, 5000, 50, True, False),
                                                        (130, 33, 3, False, True), (300, 20011, 128, True, True),
                                                        (1000, 3000, 10, False, True)])
-def test_fused_topk_vs_fp64(B, I, K, with_bias, with_mask):
+def test_fused_topk_vs_fp64(B, I, K, with_bias, with_mask, fused_mode):
     from gpu_utils import fused_topk
     rng = np.random.default_rng(B + I + K)
     nU = B + 17
@@ -151,7 +151,7 @@ def test_fused_topk_vs_fp64(B, I, K, with_bias, with_mask):
 
 
 @pytest.mark.parametrize("B,I,K", [(96, 777, 12), (70, 6000, 100), (130, 3000, 64), (65, 9000, 128)])
-def test_fused_exact_on_integer_scores(B, I, K):
+def test_fused_exact_on_integer_scores(B, I, K, fused_mode):
     """integer-valued factors make every fp32 dot product exact, so ids AND scores must match the
     oracle's ranking bit for bit, ties included (lower id first) -- with thousands of items and a few
     dozen distinct scores the K-th place is almost always inside a run of equal scores, which is what the
@@ -201,7 +201,7 @@ def test_ranking_evaluator_end_to_end(golden):
         ev.evaluate(object())
 
 
-def test_fused_evaluator_reranks_structural_ties_in_reference_order():
+def test_fused_evaluator_reranks_structural_ties_in_reference_order(fused_mode):
     """RankingEvaluator's fused path on factors with structural ties -- cold users (all-zero rows) and
     duplicated items -- returns the reference's MetricReport: tied rows are re-ranked from their dense score
     row in libstdc++'s heap order (oracle = the reference's evaluator restated, pinned on its own build)"""

@@ -48,7 +48,7 @@ def test_exact_epoch_full_size(big):
 
 
 @pytest.mark.parametrize("K,n_eval", [(10, 1_000_000), (100, 262_144)])
-def test_fused_eval_full_size_against_independent_path(big, K, n_eval):
+def test_fused_eval_full_size_against_independent_path(big, K, n_eval, fused_mode):
     """fused MFMA top-K over 1 M users (top-10) / 262 144 users (top-100) vs the dense path (skr_score_matrix -> skr_mask_train ->
     skr_eval_scores) on a random sample of users: same ids except where fp32 summation order flips a
     near-tie; every fused list is sorted, masked and duplicate-free; metric sums add up."""
