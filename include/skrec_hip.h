@@ -148,6 +148,10 @@ int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
  *   d_train_rowptr/d_train_items  CSR over ALL users, items sorted ascending (may be NULL: no mask)
  *   d_topk_ids int32[B, top_k], d_topk_scores float[B, top_k] (may be NULL)
  *   d_work / work_bytes   scratch from skr_eval_fused_workspace(B, top_k)
+ * Arithmetic (environment SKR_FUSED_MODE, read per call): "bf16x3" (default) forms every fp32 product from six
+ * bf16 x bf16 MFMA products of the exactly split operands with fp32 accumulation -- measured error vs float64
+ * below the plain chain's -- and keeps a library-owned device buffer of n_items*64*6 bytes for the split item
+ * table; "fp32" runs exact fp32 FMA chains on the FP32 MFMA.
  * Requires n_items - max train row length >= top_k (else SKR_EINVAL: use skr_eval_scores). */
 size_t skr_eval_fused_workspace(int B, int top_k);
 int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B,

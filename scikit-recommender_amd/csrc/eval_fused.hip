@@ -1,4 +1,6 @@
-// eval_fused.hip -- K4: user x item scoring on FP32 MFMA fused with train masking and top-K.
+// eval_fused.hip -- K4: user x item scoring on the matrix cores fused with train masking and top-K.
+// Two arithmetic modes: exact fp32 FMA chains on the FP32 MFMA (described first), and the default bf16x3
+// split on the bf16 MFMA (second half of the file).
 //
 // Replaces, in one launch and without ever writing the [B, I] score matrix to HBM:
 //   recommender/BPRMF.py:84-88 / LightGCN.py:102-107   U[b] @ V.T (+ bias)         (torch.matmul)
