@@ -34,7 +34,8 @@ for name in ("fetch", "write"):
         agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     pmc[name] = agg
 summary = {"tag": tag, "command": "python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline", "kernels": {}}
-for k in ("adam_kernel<true, 4, true>", "fused_topk_kernel_v3<true>", "bpr_step_kernel", "exact_assign_kernel",
+for k in ("adam_kernel<true, 4, true>", "fused_topk_kernel_v4<true>", "fused_topk_kernel_v3<true>", "split_items_kernel",
+          "bpr_step_kernel", "exact_assign_kernel<false>",
           "mt_generate_kernel"):
     if k not in stats:
         continue
@@ -48,7 +49,8 @@ for k in ("adam_kernel<true, 4, true>", "fused_topk_kernel_v3<true>", "bpr_step_
                    note="FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read stream)")
     summary["kernels"][k] = ent
 
-# 3. eval kernel PMC (MFMA utilisation, clock)
+# 3. eval kernel PMC (MFMA utilisation, clock): the largest launch of each fused kernel (v4 = bf16x3, the default;
+#    v3 = FP32 MFMA, run by bench.py for comparison)
 p = f"{src}/evalpmc_counter_collection.csv"
 if os.path.exists(p):
     agg = collections.defaultdict(dict)
@@ -58,11 +60,16 @@ if os.path.exists(p):
             d[r["Counter_Name"]] = float(r["Counter_Value"])
             d["dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             d["grid_threads"] = int(r["Grid_Size"])
-    big = max(agg.values(), key=lambda d: d["grid_threads"])
-    clk = big["GRBM_GUI_ACTIVE"] / 8 / (big["dur_us"] * 1e-6)
-    simd_cycles = big["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024
-    big["effective_clock_GHz"] = clk / 1e9
-    big["mfma_busy_fraction_at_effective_clock"] = simd_cycles / (big["GRBM_GUI_ACTIVE"] / 8)
-    summary["eval_pmc_largest_launch"] = big
+            d["kernel"] = "v4_bf16x3" if "kernel_v4" in r["Kernel_Name"] else "v3_fp32"
+    for tagk in ("v4_bf16x3", "v3_fp32"):
+        cand = [d for d in agg.values() if d["kernel"] == tagk]
+        if not cand:
+            continue
+        big = max(cand, key=lambda d: d["grid_threads"])
+        clk = big["GRBM_GUI_ACTIVE"] / 8 / (big["dur_us"] * 1e-6)
+        simd_cycles = big["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024
+        big["effective_clock_GHz"] = clk / 1e9
+        big["mfma_busy_fraction_at_effective_clock"] = simd_cycles / (big["GRBM_GUI_ACTIVE"] / 8)
+        summary[f"eval_pmc_largest_launch_{tagk}"] = big
 json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
