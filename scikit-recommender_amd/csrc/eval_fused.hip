@@ -308,7 +308,7 @@ __device__ __forceinline__ float compact_select_n(const FusedArgs& a, const Wave
 }
 
 __device__ __forceinline__ float compact_user(const FusedArgs& a, const WaveCtx& w, int ul, int64_t out_row) {
-    __threadfence_block();  // this wave's earlier appends must have landed before they are re-read
+    __threadfence_block();  // this wave's earlier appends are re-read below by other lanes of the same wave (same CU, same L1: in order)
     const int n = w.cnt[ul];   // wave-uniform
     float thr;
     if (out_row < 0) {      // mid-sweep: select
@@ -758,14 +758,17 @@ __device__ __forceinline__ void tile_candidates_v4(const FusedArgs& a, const Wav
         m1 &= valid;
     }
     if (!__any((m0 | m1) != 0u)) return;
+    // both fragments' counts in one register, exchanged between lanes c and c+32 by v_permlane32_swap (no LDS trip)
+    const uint32_t packed = static_cast<uint32_t>(__popc(m0)) | (static_cast<uint32_t>(__popc(m1)) << 16);
+    const auto sw = __builtin_amdgcn_permlane32_swap(packed, packed, false, false);   // [0]: lower half's value, [1]: upper half's
+    const uint32_t lo_cnt = sw[0], hi_cnt = sw[1];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         uint32_t mm = f ? m1 : m0;
         const f32x16& acc = f ? acc1 : acc0;
-        const int n = __popc(mm);
-        const int other = __shfl_xor(n, 32, 64);
-        uint64_t* list = w.my_cand + static_cast<int64_t>(32 * f + w.c) * a.cap + cr.cnt[f] + (w.h ? other : 0);
-        cr.cnt[f] += n + other;          // <= trigger + 32 <= cap by the compaction rule
+        const int n_lo = static_cast<int>((lo_cnt >> (16 * f)) & 0xffffu), n_hi = static_cast<int>((hi_cnt >> (16 * f)) & 0xffffu);
+        uint64_t* list = w.my_cand + static_cast<int64_t>(32 * f + w.c) * a.cap + cr.cnt[f] + (w.h ? n_lo : 0);
+        cr.cnt[f] += n_lo + n_hi;        // <= trigger + 32 <= cap by the compaction rule
         while (mm) {
             const int r = __ffs(static_cast<int>(mm)) - 1;
             mm &= mm - 1;

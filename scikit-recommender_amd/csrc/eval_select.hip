@@ -40,6 +40,7 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
                                                          skr::InvLog2Table tbl, int top_k, RowOut o) {
     __shared__ uint64_t keys[TK_CAP];
     __shared__ int s_cnt;
+    __shared__ int s_over;     // index of the last tile whose appends took s_cnt past the compaction mark
     __shared__ uint64_t s_thr;
     __shared__ int s_rank[SKR_MAX_TOPK];
     __shared__ double s_inv[SKR_MAX_TOPK];
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
     const float* r = scores + row * ld;
     if (tid == 0) {
         s_cnt = 0;
+        s_over = -2;
         s_thr = SKR_KEY_MIN;
     }
     for (int i = tid; i < SKR_MAX_TOPK; i += TK_T) s_inv[i] = tbl.v[i];
@@ -69,8 +71,14 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
     };
 
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(r) & 15) == 0);
-    for (int base = 0; base < n_items; base += TK_TILE) {
-        if (s_cnt > TK_CAP - TK_TILE) compact();  // block-uniform: s_cnt only changes between barriers
+    // The decision to compact must be the same in every thread.  Reading s_cnt at the top of a tile is NOT:
+    // a fast thread may already be appending to it (this tile) while a slow one still evaluates the test, the
+    // two then disagree and meet different barriers -- measured as a lost candidate in ~1 of 10^5 rows at
+    // top-100 (tools/debug_dense_race.py).  Instead the thread whose append crosses the mark records the TILE
+    // INDEX; the test at the top of tile `it` looks for `it - 1`, a value nobody can write during tile `it`.
+    int it = 0;
+    for (int base = 0; base < n_items; base += TK_TILE, ++it) {
+        if (s_over == it - 1) compact();
         const uint64_t thr = s_thr;
         const int i0 = base + tid * 4;
         float v[4];
@@ -88,6 +96,7 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
             if (key > thr) {
                 const int p = atomicAdd(&s_cnt, 1);
                 keys[p] = key;  // p < TK_CAP: at most TK_TILE appends per tile and s_cnt <= CAP-TILE before
+                if (p + 1 > TK_CAP - TK_TILE) s_over = it;
             }
         }
         __syncthreads();
