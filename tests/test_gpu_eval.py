@@ -229,3 +229,27 @@ def test_fused_evaluator_reranks_structural_ties_in_reference_order(fused_mode):
     _, want, _ = O.ranking_evaluate(M().predict, train, test, metric=["Precision", "Recall", "MAP", "NDCG", "MRR"],
                                     top_k=[5, 10, 20], batch_size=32)
     np.testing.assert_allclose(np.array(list(got.values()), np.float32), want, rtol=1e-6, atol=0)   # fp32 mean order
+
+
+def test_eval_scores_is_deterministic_on_long_rows():
+    """Regression: the decision to compact the LDS candidate buffer used to be taken from a counter that other
+    threads were already incrementing, so threads could disagree and a candidate was lost in about one of 1e5
+    rows at top-100 (different rows on different runs).  Same input, repeated launches -> identical lists, and
+    the lists are the oracle's."""
+    import torch
+    from skrec import _hip
+    L = _hip.lib()
+    rng = np.random.default_rng(21)
+    B, I, K = 3072, 100_000, 100
+    sc = torch.from_numpy((rng.standard_normal((B, I)) * 0.1).astype(np.float32)).cuda()
+    outs = []
+    for _ in range(5):
+        ids = torch.empty((B, K), dtype=torch.int32, device="cuda")
+        _hip.check(L.skr_eval_scores(_hip.ptr(sc), B, I, I, None, None, None, 0, K, None, _hip.ptr(ids), None, _hip.stream()))
+        torch.cuda.synchronize()
+        outs.append(ids)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    host = sc[:64].cpu().numpy()
+    for r in range(64):
+        assert np.array_equal(outs[0][r].cpu().numpy(), O.topk_ids_heap(host[r], K))
