@@ -111,3 +111,17 @@ def test_bench_contract_on_a_small_workload():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 20 * cb["value"]
+
+
+def test_dataset_csr_gpu_sort_equals_numpy(monkeypatch):
+    """ingest: the CSR views built with the GPU sorts (large tables) are identical to the numpy ones"""
+    import pandas as pd
+    from skrec.io import dataset as D
+    rng = np.random.default_rng(5)
+    n, nu, ni = 1_300_000, 40_000, 3_000
+    df = pd.DataFrame({"user": rng.integers(0, nu, n), "item": rng.integers(0, ni, n), "rating": 1.0, "time": np.arange(n)})
+    a = D.ImplicitFeedback(df.copy(), nu, ni).to_csr_arrays()
+    monkeypatch.setattr(D, "_sort_device", lambda n_: None)
+    b = D.ImplicitFeedback(df.copy(), nu, ni).to_csr_arrays()
+    for x, y in zip(a, b):
+        assert x.dtype == y.dtype and np.array_equal(x, y)

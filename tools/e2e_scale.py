@@ -53,7 +53,16 @@ reg = ModelRegistry()
 reg.load_skrec_model(args.model)
 cls, _ = reg.get_model(args.model)
 t0 = time.time()
-model = cls(rc, {"epochs": args.epochs, "batch_size": args.batch})
+if os.environ.get("E2E_PROFILE"):
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    model = cls(rc, {"epochs": args.epochs, "batch_size": args.batch})
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+else:
+    model = cls(rc, {"epochs": args.epochs, "batch_size": args.batch})
 print(f"[e2e] model constructed in {time.time() - t0:.1f}s", flush=True)
 from skrec.io import PairwiseIterator  # noqa: E402
 t0 = time.time()
