@@ -114,6 +114,46 @@ def build_adjacency(users_np, items_np, num_users, num_items, adj_type):
     return mean_adj + sp.eye(mean_adj.shape[0])
 
 
+def build_adjacency_device(users, items, num_users, num_items, adj_type, dev):
+    """The same matrices as ``build_adjacency`` without the host: (adj, adj_transposed) as DeviceCSR, built
+    from the train pairs with device sorts.  Used for large graphs, where scipy needs about a minute for 10^8
+    non-zeros; values agree with the scipy build to 1 ulp (numpy's and the device's pow differ in the last bit)."""
+    n = num_users + num_items
+    u = torch.as_tensor(users, dtype=torch.int64).to(dev)
+    i = torch.as_tensor(items, dtype=torch.int64).to(dev) + num_users
+    key, counts = torch.unique(torch.cat([u * n + i, i * n + u]), return_counts=True)   # duplicate pairs sum (csr_matrix)
+    rows, cols, vals = torch.div(key, n, rounding_mode="floor"), key % n, counts.float()
+    eye = torch.arange(n, dtype=torch.int64, device=dev)
+
+    def with_identity(r, c, v):
+        k = torch.cat([r * n + c, eye * n + eye])
+        v = torch.cat([v, torch.ones(n, dtype=torch.float32, device=dev)])
+        k, inv = torch.unique(k, return_inverse=True)
+        return torch.div(k, n, rounding_mode="floor"), k % n, torch.zeros(k.numel(), device=dev).index_add_(0, inv, v)
+
+    def inv_pow(deg, p):
+        s = deg.pow(p)
+        return torch.where(torch.isinf(s), torch.zeros_like(s), s)
+
+    if adj_type == "norm":
+        rows, cols, vals = with_identity(rows, cols, vals)
+    deg = torch.zeros(n, dtype=torch.float32, device=dev).index_add_(0, rows, vals)
+    if adj_type == "pre":
+        s_ = inv_pow(deg, -0.5)
+        vals = (s_[rows] * vals) * s_[cols]
+    elif adj_type != "plain":
+        vals = inv_pow(deg, -1.0)[rows] * vals
+        if adj_type not in ("norm", "gcmc"):
+            rows, cols, vals = with_identity(rows, cols, vals)
+    adj = DeviceCSR.from_device_coo(rows, cols, vals, n)
+    adj_t = adj if adj_type in ("pre", "plain") else DeviceCSR.from_device_coo(cols, rows, vals, n)
+    return adj, adj_t
+
+
+# graphs with at least this many train pairs are built on the device (no scipy pass, no .npz cache file)
+DEVICE_ADJ_MIN_PAIRS = 1 << 21
+
+
 class LightGCN(AbstractRecommender):
     def __init__(self, run_config: RunConfig, model_config: Dict):
         self.config = LightGCNConfig(**model_config)
@@ -126,7 +166,9 @@ class LightGCN(AbstractRecommender):
         # one process per GPU (torchrun): user-sharded propagation, see skrec/parallel.py
         from ..parallel import init_from_env, ShardedLightGCN
         self.dist = init_from_env()
-        adj = self._load_adj_mat(cfg.adj_type)
+        n_pairs = len(self.dataset.train_data)
+        on_device = (not self.dist.active) and n_pairs >= DEVICE_ADJ_MIN_PAIRS
+        adj = None if on_device else self._load_adj_mat(cfg.adj_type)
         self._final_is_current = False
         self.sampler_mode = getattr(run_config, "sampler_mode", None)
         self.step_losses = None
@@ -139,9 +181,14 @@ class LightGCN(AbstractRecommender):
             self._full_user_final = None
             return
         self.engine = None
-        self.adj = DeviceCSR(adj, self.device)
-        # backward needs A^T; 'pre' and 'plain' are symmetric, 'norm'/'gcmc' are not
-        self.adj_t = self.adj if cfg.adj_type in ("pre", "plain") else DeviceCSR(sp.csr_matrix(adj).T, self.device)
+        if on_device:
+            pairs = self.dataset.train_data.to_user_item_pairs()
+            self.adj, self.adj_t = build_adjacency_device(pairs[:, 0], pairs[:, 1], self.num_users, self.num_items,
+                                                          cfg.adj_type, self.device)
+        else:
+            self.adj = DeviceCSR(adj, self.device)
+            # backward needs A^T; 'pre' and 'plain' are symmetric, 'norm'/'gcmc' are not
+            self.adj_t = self.adj if cfg.adj_type in ("pre", "plain") else DeviceCSR(sp.csr_matrix(adj).T, self.device)
         # xavier_uniform init in the reference's order (_LightGCN.__init__, LightGCN.py:71-80)
         ue, ie = nn.Embedding(self.num_users, cfg.embed_size), nn.Embedding(self.num_items, cfg.embed_size)
         get_initializer("xavier_uniform")(ue.weight)

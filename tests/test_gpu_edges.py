@@ -125,3 +125,24 @@ def test_dataset_csr_gpu_sort_equals_numpy(monkeypatch):
     b = D.ImplicitFeedback(df.copy(), nu, ni).to_csr_arrays()
     for x, y in zip(a, b):
         assert x.dtype == y.dtype and np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("adj_type", ["plain", "norm", "gcmc", "pre", "mean_plus_eye"])
+def test_lightgcn_adjacency_device_build_equals_scipy(adj_type):
+    """large graphs skip scipy: the device-built CSR has the structure of LightGCN._create_adj_mat's matrix
+    (LightGCN.py:142-169, duplicate pairs summed, zero-degree rows zero) and its values to 1 ulp"""
+    import scipy.sparse as sp
+    import torch
+    from skrec.recommender.LightGCN import build_adjacency, build_adjacency_device
+    rng = np.random.default_rng(9)
+    nu, ni, n = 700, 300, 6000
+    users, items = rng.integers(0, nu - 5, n), rng.integers(0, ni - 3, n)      # some zero-degree nodes, some duplicates
+    want = sp.csr_matrix(build_adjacency(users, items, nu, ni, adj_type))
+    want.sum_duplicates()
+    want.sort_indices()
+    adj, adj_t = build_adjacency_device(users, items, nu, ni, adj_type, torch.device("cuda", 0))
+    for got, ref in ((adj, want), (adj_t, sp.csr_matrix(want.T))):
+        ref.sort_indices()
+        assert np.array_equal(got.rowptr.cpu().numpy(), ref.indptr)
+        assert np.array_equal(got.col.cpu().numpy()[:got.nnz], ref.indices)
+        np.testing.assert_allclose(got.val.cpu().numpy()[:got.nnz], ref.data, rtol=3e-7, atol=0)
