@@ -26,7 +26,7 @@ from ..io import PairwiseIterator
 from ..run_config import RunConfig
 from ..utils.py import EarlyStopping, ModelConfig
 from .base import AbstractRecommender, DenseAdam
-from .LightGCN import DeviceCSR
+from .LightGCN import DEVICE_ADJ_MIN_PAIRS, DeviceCSR
 
 __all__ = ["LayerGCN", "LayerGCNConfig"]
 
@@ -94,7 +94,10 @@ class LayerGCN(AbstractRecommender):
                                           cfg.n_layers, cfg.lr, cfg.reg, self.device)
             self._full_user_out = None
             return
-        self.adj = DeviceCSR(build_layergcn_adjacency(inter, self.num_users, self.num_items), self.device)
+        if inter.nnz >= DEVICE_ADJ_MIN_PAIRS:     # large graph: no scipy pass (same values: float64 degrees, fp32 result)
+            self.adj = self._device_adjacency(inter)
+        else:
+            self.adj = DeviceCSR(build_layergcn_adjacency(inter, self.num_users, self.num_items), self.device)
         self.train_adj = self.adj                       # masked_adj of the reference (LayerGCN.py:119,135)
         # edge list + normalised edge values for the pruning step (get_edge_info, LayerGCN.py:165-171)
         self._edge_u = torch.from_numpy(np.asarray(inter.row, dtype=np.int64)).to(self.device)
@@ -124,6 +127,19 @@ class LayerGCN(AbstractRecommender):
         if self.engine is not None:
             return self.engine.item_rows
         return self.ego[self.num_users:]
+
+    def _device_adjacency(self, inter):
+        """get_norm_adj_mat (LayerGCN.py:173-197) on the device: binary bipartite graph (duplicate pairs are one
+        edge), D^-1/2 A D^-1/2 with 1e-7 added to the degrees, float64 arithmetic rounded to float32"""
+        dev, nu, n = self.device, self.num_users, self.num_users + self.num_items
+        key = torch.unique(torch.from_numpy(np.asarray(inter.row, dtype=np.int64)).to(dev) * self.num_items
+                           + torch.from_numpy(np.asarray(inter.col, dtype=np.int64)).to(dev))
+        u, i = torch.div(key, self.num_items, rounding_mode="floor"), key % self.num_items
+        one = torch.ones(u.numel(), dtype=torch.float64, device=dev)
+        du = (torch.zeros(nu, dtype=torch.float64, device=dev).index_add_(0, u, one) + 1e-7).pow(-0.5)
+        di = (torch.zeros(self.num_items, dtype=torch.float64, device=dev).index_add_(0, i, one) + 1e-7).pow(-0.5)
+        vals = (du[u] * di[i]).float()
+        return DeviceCSR.from_device_coo(torch.cat([u, i + nu]), torch.cat([i + nu, u]), torch.cat([vals, vals]), n)
 
     def _normalize_edges(self, u, i):
         """_normalize_adj_m (LayerGCN.py:154-163): 1/sqrt((deg_u + 1e-7)(deg_i + 1e-7)) on the given edges"""

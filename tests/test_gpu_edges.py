@@ -146,3 +146,18 @@ def test_lightgcn_adjacency_device_build_equals_scipy(adj_type):
         assert np.array_equal(got.rowptr.cpu().numpy(), ref.indptr)
         assert np.array_equal(got.col.cpu().numpy()[:got.nnz], ref.indices)
         np.testing.assert_allclose(got.val.cpu().numpy()[:got.nnz], ref.data, rtol=3e-7, atol=0)
+
+
+def test_layergcn_device_adjacency_equals_scipy(tiny_dir, monkeypatch, tmp_path):
+    """LayerGCN's large-graph path (device-built normalised adjacency) == get_norm_adj_mat restated with scipy"""
+    import scipy.sparse as sp
+    from skrec import RunConfig
+    from skrec.recommender import LayerGCN as M
+    monkeypatch.chdir(tmp_path)
+    rc = RunConfig(recommender="LayerGCN", data_dir=tiny_dir, file_column="UIRT", sep="\t", metric=("Recall",), top_k=(5,))
+    host = M.LayerGCN(rc, dict(epochs=1))
+    monkeypatch.setattr(M, "DEVICE_ADJ_MIN_PAIRS", 1)
+    dev = M.LayerGCN(rc, dict(epochs=1))
+    for a, b in ((host.adj.rowptr, dev.adj.rowptr), (host.adj.col, dev.adj.col)):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    np.testing.assert_allclose(dev.adj.val.cpu().numpy(), host.adj.val.cpu().numpy(), rtol=2e-7, atol=0)
