@@ -310,6 +310,46 @@ def main():
             pids = step_ids.data_ptr()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)] \
             if events is not None else None
+        if kblk > 1:
+            # N = 1: temporally blocked dense Adam (csrc/train.hip K2b; what skrec.recommender.BPRMF.train_epoch does).
+            # Per block of kblk steps: rows no batch of the block touches get their kblk zero-gradient updates in ONE
+            # pass (adam_cold_kernel), touched rows get the ordinary update after every batch (adam_hot_kernel).
+            # Every parameter receives every update in the same arithmetic -- bit-identical to a dense launch per step.
+            for s0 in range(0, n_steps, kblk):
+                kk = min(kblk, n_steps - s0)
+                lo, hi = s0 * b, (s0 + kk) * b
+                bi, bj = ii[lo:hi], jj[lo:hi]
+                blk = torch.cat([uu[lo:hi], bi + nU, bj + nU, (bi >> 6) + (nU + nI), (bj >> 6) + (nU + nI)])
+                run_slice.serial += 1
+                cur = torch.cuda.current_stream()
+                if run_slice.serial > 1:
+                    cur.wait_event(ev_cold)      # the previous cold pass still reads the tags / writes cold rows
+                rc = L.skr_adam_block_mark(blk.data_ptr(), blk.numel(), 0, 64, blk_tag.data_ptr(), run_slice.serial, stream)
+                # the cold pass touches no row this block's batches read or write: side stream, under the small launches
+                ev_marked.record(cur)
+                side.wait_event(ev_marked)
+                if ev is not None:
+                    ev[s0][0].record(side)
+                rc |= L.skr_adam_block_cold(P["flat"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, run_slice.t, kk,
+                                            blk_tag.data_ptr(), run_slice.serial, side.cuda_stream)
+                if ev is not None:
+                    ev[s0][1].record(side)
+                ev_cold.record(side)
+                pblk, nblk = blk.data_ptr(), blk.numel()
+                for s in range(s0, s0 + kk):
+                    o = s * b * 4
+                    rc |= L.skr_bpr_step(P["U"], P["V"], P["bias"], P["U"], P["V"], pu + o, pi + o, pj + o, b, 1.0, 1e-3, 1.0,
+                                         P["gU"], P["gV"], P["gb"], P["gU"], P["gV"], P["loss"], None, None, stream)
+                    run_slice.t += 1
+                    rc |= L.skr_adam_block_hot(P["flat"], P["grad"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, run_slice.t,
+                                               pblk, nblk, 0, 64, blk_claim.data_ptr(), run_slice.t, stream)
+                if rc:
+                    _hip.check(rc)
+                keep_alive.append(blk)
+            torch.cuda.current_stream().wait_event(ev_cold)
+            if events is not None:
+                events.extend(ev[s0] for s0 in range(0, n_steps, kblk))
+            return
         for s in range(n_steps):
             o = s * b * 4
             rc = L.skr_bpr_step(P["U"], P["V"], P["bias"], P["U"], P["V"], pu + o, pi + o, pj + o, b, 1.0, 1e-3, 1.0,
@@ -348,6 +388,16 @@ def main():
         if events is not None:
             events.extend(ev)
     n_user_par = nU * D
+    # SKR_ADAM_BLOCK = k (default 8, N = 1 only): look k batches ahead and block the dense Adam over them; 1 = classic
+    kblk = max(1, min(16, int(os.environ.get("SKR_ADAM_BLOCK", "8")))) if world == 1 else 1
+    blk_tag = torch.zeros((n_par + 63) // 64, dtype=torch.int32, device=dev)
+    blk_claim = torch.zeros_like(blk_tag)
+    keep_alive = []
+    # the cold pass may run on a side stream under the small launches (what BPRMF.train_epoch does: +13 % there, where the
+    # batches' rows are spread over the whole tables); on this bench's user-prefix slices it costs 15 %, so it is off here
+    side = torch.cuda.Stream(device=dev) if os.environ.get("SKR_ADAM_OVERLAP", "0") != "0" else torch.cuda.current_stream()
+    ev_marked, ev_cold = torch.cuda.Event(), torch.cuda.Event()
+    run_slice.serial = 0
     gather_into = world > 1 and dist.get_backend() == "nccl"    # gloo rehearsals use the list form
     if exchange == "sparse":
         # probe the collective once outside the timed region; every rank takes the same branch because a
@@ -423,12 +473,27 @@ def main():
     # ---- roofline of the dominant kernel (adam_kernel over the flat parameter buffer) ---------------
     # 7 fp32 per parameter per step (p,g,m,v in; p,m,v out).  For N > 1 the timed launch is the
     # replicated [V | b] part (the user part overlaps the all-reduce and is not bracketed by the events).
-    adam_bytes = float(n_par if world == 1 else n_par - nU * D) * 28.0
-    ach = adam_bytes / (adam_ms * 1e-3) / 1e9
-    out["roofline"] = {"kernel": "adam_kernel<true> (dense Adam over the flat [U|V|b] buffer, one launch per step)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("adam_kernel") if world == 1 and args.users == 1_000_000 else None,
-                       "avg_launch_ms": adam_ms,
-                       "algorithmic_bytes_per_launch": adam_bytes}
+    if kblk > 1:
+        # dominant train kernel in blocked mode: adam_cold_kernel, ONE pass per kblk steps over (nearly) the whole flat
+        # buffer: p, m, v read and written once = 24 B per parameter per LAUNCH (no gradient read: cold blocks have
+        # none); the launch applies kblk optimiser steps.  SURVEY 8(d)'s per-step figure (28 B per parameter and step)
+        # is what this pass replaces kblk times over; it is reported as `dense_equivalent_GBps`, not as `achieved`.
+        cold_bytes = float(n_par) * 24.0
+        ach = cold_bytes / (adam_ms * 1e-3) / 1e9
+        out["roofline"] = {"kernel": f"adam_cold_kernel (temporally blocked dense Adam: {kblk} zero-gradient steps per pass over the "
+                                     f"blocks no batch of the block touches; bit-identical to a dense launch per step)",
+                           "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic("adam_cold_kernel") if args.users == 1_000_000 else None,
+                           "avg_launch_ms": adam_ms, "algorithmic_bytes_per_launch": cold_bytes,
+                           "optimizer_steps_per_launch": kblk,
+                           "dense_equivalent_GBps": float(n_par) * 28.0 * kblk / (adam_ms * 1e-3) / 1e9}
+    else:
+        adam_bytes = float(n_par if world == 1 else n_par - nU * D) * 28.0
+        ach = adam_bytes / (adam_ms * 1e-3) / 1e9
+        out["roofline"] = {"kernel": "adam_kernel<true> (dense Adam over the flat [U|V|b] buffer, one launch per step)", "bound": "hbm",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic("adam_kernel") if world == 1 and args.users == 1_000_000 else None,
+                           "avg_launch_ms": adam_ms, "algorithmic_bytes_per_launch": adam_bytes}
 
     # ---- eval leg: fused GEMM(MFMA)+mask+top-K over a block of this rank's users -------------------
     if not args.no_eval:

@@ -241,6 +241,24 @@ int skr_gather_rows(const float* d_table, const int32_t* d_idx, int64_t n, int d
 int skr_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
 int skr_scale(float a, float* d_x, int64_t n, void* stream);                 /* x *= a */
 
+/* The same dense Adam, temporally blocked over k consecutive steps whose batches are known in advance (an epoch's
+ * batches are: data_iterator.py:230-234).  64-float blocks of the flat buffer that none of the k steps touches get
+ * their k zero-gradient updates in ONE pass; touched blocks get the ordinary update at every step.  Every
+ * parameter receives every update in the arithmetic of skr_adam_step: the results are bit-identical.
+ *   skr_adam_block_mark   d_tag[(offset + id*stride) >> 6] = tag_value for every id (call once per id list:
+ *                         user rows offset 0 stride 64, item rows offset U*64, bias offset (U+I)*64 stride 1)
+ *   skr_adam_block_cold   steps step_t0+1 .. step_t0+k with zero gradient on every block whose tag != hot_value
+ *   skr_adam_block_hot    step step_t on the blocks the ids name, each claimed once (d_claim[block] = claim_value);
+ *                         reads and clears their gradient.  Pass the id lists of the WHOLE k-step block at every step.
+ *   d_tag, d_claim        int32[ceil(n / 64)], zero-initialised; use a fresh non-zero tag_value / claim_value each time */
+int skr_adam_block_mark(const int32_t* d_ids, int64_t n_ids, int64_t offset_floats, int stride_floats, int32_t* d_tag,
+                        int32_t tag_value, void* stream);
+int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        int64_t step_t0, int k, const int32_t* d_tag, int32_t hot_value, void* stream);
+int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
+                       int stride_floats, int32_t* d_claim, int32_t claim_value, void* stream);
+
 /* Sparse exchange of a replicated table's gradient between ranks (no reference counterpart -- the
  * reference is single-process).  A BPR step touches at most 2*batch item rows, so instead of all-reducing the
  * dense [I, 65] block each rank packs its touched rows, the ranks all-gather the packs, and every rank adds

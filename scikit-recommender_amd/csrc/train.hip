@@ -354,6 +354,112 @@ __global__ void scale_kernel(float a, float* __restrict__ x, int64_t n) {
 inline unsigned rows_to_blocks(int64_t n_rows) { return static_cast<unsigned>((n_rows * 64 + 255) / 256); }
 
 // ------------------------------------------------------------------------------------------------
+// K2b: the same dense Adam, temporally blocked.  The reference's optimiser moves EVERY parameter at EVERY
+// step, but a BPR step puts a non-zero gradient into at most 3*batch of the ~1.1 M rows, and the batches of an
+// epoch are known in advance.  For a block of k consecutive steps the 64-float blocks of the flat buffer
+// are split into HOT (touched by at least one of the k steps) and COLD.  A cold block sees k zero-gradient
+// updates: they are applied in ONE pass (p, m, v read and written once instead of k times), each of the k
+// updates evaluated exactly as adam_elem does with g = 0 and that step's bias corrections.  Hot blocks get
+// the ordinary update at every step, through the id lists of the block (each block claimed once per step).
+// Every parameter still receives every update, in the same arithmetic: results are bit-identical to calling
+// skr_adam_step after every step (tests/test_gpu_train.py::test_blocked_adam_is_bit_identical).
+// ------------------------------------------------------------------------------------------------
+constexpr int AB_KMAX = 16;
+struct AdamBlockArgs {
+    float one_minus_b1, b2, one_minus_b2, eps;
+    float neg_step_size[AB_KMAX], bc2_sqrt[AB_KMAX];
+    int k;
+};
+
+__global__ __launch_bounds__(256) void adam_mark_kernel(const int32_t* __restrict__ ids, int64_t n, int64_t offset,
+                                                        int stride, int32_t* __restrict__ tag, int32_t value) {
+    const int64_t g = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (g < n) tag[(offset + static_cast<int64_t>(ids[g]) * stride) >> 6] = value;
+}
+
+// cold pass: every float4 whose 64-float block is not tagged gets k zero-gradient updates
+template <int UNROLL>
+__global__ __launch_bounds__(256) void adam_cold_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                        int64_t n, AdamBlockArgs a, const int32_t* __restrict__ tag,
+                                                        int32_t hot_value) {
+    const int64_t n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    auto ld = [](const float4* q) -> float4 {
+        float4 r;
+        r.x = __builtin_nontemporal_load(&q->x); r.y = __builtin_nontemporal_load(&q->y);
+        r.z = __builtin_nontemporal_load(&q->z); r.w = __builtin_nontemporal_load(&q->w);
+        return r;
+    };
+    auto stv = [](float4* q, const float4& r) {
+        __builtin_nontemporal_store(r.x, &q->x); __builtin_nontemporal_store(r.y, &q->y);
+        __builtin_nontemporal_store(r.z, &q->z); __builtin_nontemporal_store(r.w, &q->w);
+    };
+    auto steps = [&](float& pp, float& mm, float& vv) {
+        for (int s = 0; s < a.k; ++s) {
+            AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
+            adam_elem(pp, 0.0f, mm, vv, one);
+        }
+    };
+    for (int64_t i0 = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i0 < n4; i0 += stride * UNROLL) {
+        float4 pp[UNROLL], mm[UNROLL], vv[UNROLL];
+        bool cold[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t i = i0 + u * stride;
+            cold[u] = i < n4 && tag[i >> 4] != hot_value;
+            if (cold[u]) {
+                pp[u] = ld(&p4[i]);
+                mm[u] = ld(&m4[i]);
+                vv[u] = ld(&v4[i]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (cold[u]) {
+                const int64_t i = i0 + u * stride;
+                steps(pp[u].x, mm[u].x, vv[u].x);
+                steps(pp[u].y, mm[u].y, vv[u].y);
+                steps(pp[u].z, mm[u].z, vv[u].z);
+                steps(pp[u].w, mm[u].w, vv[u].w);
+                stv(&p4[i], pp[u]);
+                stv(&m4[i], mm[u]);
+                stv(&v4[i], vv[u]);
+            }
+        }
+    }
+    // tail (n not a multiple of 4)
+    for (int64_t i = (n4 << 2) + blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride)
+        if (tag[i >> 6] != hot_value) steps(p[i], m[i], v[i]);
+}
+
+// hot step: one wavefront per id; the block it names is claimed once per step and gets the ordinary update
+__global__ __launch_bounds__(256) void adam_hot_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, int64_t n, AdamArgs a,
+                                                       const int32_t* __restrict__ ids, int64_t n_ids, int64_t offset,
+                                                       int stride, int32_t* __restrict__ claim, int32_t claim_value) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= n_ids) return;
+    const int64_t blk = (offset + static_cast<int64_t>(ids[e]) * stride) >> 6;
+    int old = 0;
+    if (lane == 0) old = atomicExch(&claim[blk], claim_value);
+    old = __shfl(old, 0, 64);
+    if (old == claim_value) return;
+    const int64_t i = blk * 64 + lane;
+    if (i < n) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_elem(pp, g[i], mm, vv, a);
+        p[i] = pp;
+        m[i] = mm;
+        v[i] = vv;
+        g[i] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sparse exchange of the replicated item table's gradient (multi-GPU BPRMF).  A step touches at
 // most 2 * batch of the I item rows, so the ranks exchange packed rows [id | dV (64) | db] instead of
 // all-reducing the dense [I, 65] block (26 MB at I = 100 k): pack -> all-gather -> unpack.
@@ -583,6 +689,68 @@ int skr_unpack_grad_rows(const float* d_in, int n_per_rank, int n_ranks, float* 
                            d_touch_base);
         SKR_LAUNCH_CHECK();
     }
+    return SKR_OK;
+}
+
+static void adam_scalars(float lr, float beta1, float beta2, int64_t step_t, float* neg_step_size, float* bc2_sqrt) {
+    // torch/optim/adam.py _single_tensor_adam: python-double scalars, cast to fp32 at the tensor ops (as skr_adam_step)
+    const double b1 = static_cast<double>(beta1), b2 = static_cast<double>(beta2);
+    const double bc1 = 1.0 - std::pow(b1, static_cast<double>(step_t));
+    const double bc2 = 1.0 - std::pow(b2, static_cast<double>(step_t));
+    *neg_step_size = static_cast<float>(-(static_cast<double>(lr) / bc1));
+    *bc2_sqrt = static_cast<float>(std::sqrt(bc2));
+}
+
+int skr_adam_block_mark(const int32_t* d_ids, int64_t n_ids, int64_t offset_floats, int stride_floats, int32_t* d_tag,
+                        int32_t tag_value, void* stream) {
+    SKR_REQUIRE(d_ids && d_tag, "skr_adam_block_mark: NULL argument");
+    SKR_REQUIRE(n_ids >= 0 && offset_floats >= 0 && stride_floats >= 1, "skr_adam_block_mark: bad shape");
+    if (n_ids == 0) return SKR_OK;
+    hipLaunchKernelGGL(adam_mark_kernel, dim3(static_cast<unsigned>((n_ids + 255) / 256)), dim3(256), 0, skr::as_stream(stream),
+                       d_ids, n_ids, offset_floats, stride_floats, d_tag, tag_value);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        int64_t step_t0, int k, const int32_t* d_tag, int32_t hot_value, void* stream) {
+    SKR_REQUIRE(d_p && d_m && d_v && d_tag, "skr_adam_block_cold: NULL argument");
+    SKR_REQUIRE(n >= 0 && step_t0 >= 0 && k >= 1 && k <= AB_KMAX, "skr_adam_block_cold: need 1 <= k <= %d", AB_KMAX);
+    SKR_REQUIRE(((reinterpret_cast<uintptr_t>(d_p) | reinterpret_cast<uintptr_t>(d_m) | reinterpret_cast<uintptr_t>(d_v)) & 15) == 0,
+                "skr_adam_block_cold: buffers must be 16-byte aligned");
+    if (n == 0) return SKR_OK;
+    AdamBlockArgs a;
+    a.one_minus_b1 = static_cast<float>(1.0 - static_cast<double>(beta1));
+    a.b2 = beta2;
+    a.one_minus_b2 = static_cast<float>(1.0 - static_cast<double>(beta2));
+    a.eps = eps;
+    a.k = k;
+    for (int s = 0; s < k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s]);
+    static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // 8 measured best (tools/adam_block_sweep.sh)
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 256 * bpc) blocks = 256 * bpc;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_cold_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream), d_p, d_m,
+                       d_v, n, a, d_tag, hot_value);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
+                       int stride_floats, int32_t* d_claim, int32_t claim_value, void* stream) {
+    SKR_REQUIRE(d_p && d_g && d_m && d_v && d_ids && d_claim, "skr_adam_block_hot: NULL argument");
+    SKR_REQUIRE(n >= 0 && step_t >= 1 && n_ids >= 0 && offset_floats >= 0 && stride_floats >= 1, "skr_adam_block_hot: bad shape");
+    if (n_ids == 0) return SKR_OK;
+    AdamArgs a;
+    a.one_minus_b1 = static_cast<float>(1.0 - static_cast<double>(beta1));
+    a.b2 = beta2;
+    a.one_minus_b2 = static_cast<float>(1.0 - static_cast<double>(beta2));
+    a.eps = eps;
+    adam_scalars(lr, beta1, beta2, step_t, &a.neg_step_size, &a.bc2_sqrt);
+    hipLaunchKernelGGL(adam_hot_kernel, dim3(static_cast<unsigned>((n_ids + 3) / 4)), dim3(256), 0, skr::as_stream(stream), d_p,
+                       d_g, d_m, d_v, n, a, d_ids, n_ids, offset_floats, stride_floats, d_claim, claim_value);
+    SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
 

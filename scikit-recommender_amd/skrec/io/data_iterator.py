@@ -84,6 +84,22 @@ def _n_batches(n, batch_size, drop_last):
     return n // batch_size if drop_last else (n + batch_size - 1) // batch_size
 
 
+def _shuffled_columns(columns, shuffle, device_shuffle=False):
+    """whole epoch columns, shuffled once on the device (contract: see _device_batches)"""
+    import torch
+    n = columns[0].shape[0]
+    if shuffle:
+        dev = columns[0].device
+        if device_shuffle:
+            g = torch.Generator(device=dev)
+            g.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
+            perm = torch.randperm(n, generator=g, device=dev)
+        else:
+            perm = torch.from_numpy(np.random.permutation(n)).to(dev)
+        columns = [c.index_select(0, perm) for c in columns]
+    return columns
+
+
 def _device_batches(columns, batch_size, shuffle, drop_last, device_shuffle=False):
     """Shuffle whole epoch columns once on the device, then yield consecutive slices.
     Default: the reference's contract -- ONE np.random.permutation(n) from numpy's global generator per
@@ -130,6 +146,18 @@ class PairwiseIterator(object):
             neg = neg.view(-1, self.num_neg)
         return _device_batches([self._s.d_users, self._s.d_pos, neg], self.batch_size, self.shuffle, self.drop_last,
                                self.device_shuffle)
+
+    def epoch_columns(self):
+        """One epoch as whole device columns: (users, pos, neg) after sampling and shuffling, plus the batch
+        boundaries [(start, stop), ...] that iter_device() would walk.  Consumes the sampler stream and numpy's
+        permutation exactly like one ``iter_device()`` pass; lets a trainer look k batches ahead."""
+        neg = self._s.sample()
+        if self.num_neg > 1:
+            neg = neg.view(-1, self.num_neg)
+        cols = _shuffled_columns([self._s.d_users, self._s.d_pos, neg], self.shuffle, self.device_shuffle)
+        n, b = cols[0].shape[0], self.batch_size
+        bounds = [(s, min(s + b, n)) for s in range(0, n, b) if not (self.drop_last and s + b > n)]
+        return cols, bounds
 
     def __iter__(self):
         for u, i, j in self.iter_device():

@@ -8,6 +8,7 @@ BPRMF.py:117-124) and the same dense Adam.  One training step is two kinds of la
 ``skr_bpr_step`` (gather + score + loss + gradient scatter fused) and ONE ``skr_adam_step`` over the
 flat [U | V | b] parameter buffer.
 """
+import os
 from typing import Dict
 
 import numpy as np
@@ -82,7 +83,9 @@ class BPRMF(AbstractRecommender):
         self.user_embeddings = self._flat[:nu * d].view(nu, d)
         self.item_embeddings = self._flat[nu * d:(nu + ni) * d].view(ni, d)
         self.item_biases = self._flat[(nu + ni) * d:]
-        self.optimizer = DenseAdam(self._flat, lr=self.config.lr, track_touch=True)
+        # SKR_ADAM_BLOCK = k: look k batches ahead and block the dense Adam over them (1: one dense launch per step)
+        self.adam_block = max(1, min(16, int(os.environ.get("SKR_ADAM_BLOCK", "8"))))
+        self.optimizer = DenseAdam(self._flat, lr=self.config.lr, track_touch=self.adam_block <= 1)
         self._grads = (self.optimizer.grad_view(0, (nu, d)), self.optimizer.grad_view(nu * d, (ni, d)),
                        self.optimizer.grad_view((nu + ni) * d, (ni,)))
 
@@ -94,7 +97,8 @@ class BPRMF(AbstractRecommender):
             _hip.ptr(self.user_embeddings), _hip.ptr(self.item_embeddings),
             _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), 1.0, self.config.reg, 1.0,
             _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(gb), _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(loss_slot),
-            _hip.ptr(self.optimizer.touch), _hip.ptr(self.optimizer.grad), _hip.stream()))
+            _hip.ptr(self.optimizer.touch), _hip.ptr(self.optimizer.grad) if self.optimizer.touch is not None else None,
+            _hip.stream()))
         self.optimizer.step()
 
     def train_epoch(self, data_iter):
@@ -109,17 +113,47 @@ class BPRMF(AbstractRecommender):
         gU, gV, gb = self._grads
         pU, pV, pb = self.user_embeddings.data_ptr(), self.item_embeddings.data_ptr(), self.item_biases.data_ptr()
         pgU, pgV, pgb = gU.data_ptr(), gV.data_ptr(), gb.data_ptr()
-        ptouch, pgrad, pflat, pm, pv = (t.data_ptr() for t in (opt.touch, opt.grad, opt.flat, opt.m, opt.v))
-        ploss, n_par, reg = self.step_losses.data_ptr(), opt.flat.numel(), self.config.reg
-        for k, (u, i, j) in enumerate(data_iter.iter_device()):
-            # slices of the contiguous epoch columns are themselves contiguous (num_neg == 1)
-            rc = L.skr_bpr_step(pU, pV, pb, pU, pV, u.data_ptr(), i.data_ptr(), j.data_ptr(), u.numel(), 1.0, reg, 1.0,
-                                pgU, pgV, pgb, pgU, pgV, ploss + 8 * k, ptouch, pgrad, st)
-            opt.t += 1
-            rc |= L.skr_adam_step(pflat, pgrad, pm, pv, n_par, opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.t, 1,
-                                  ptouch, st)
+        ploss, reg = self.step_losses.data_ptr(), self.config.reg
+        kblk = self.adam_block
+        if kblk <= 1 or data_iter.num_neg != 1:
+            ptouch, pgrad, pflat, pm, pv = (t.data_ptr() for t in (opt.touch, opt.grad, opt.flat, opt.m, opt.v))
+            n_par = opt.flat.numel()
+            for k, (u, i, j) in enumerate(data_iter.iter_device()):
+                # slices of the contiguous epoch columns are themselves contiguous (num_neg == 1)
+                rc = L.skr_bpr_step(pU, pV, pb, pU, pV, u.data_ptr(), i.data_ptr(), j.data_ptr(), u.numel(), 1.0, reg, 1.0,
+                                    pgU, pgV, pgb, pgU, pgV, ploss + 8 * k, ptouch, pgrad, st)
+                opt.t += 1
+                rc |= L.skr_adam_step(pflat, pgrad, pm, pv, n_par, opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.t, 1,
+                                      ptouch, st)
+                if rc:
+                    _hip.check(rc)
+            return
+        # Temporally blocked dense Adam (csrc/train.hip, K2b): the epoch's batches are known, so for every block of
+        # `kblk` steps the rows no batch of the block touches get their kblk zero-gradient updates in one pass and
+        # only the touched rows are stepped batch by batch -- the same updates in the same arithmetic, bit-identical
+        # to the loop above, with 1/kblk of its optimiser traffic.
+        (cu, ci, cj), bounds = data_iter.epoch_columns()
+        nu, ni = self.num_users, self.num_items
+        pcu, pci, pcj = cu.data_ptr(), ci.data_ptr(), cj.data_ptr()
+        bpr = L.skr_bpr_step
+        for s0 in range(0, len(bounds), kblk):
+            blk = bounds[s0:s0 + kblk]
+            lo, hi = blk[0][0], blk[-1][1]
+            ii, jj = ci[lo:hi], cj[lo:hi]
+            # 64-float blocks of the flat [U | V | b] buffer the block's batches touch: user rows, item rows, bias words
+            opt.begin_block(torch.cat([cu[lo:hi], ii + nu, jj + nu, (ii >> 6) + (nu + ni), (jj >> 6) + (nu + ni)]), len(blk))
+            hot, pp, pg, pm, pv, n_par, pids, nids, pclaim, _ = opt._hot
+            lr, b1, b2, eps, t = opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.t
+            rc = 0
+            for k, (a, b) in enumerate(blk, start=s0):      # two launches per step, on cached integer addresses
+                t += 1
+                rc |= bpr(pU, pV, pb, pU, pV, pcu + 4 * a, pci + 4 * a, pcj + 4 * a, b - a, 1.0, reg, 1.0,
+                          pgU, pgV, pgb, pgU, pgV, ploss + 8 * k, None, None, st)
+                rc |= hot(pp, pg, pm, pv, n_par, lr, b1, b2, eps, t, pids, nids, 0, 64, pclaim, t, st)
+            opt.t = t
             if rc:
                 _hip.check(rc)
+        opt.end_blocks()
 
     def fit(self):
         data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,

@@ -77,6 +77,56 @@ class DenseAdam(object):
         self.tf_epsilon = bool(tf_epsilon)
         self.t = 0
 
+    # ---- temporally blocked stepping (bit-identical to step() after every batch) -----------------------------
+    def begin_block(self, block_ids, k):
+        """``block_ids``: int32 device tensor with the index (float offset / 64) of every 64-float block that any
+        of the coming k steps touches, duplicates allowed.  Tags those blocks and gives every OTHER block its k
+        zero-gradient updates in one pass; ``hot_step()`` must then be called once per step, k times."""
+        import torch
+        from .. import _hip
+        L, st = _hip.lib(), _hip.stream()
+        if getattr(self, "_blk_tag", None) is None:
+            nb = (self.flat.numel() + 63) // 64
+            self._blk_tag = torch.zeros(nb, dtype=torch.int32, device=self.flat.device)
+            self._blk_claim = torch.zeros(nb, dtype=torch.int32, device=self.flat.device)
+            self._blk_serial = 0
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            import os
+            self._side = torch.cuda.Stream(device=self.flat.device) if os.environ.get("SKR_ADAM_OVERLAP", "1") != "0" else cur
+            self._ev_marked, self._ev_cold = torch.cuda.Event(), torch.cuda.Event()
+        else:
+            cur.wait_event(self._ev_cold)    # the previous block's cold pass still reads the tags and writes cold rows
+        self._blk_serial += 1
+        self._blk_ids = block_ids           # kept alive until the block is done
+        _hip.check(L.skr_adam_block_mark(_hip.ptr(block_ids), block_ids.numel(), 0, 64, _hip.ptr(self._blk_tag),
+                                         self._blk_serial, st))
+        # the cold pass (ALU-bound: k correctly rounded sqrt/divide chains per element) touches no row the block's
+        # batches read or write, so it runs on a side stream underneath the k small bpr / hot-step launches
+        self._ev_marked.record(cur)
+        self._side.wait_event(self._ev_marked)
+        _hip.check(L.skr_adam_block_cold(_hip.ptr(self.flat), _hip.ptr(self.m), _hip.ptr(self.v), self.flat.numel(), self.lr,
+                                         self.betas[0], self.betas[1], self.eps, self.t, int(k), _hip.ptr(self._blk_tag),
+                                         self._blk_serial, self._side.cuda_stream))
+        self._ev_cold.record(self._side)
+        self._hot = (L.skr_adam_block_hot, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                     self.flat.numel(), block_ids.data_ptr(), block_ids.numel(), self._blk_claim.data_ptr(), st)
+
+    def end_blocks(self):
+        """join the side stream: call after the last block, before anything else reads the parameters"""
+        import torch
+        if getattr(self, "_side", None) is not None:
+            torch.cuda.current_stream().wait_event(self._ev_cold)
+
+    def hot_step(self):
+        """the ordinary update of this step on the blocks tagged by begin_block (their gradients are consumed)"""
+        fn, pp, pg, pm, pv, n, pids, nids, pclaim, st = self._hot
+        self.t += 1
+        rc = fn(pp, pg, pm, pv, n, self.lr, self.betas[0], self.betas[1], self.eps, self.t, pids, nids, 0, 64, pclaim, self.t, st)
+        if rc:
+            from .. import _hip
+            _hip.check(rc)
+
     def grad_view(self, start, shape):
         n = 1
         for d in shape:

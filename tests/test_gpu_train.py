@@ -194,3 +194,59 @@ def test_gather_axpy_scale():
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), T[idx])
     _close(y.cpu().numpy(), (T + np.float32(0.5) * T) * np.float32(3.0), rtol=1e-6)
+
+
+@pytest.mark.parametrize("k,n_steps", [(8, 37), (1, 5), (16, 16), (3, 10)])
+def test_blocked_adam_is_bit_identical(k, n_steps):
+    """temporally blocked dense Adam (cold blocks: k zero-gradient updates in one pass; hot blocks: the ordinary
+    update every step) == skr_adam_step after every batch, BIT FOR BIT: parameters and both moments"""
+    import torch
+    from skrec import _hip
+    from skrec.recommender.base import DenseAdam
+    L, st = _hip.lib(), _hip.stream
+    rng = np.random.default_rng(100 + k)
+    nU, nI, b = 5000, 777, 256
+    n_par = (nU + nI) * 64 + nI
+    init = torch.from_numpy((rng.standard_normal(n_par) * 0.05).astype(np.float32)).cuda()
+    # rows are distinct within a step (float atomics on a row then happen once: the gradients are deterministic
+    # and the comparison isolates the optimiser); across steps they repeat freely
+    u = torch.from_numpy(np.stack([rng.permutation(nU)[:b] for _ in range(n_steps)]).astype(np.int32)).cuda()
+    ij = np.stack([rng.permutation(nI)[:2 * b] for _ in range(n_steps)]).astype(np.int32)
+    i, j = torch.from_numpy(ij[:, :b].copy()).cuda(), torch.from_numpy(ij[:, b:].copy()).cuda()
+
+    def views(opt):
+        f, g = opt.flat, opt.grad
+        sl = lambda t: (t[:nU * 64].view(nU, 64), t[nU * 64:(nU + nI) * 64].view(nI, 64), t[(nU + nI) * 64:])  # noqa: E731
+        return sl(f), sl(g)
+
+    def bpr(opt, s, loss, touch):
+        (U, V, bias), (gU, gV, gb) = views(opt)
+        _hip.check(L.skr_bpr_step(_hip.ptr(U), _hip.ptr(V), _hip.ptr(bias), _hip.ptr(U), _hip.ptr(V), _hip.ptr(u[s]), _hip.ptr(i[s]),
+                                  _hip.ptr(j[s]), b, 1.0, 1e-3, 1.0, _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(gb), _hip.ptr(gU),
+                                  _hip.ptr(gV), _hip.ptr(loss), _hip.ptr(touch), _hip.ptr(opt.grad) if touch is not None else None,
+                                  st()))
+
+    # classic: one dense launch per step
+    a = DenseAdam(init.clone(), lr=1e-2, track_touch=True)
+    la = torch.zeros(2, device="cuda")
+    for s in range(n_steps):
+        bpr(a, s, la, a.touch)
+        a.step()
+    # blocked
+    c = DenseAdam(init.clone(), lr=1e-2)
+    lc = torch.zeros(2, device="cuda")
+    for s0 in range(0, n_steps, k):
+        kk = min(k, n_steps - s0)
+        uu, ii, jj = (t[s0:s0 + kk].reshape(-1) for t in (u, i, j))
+        c.begin_block(torch.cat([uu, ii + nU, jj + nU, (ii >> 6) + (nU + nI), (jj >> 6) + (nU + nI)]), kk)
+        for s in range(s0, s0 + kk):
+            bpr(c, s, lc, None)
+            c.hot_step()
+    c.end_blocks()
+    torch.cuda.synchronize()
+    assert c.t == a.t == n_steps
+    assert int((a.flat != c.flat).sum()) == 0
+    assert torch.equal(a.m, c.m) and torch.equal(a.v, c.v)
+    assert float(c.grad.abs().max()) == 0.0          # every gradient was consumed
+    # the losses are sums of atomically accumulated terms: equal up to summation order
+    np.testing.assert_allclose(la.cpu().numpy(), lc.cpu().numpy(), rtol=1e-5)
