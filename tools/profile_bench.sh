@@ -6,7 +6,7 @@
 # PMC passes never carry --stats / sys-trace flags.  Outputs land under gpurun_out/prof_<tag>/.
 TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
-ARGS="--steps 100 --warmup 10 --no-cpu-baseline"
+ARGS="--steps 104 --warmup 8 --no-cpu-baseline"   # multiples of the Adam block (8)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o stats -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_$TAG.stats.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_$TAG -o fetch -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_$TAG.fetch.log 2>&1 &&
