@@ -311,15 +311,27 @@ def main():
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)] \
             if events is not None else None
         if kblk > 1:
-            # N = 1: temporally blocked dense Adam (csrc/train.hip K2b; what skrec.recommender.BPRMF.train_epoch does).
+            # Temporally blocked dense Adam (csrc/train.hip K2b; at N = 1 what skrec.recommender.BPRMF.train_epoch does).
             # Per block of kblk steps: rows no batch of the block touches get their kblk zero-gradient updates in ONE
             # pass (adam_cold_kernel), touched rows get the ordinary update after every batch (adam_hot_kernel).
             # Every parameter receives every update in the same arithmetic -- bit-identical to a dense launch per step.
             for s0 in range(0, n_steps, kblk):
                 kk = min(kblk, n_steps - s0)
                 lo, hi = s0 * b, (s0 + kk) * b
-                bi, bj = ii[lo:hi], jj[lo:hi]
-                blk = torch.cat([uu[lo:hi], bi + nU, bj + nU, (bi >> 6) + (nU + nI), (bj >> 6) + (nU + nI)])
+                if world > 1:
+                    # the item table is replicated: its hot rows are those ANY rank's batches of the block touch -- the
+                    # ranks exchange the block's item ids once (kk * 2b int32 each), then every rank tags the same item rows
+                    mine = torch.cat([ii[lo:hi], jj[lo:hi]])
+                    every = torch.empty((world, mine.numel()), dtype=torch.int32, device=dev)
+                    if gather_into:
+                        dist.all_gather_into_tensor(every, mine)
+                    else:
+                        dist.all_gather([every[r] for r in range(world)], mine)
+                    every = every.view(-1)
+                    blk = torch.cat([uu[lo:hi], every + nU, (every >> 6) + (nU + nI)])
+                else:
+                    bi, bj = ii[lo:hi], jj[lo:hi]
+                    blk = torch.cat([uu[lo:hi], bi + nU, bj + nU, (bi >> 6) + (nU + nI), (bj >> 6) + (nU + nI)])
                 run_slice.serial += 1
                 cur = torch.cuda.current_stream()
                 if run_slice.serial > 1:
@@ -341,6 +353,13 @@ def main():
                     rc |= L.skr_bpr_step(P["U"], P["V"], P["bias"], P["U"], P["V"], pu + o, pi + o, pj + o, b, 1.0, 1e-3, 1.0,
                                          P["gU"], P["gV"], P["gb"], P["gU"], P["gV"], P["loss"], None, None, stream)
                     run_slice.t += 1
+                    if world > 1:   # the step's one exchange: packed item-gradient rows, summed in rank order on every rank
+                        rc |= L.skr_pack_grad_rows(pids + s * 2 * b * 4, 2 * b, P["gV"], P["gb"], D, pack_buf.data_ptr(), stream)
+                        if gather_into:
+                            dist.all_gather_into_tensor(gather_buf, pack_buf)
+                        else:
+                            dist.all_gather(gather_views, pack_buf)
+                        rc |= L.skr_unpack_grad_rows(gather_buf.data_ptr(), 2 * b, world, P["gV"], P["gb"], D, None, None, stream)
                     rc |= L.skr_adam_block_hot(P["flat"], P["grad"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, run_slice.t,
                                                pblk, nblk, 0, 64, blk_claim.data_ptr(), run_slice.t, stream)
                 if rc:
@@ -388,8 +407,8 @@ def main():
         if events is not None:
             events.extend(ev)
     n_user_par = nU * D
-    # SKR_ADAM_BLOCK = k (default 8, N = 1 only): look k batches ahead and block the dense Adam over them; 1 = classic
-    kblk = max(1, min(16, int(os.environ.get("SKR_ADAM_BLOCK", "8")))) if world == 1 else 1
+    # SKR_ADAM_BLOCK = k (default 8; N > 1 needs the sparse exchange): look k batches ahead and block the dense Adam; 1 = classic
+    kblk = max(1, min(16, int(os.environ.get("SKR_ADAM_BLOCK", "8")))) if (world == 1 or exchange == "sparse") else 1
     blk_tag = torch.zeros((n_par + 63) // 64, dtype=torch.int32, device=dev)
     blk_claim = torch.zeros_like(blk_tag)
     keep_alive = []
@@ -413,6 +432,7 @@ def main():
                 print(f"[bench] sparse exchange unavailable ({type(e).__name__}: {e}); using the dense all-reduce",
                       file=sys.stderr)
             exchange = "dense"
+            kblk = 1
             touch[nU:] = 2
     P = {k: t.data_ptr() for k, t in dict(U=U, V=V, bias=bias, gU=gU, gV=gV, gb=gb, loss=loss, touch=touch, grad=grad,
                                           flat=flat, m1=m1, m2=m2).items()}
@@ -591,6 +611,13 @@ def main():
             out["cpu_baseline"]["eval_users_per_sec"] = ev_rate
             out["cpu_baseline"]["eval_kind"] = ev_kind
             out["cpu_baseline"]["eval_sample"] = "4 batches of 64 users: torch-CPU matmul + numpy masking + native top-K (4 threads)"
+    if world > 1:
+        # the replicated item table must be bit-identical on every rank after the timed steps
+        chk = torch.stack([V.double().sum(), bias.double().sum(), V.view(torch.int32).long().sum().double()])
+        lo_, hi_ = chk.clone(), chk.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        out["config"]["item_table_replicas_identical"] = bool(torch.equal(lo_, hi_))
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
