@@ -328,7 +328,8 @@ def main():
                     else:
                         dist.all_gather([every[r] for r in range(world)], mine)
                     every = every.view(-1)
-                    blk = torch.cat([uu[lo:hi], every + nU, (every >> 6) + (nU + nI)])
+                    # de-duplicated: at N = 8 the raw list has ~270 k entries for ~70 k distinct blocks, and the hot step walks it
+                    blk = torch.unique(torch.cat([uu[lo:hi], every + nU, (every >> 6) + (nU + nI)]))
                 else:
                     bi, bj = ii[lo:hi], jj[lo:hi]
                     blk = torch.cat([uu[lo:hi], bi + nU, bj + nU, (bi >> 6) + (nU + nI), (bj >> 6) + (nU + nI)])
