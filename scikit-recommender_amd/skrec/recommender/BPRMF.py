@@ -116,12 +116,14 @@ class BPRMF(AbstractRecommender):
         ploss, reg = self.step_losses.data_ptr(), self.config.reg
         kblk = self.adam_block
         if kblk <= 1 or data_iter.num_neg != 1:
-            ptouch, pgrad, pflat, pm, pv = (t.data_ptr() for t in (opt.touch, opt.grad, opt.flat, opt.m, opt.v))
+            pgrad, pflat, pm, pv = (t.data_ptr() for t in (opt.grad, opt.flat, opt.m, opt.v))
+            ptouch = opt.touch.data_ptr() if opt.touch is not None else None    # None: plain dense step, every gradient read
+            pgrad_base = pgrad if ptouch is not None else None
             n_par = opt.flat.numel()
             for k, (u, i, j) in enumerate(data_iter.iter_device()):
                 # slices of the contiguous epoch columns are themselves contiguous (num_neg == 1)
                 rc = L.skr_bpr_step(pU, pV, pb, pU, pV, u.data_ptr(), i.data_ptr(), j.data_ptr(), u.numel(), 1.0, reg, 1.0,
-                                    pgU, pgV, pgb, pgU, pgV, ploss + 8 * k, ptouch, pgrad, st)
+                                    pgU, pgV, pgb, pgU, pgV, ploss + 8 * k, ptouch, pgrad_base, st)
                 opt.t += 1
                 rc |= L.skr_adam_step(pflat, pgrad, pm, pv, n_par, opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.t, 1,
                                       ptouch, st)

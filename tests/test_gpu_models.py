@@ -48,10 +48,14 @@ def _check_reports(got, want, names):
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-4, err_msg=str(names))
 
 
-def test_bprmf_replays_reference(golden, tiny_dir, monkeypatch, tmp_path):
+@pytest.mark.parametrize("adam_block", ["8", "1", "3"])
+def test_bprmf_replays_reference(golden, tiny_dir, monkeypatch, tmp_path, adam_block):
+    """the reference's recorded fit() trajectory, with the temporally blocked Adam (default 8 batches, and 3: blocks
+    that do not divide the epoch) and with one dense launch per step"""
     from skrec.recommender.BPRMF import BPRMF
     from skrec.utils.py.random import reset_global_sampler
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SKR_ADAM_BLOCK", adam_block)
     g = golden("golden_bprmf")
     reset_global_sampler(2020)
     _seed()
