@@ -413,9 +413,9 @@ def main():
     blk_tag = torch.zeros((n_par + 63) // 64, dtype=torch.int32, device=dev)
     blk_claim = torch.zeros_like(blk_tag)
     keep_alive = []
-    # the cold pass may run on a side stream under the small launches (what BPRMF.train_epoch does: +13 % there, where the
-    # batches' rows are spread over the whole tables); on this bench's user-prefix slices it costs 15 %, so it is off here
-    side = torch.cuda.Stream(device=dev) if os.environ.get("SKR_ADAM_OVERLAP", "0") != "0" else torch.cuda.current_stream()
+    # the cold pass (vector-ALU-bound) runs on a side stream underneath the small, latency-bound bpr / hot-step launches
+    # of its block, as in BPRMF.train_epoch: +9 % here, +13 % through the API (SKR_ADAM_OVERLAP=0 turns it off)
+    side = torch.cuda.Stream(device=dev) if os.environ.get("SKR_ADAM_OVERLAP", "1") != "0" else torch.cuda.current_stream()
     ev_marked, ev_cold = torch.cuda.Event(), torch.cuda.Event()
     run_slice.serial = 0
     gather_into = world > 1 and dist.get_backend() == "nccl"    # gloo rehearsals use the list form
@@ -507,6 +507,7 @@ def main():
                            "traffic": pmc_traffic("adam_cold_kernel") if args.users == 1_000_000 else None,
                            "avg_launch_ms": adam_ms, "algorithmic_bytes_per_launch": cold_bytes,
                            "optimizer_steps_per_launch": kblk,
+                           "overlapped_with_step_kernels": side != torch.cuda.current_stream(),
                            "dense_equivalent_GBps": float(n_par) * 28.0 * kblk / (adam_ms * 1e-3) / 1e9}
     else:
         adam_bytes = float(n_par if world == 1 else n_par - nU * D) * 28.0
