@@ -428,7 +428,9 @@ class ShardedBPRMF(object):
         self.user_rows = self.flat[:nl * 64].view(nl, 64)
         self.item_rows = self.flat[nl * 64:(nl + ni) * 64].view(ni, 64)
         self.item_bias = self.flat[(nl + ni) * 64:]
-        self.optimizer = DenseAdam(self.flat, lr=lr, track_touch=True)
+        # SKR_ADAM_BLOCK = k > 1: temporally blocked dense Adam through train_block() (no touch bytes then)
+        self.adam_block = max(1, min(16, int(os.environ.get("SKR_ADAM_BLOCK", "8"))))
+        self.optimizer = DenseAdam(self.flat, lr=lr, track_touch=self.adam_block <= 1)
         g = self.optimizer.grad
         self._gU, self._gV, self._gb = g[:nl * 64].view(nl, 64), g[nl * 64:(nl + ni) * 64].view(ni, 64), g[(nl + ni) * 64:]
         self._g_item = g[nl * 64:]                      # [V | b]: what the ranks exchange
@@ -442,7 +444,7 @@ class ShardedBPRMF(object):
         cap = 2 * int(torch.bincount(users.long() % world, minlength=world).max())   # same number on every rank
         sparse = self.exchange == "sparse" or (self.exchange == "auto" and world * cap * 66 < ni * 65)
         if not sparse:
-            if not self._dense_marked:
+            if opt.touch is not None and not self._dense_marked:
                 opt.touch[self.n_local:] = 2            # summed gradients are dense: always read them
                 self._dense_marked = True
             self.ctx.all_reduce(self._g_item)
@@ -461,10 +463,27 @@ class ShardedBPRMF(object):
         _hip.check(L.skr_pack_grad_rows(_hip.ptr(ids), cap, _hip.ptr(self._gV), _hip.ptr(self._gb), 64, _hip.ptr(pack), st))
         self.ctx.all_gather_rows(gathered, pack)
         _hip.check(L.skr_unpack_grad_rows(_hip.ptr(gathered), cap, world, _hip.ptr(self._gV), _hip.ptr(self._gb), 64,
-                                          _hip.ptr(opt.touch), _hip.ptr(opt.grad), st))
+                                          _hip.ptr(opt.touch), _hip.ptr(opt.grad) if opt.touch is not None else None, st))
 
-    def train_step(self, users, pos, neg):
-        """users/pos/neg: int32 device tensors of the GLOBAL batch, identical on every rank"""
+    def train_block(self, users, pos, neg, bounds, loss_out):
+        """k consecutive GLOBAL batches (``bounds`` = [(start, stop), ...] into the epoch columns users / pos / neg,
+        identical on every rank) with the temporally blocked Adam: every rank sees the whole block, so the hot rows
+        (its own users of the block, every item of the block) are known without communication.  Same results as
+        ``train_step`` per batch.  ``loss_out[i]`` receives the global (bpr sum, l2) of batch i."""
+        world, rank, nl, ni = self.ctx.world, self.ctx.rank, self.n_local, self.num_items
+        lo, hi = bounds[0][0], bounds[-1][1]
+        ub, ib, jb = users[lo:hi], pos[lo:hi], neg[lo:hi]
+        mine = ub[(ub % world) == rank] if world > 1 else ub
+        local = torch.div(mine, world, rounding_mode="floor").int() if world > 1 else mine
+        self.optimizer.begin_block(torch.cat([local, ib + nl, jb + nl, (ib >> 6) + (nl + ni), (jb >> 6) + (nl + ni)]), len(bounds))
+        for k, (a, b) in enumerate(bounds):
+            self._step_grads(users[a:b], pos[a:b], neg[a:b])
+            loss_out[k] = self.loss
+            self.optimizer.hot_step()
+        self.optimizer.end_blocks()
+
+    def _step_grads(self, users, pos, neg):
+        """the gradients of one global batch in the dense buffer (local part computed, item part exchanged)"""
         world, rank = self.ctx.world, self.ctx.rank
         if world > 1:
             sel = (users % world) == rank
@@ -479,11 +498,15 @@ class ShardedBPRMF(object):
                 _hip.ptr(self.user_rows), _hip.ptr(self.item_rows), _hip.ptr(self.item_bias), _hip.ptr(self.user_rows),
                 _hip.ptr(self.item_rows), _hip.ptr(ul), _hip.ptr(il), _hip.ptr(jl), ul.numel(), 1.0, self.reg, 1.0,
                 _hip.ptr(self._gU), _hip.ptr(self._gV), _hip.ptr(self._gb), _hip.ptr(self._gU), _hip.ptr(self._gV),
-                _hip.ptr(self.loss), _hip.ptr(opt.touch), _hip.ptr(opt.grad), _hip.stream()))
+                _hip.ptr(self.loss), _hip.ptr(opt.touch), _hip.ptr(opt.grad) if opt.touch is not None else None, _hip.stream()))
         if world > 1:
             self._exchange_item_grads(users, il, jl)    # the one exchange step
         self.ctx.all_reduce(self.loss)
-        opt.step()
+
+    def train_step(self, users, pos, neg):
+        """users/pos/neg: int32 device tensors of the GLOBAL batch, identical on every rank"""
+        self._step_grads(users, pos, neg)
+        self.optimizer.step()
 
     def gather_user_table(self):
         full = torch.zeros((self.num_users, 64), dtype=torch.float32, device=self.device)

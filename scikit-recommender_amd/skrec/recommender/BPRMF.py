@@ -105,9 +105,15 @@ class BPRMF(AbstractRecommender):
         """one epoch; the per-step host work is two ctypes calls on cached addresses"""
         self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
         if self.engine is not None:   # every rank walks the same global batches and keeps its users
+            eng = self.engine
+            if eng.adam_block > 1 and data_iter.num_neg == 1:
+                (cu, ci, cj), bounds = data_iter.epoch_columns()
+                for s0 in range(0, len(bounds), eng.adam_block):
+                    eng.train_block(cu, ci, cj, bounds[s0:s0 + eng.adam_block], self.step_losses[s0:s0 + eng.adam_block])
+                return
             for k, (u, i, j) in enumerate(data_iter.iter_device()):
-                self.engine.train_step(u, i, j)
-                self.step_losses[k] = self.engine.loss
+                eng.train_step(u, i, j)
+                self.step_losses[k] = eng.loss
             return
         L, st, opt = _hip.lib(), _hip.stream(), self.optimizer
         gU, gV, gb = self._grads

@@ -141,8 +141,9 @@ def test_lightgcn_fit_under_torchrun_contract(tiny_dir, tmp_path):
 
 
 def _bprmf_worker(rank, world, port, data_dir, workdir, exchange, ret):
+    exchange, _, adam_block = exchange.partition("/")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
-                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo", SKR_EXCHANGE=exchange)
+                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo", SKR_EXCHANGE=exchange, SKR_ADAM_BLOCK=adam_block or "8")
     os.chdir(workdir)
     import random
     from skrec import RunConfig
@@ -175,10 +176,11 @@ def _bprmf_worker(rank, world, port, data_dir, workdir, exchange, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "sparse"), (3, "sparse"), (3, "auto")])
+@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "sparse"), (3, "sparse"), (3, "auto"), (2, "sparse/1"), (2, "dense/3")])
 def test_bprmf_fit_under_torchrun_contract(world, exchange, tiny_dir, tmp_path):
     """BPRMF.fit() on N ranks (global batch 256 split by user ownership; item gradients summed either by a
-    dense all-reduce or by the packed-row all-gather) == the reference's single-process run"""
+    dense all-reduce or by the packed-row all-gather; Adam blocked over 8 / 3 batches or stepped per batch ("/1"))
+    == the reference's single-process run"""
     g = np.load(os.path.join(GOLDEN, "golden_bprmf.npz"))
     with mp.Manager() as mgr:
         ret = mgr.dict()
