@@ -144,12 +144,22 @@ class BPRMF(AbstractRecommender):
         nu, ni = self.num_users, self.num_items
         pcu, pci, pcj = cu.data_ptr(), ci.data_ptr(), cj.data_ptr()
         bpr = L.skr_bpr_step
+
+        def block_ids(u_, i_, j_, dim):
+            # 64-float blocks of the flat [U | V | b] buffer the batches touch: user rows, item rows, bias words
+            return torch.cat([u_, i_ + nu, j_ + nu, (i_ >> 6) + (nu + ni), (j_ >> 6) + (nu + ni)], dim=dim)
+        # all full blocks of the epoch at once (one row of ids per block): no per-block tensor arithmetic in the loop
+        bsz = self.config.batch_size
+        n_full_blocks = (len(cu) // bsz) // kblk
+        rows = n_full_blocks * kblk * bsz
+        ids_all = block_ids(*(c[:rows].view(n_full_blocks, kblk * bsz) for c in (cu, ci, cj)), dim=1) if n_full_blocks else None
         for s0 in range(0, len(bounds), kblk):
             blk = bounds[s0:s0 + kblk]
             lo, hi = blk[0][0], blk[-1][1]
-            ii, jj = ci[lo:hi], cj[lo:hi]
-            # 64-float blocks of the flat [U | V | b] buffer the block's batches touch: user rows, item rows, bias words
-            opt.begin_block(torch.cat([cu[lo:hi], ii + nu, jj + nu, (ii >> 6) + (nu + ni), (jj >> 6) + (nu + ni)]), len(blk))
+            if s0 // kblk < n_full_blocks:
+                opt.begin_block(ids_all[s0 // kblk], len(blk))
+            else:
+                opt.begin_block(block_ids(cu[lo:hi], ci[lo:hi], cj[lo:hi], 0), len(blk))
             hot, pp, pg, pm, pv, n_par, pids, nids, pclaim, _ = opt._hot
             lr, b1, b2, eps, t = opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.t
             rc = 0
