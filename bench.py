@@ -208,6 +208,8 @@ def lightgcn_main(args, world, rank, dev, dist, full):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["bprmf", "lightgcn"], default="bprmf")
+    ap.add_argument("--start-step", type=int, default=0, help="optimiser step count the run starts from (0 = a fresh model; "
+                    "past ~16 600 steps Adam's second bias correction is exactly 1 and its division is skipped)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -437,7 +439,7 @@ def main():
             touch[nU:] = 2
     P = {k: t.data_ptr() for k, t in dict(U=U, V=V, bias=bias, gU=gU, gV=gV, gb=gb, loss=loss, touch=touch, grad=grad,
                                           flat=flat, m1=m1, m2=m2).items()}
-    run_slice.t = 0
+    run_slice.t = int(args.start_step)
 
     def barrier():
         if world > 1:

@@ -115,6 +115,15 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p = p + (a.neg_step_size * m) / denom;      // addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+// the same update when sqrt(1 - beta2^t) is exactly 1.0f (beta2 = 0.999: from step ~16 600 on): x / 1.0f == x, so the
+// correctly rounded division by the bias correction (a dozen instructions) is left out -- results are identical
+__device__ __forceinline__ void adam_elem_unit_bc2(float& p, float g, float& m, float& v, const AdamArgs& a) {
+    m = m + a.one_minus_b1 * (g - m);
+    v = v * a.b2 + (a.one_minus_b2 * g) * g;
+    const float denom = sqrtf(v) + a.eps;
+    p = p + (a.neg_step_size * m) / denom;
+}
+
 template <bool TOUCH, int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, AdamArgs a, int zero_grad,
@@ -408,10 +417,17 @@ __global__ __launch_bounds__(256) void adam_cold_kernel(float* __restrict__ p, f
     auto steps4 = [&](float4& pp, float4& mm, float4& vv) {
         for (int s = 0; s < a.k; ++s) {
             AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
-            adam_elem(pp.x, 0.0f, mm.x, vv.x, one);
-            adam_elem(pp.y, 0.0f, mm.y, vv.y, one);
-            adam_elem(pp.z, 0.0f, mm.z, vv.z, one);
-            adam_elem(pp.w, 0.0f, mm.w, vv.w, one);
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(one.bc2_sqrt)) == 0x3f800000) {   // scalar branch, not a select
+                adam_elem_unit_bc2(pp.x, 0.0f, mm.x, vv.x, one);
+                adam_elem_unit_bc2(pp.y, 0.0f, mm.y, vv.y, one);
+                adam_elem_unit_bc2(pp.z, 0.0f, mm.z, vv.z, one);
+                adam_elem_unit_bc2(pp.w, 0.0f, mm.w, vv.w, one);
+            } else {
+                adam_elem(pp.x, 0.0f, mm.x, vv.x, one);
+                adam_elem(pp.y, 0.0f, mm.y, vv.y, one);
+                adam_elem(pp.z, 0.0f, mm.z, vv.z, one);
+                adam_elem(pp.w, 0.0f, mm.w, vv.w, one);
+            }
         }
     };
     for (int64_t i0 = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i0 < n4; i0 += stride * UNROLL) {

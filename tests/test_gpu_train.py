@@ -196,8 +196,8 @@ def test_gather_axpy_scale():
     _close(y.cpu().numpy(), (T + np.float32(0.5) * T) * np.float32(3.0), rtol=1e-6)
 
 
-@pytest.mark.parametrize("k,n_steps", [(8, 37), (1, 5), (16, 16), (3, 10)])
-def test_blocked_adam_is_bit_identical(k, n_steps):
+@pytest.mark.parametrize("k,n_steps,t0", [(8, 37, 0), (1, 5, 0), (16, 16, 0), (3, 10, 0), (8, 20, 16595), (8, 16, 40000)])
+def test_blocked_adam_is_bit_identical(k, n_steps, t0):
     """temporally blocked dense Adam (cold blocks: k zero-gradient updates in one pass; hot blocks: the ordinary
     update every step) == skr_adam_step after every batch, BIT FOR BIT: parameters and both moments"""
     import torch
@@ -227,13 +227,17 @@ def test_blocked_adam_is_bit_identical(k, n_steps):
                                   st()))
 
     # classic: one dense launch per step
+    # t0: optimiser steps already taken (around 16 600 the second bias correction becomes exactly 1.0f and both forms
+    # drop its division; the block starting at 16 595 straddles that point)
     a = DenseAdam(init.clone(), lr=1e-2, track_touch=True)
+    a.t = t0
     la = torch.zeros(2, device="cuda")
     for s in range(n_steps):
         bpr(a, s, la, a.touch)
         a.step()
     # blocked
     c = DenseAdam(init.clone(), lr=1e-2)
+    c.t = t0
     lc = torch.zeros(2, device="cuda")
     for s0 in range(0, n_steps, k):
         kk = min(k, n_steps - s0)
@@ -244,7 +248,7 @@ def test_blocked_adam_is_bit_identical(k, n_steps):
             c.hot_step()
     c.end_blocks()
     torch.cuda.synchronize()
-    assert c.t == a.t == n_steps
+    assert c.t == a.t == t0 + n_steps
     assert int((a.flat != c.flat).sum()) == 0
     assert torch.equal(a.m, c.m) and torch.equal(a.v, c.v)
     assert float(c.grad.abs().max()) == 0.0          # every gradient was consumed
