@@ -333,13 +333,16 @@ def main():
                     # de-duplicated: at N = 8 the raw list has ~270 k entries for ~70 k distinct blocks, and the hot step walks it
                     blk = torch.unique(torch.cat([uu[lo:hi], every + nU, (every >> 6) + (nU + nI)]))
                 else:
-                    bi, bj = ii[lo:hi], jj[lo:hi]
-                    blk = torch.cat([uu[lo:hi], bi + nU, bj + nU, (bi >> 6) + (nU + nI), (bj >> 6) + (nU + nI)])
+                    # step-major (5b entries per step): a hot step names the rows of its own batch and of the next one
+                    ub, bi, bj = uu[lo:hi].view(kk, b), ii[lo:hi].view(kk, b), jj[lo:hi].view(kk, b)
+                    blk = torch.cat([ub, bi + nU, bj + nU, (bi >> 6) + (nU + nI), (bj >> 6) + (nU + nI)], dim=1).view(-1)
                 run_slice.serial += 1
                 cur = torch.cuda.current_stream()
                 if run_slice.serial > 1:
                     cur.wait_event(ev_cold)      # the previous cold pass still reads the tags / writes cold rows
-                rc = L.skr_adam_block_mark(blk.data_ptr(), blk.numel(), 0, 64, blk_tag.data_ptr(), run_slice.serial, stream)
+                t0 = run_slice.t
+                rc = L.skr_adam_block_mark(blk.data_ptr(), blk.numel(), 0, 64, blk_tag.data_ptr(), run_slice.serial,
+                                           blk_claim.data_ptr(), t0, stream)
                 # the cold pass touches no row this block's batches read or write: side stream, under the small launches
                 ev_marked.record(cur)
                 side.wait_event(ev_marked)
@@ -363,8 +366,12 @@ def main():
                         else:
                             dist.all_gather(gather_views, pack_buf)
                         rc |= L.skr_unpack_grad_rows(gather_buf.data_ptr(), 2 * b, world, P["gV"], P["gb"], D, None, None, stream)
-                    rc |= L.skr_adam_block_hot(P["flat"], P["grad"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, run_slice.t,
-                                               pblk, nblk, 0, 64, blk_claim.data_ptr(), run_slice.t, stream)
+                    if world == 1 and s < s0 + kk - 1:      # the block's last step names every hot row: all end at t0 + kk
+                        rc |= L.skr_adam_block_hot(P["flat"], P["grad"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, t0,
+                                                   run_slice.t, pblk + 4 * 5 * b * (s - s0), 10 * b, 0, 64, blk_claim.data_ptr(), stream)
+                    else:
+                        rc |= L.skr_adam_block_hot(P["flat"], P["grad"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, t0,
+                                                   run_slice.t, pblk, nblk, 0, 64, blk_claim.data_ptr(), stream)
                 if rc:
                     _hip.check(rc)
                 keep_alive.append(blk)

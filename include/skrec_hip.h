@@ -245,19 +245,35 @@ int skr_scale(float a, float* d_x, int64_t n, void* stream);                 /* 
  * batches are: data_iterator.py:230-234).  64-float blocks of the flat buffer that none of the k steps touches get
  * their k zero-gradient updates in ONE pass; touched blocks get the ordinary update at every step.  Every
  * parameter receives every update in the arithmetic of skr_adam_step: the results are bit-identical.
- *   skr_adam_block_mark   d_tag[(offset + id*stride) >> 6] = tag_value for every id (call once per id list:
- *                         user rows offset 0 stride 64, item rows offset U*64, bias offset (U+I)*64 stride 1)
+ *   skr_adam_block_mark   d_tag[(offset + id*stride) >> 6] = tag_value and d_claim[same] = step_t0 for every id (call
+ *                         once per id list: user rows offset 0 stride 64, item rows offset U*64, bias offset
+ *                         (U+I)*64 stride 1).  step_t0 = optimiser steps taken before the k-step block.
  *   skr_adam_block_cold   steps step_t0+1 .. step_t0+k with zero gradient on every block whose tag != hot_value
- *   skr_adam_block_hot    step step_t on the blocks the ids name, each claimed once (d_claim[block] = claim_value);
- *                         reads and clears their gradient.  Pass the id lists of the WHOLE k-step block at every step.
- *   d_tag, d_claim        int32[ceil(n / 64)], zero-initialised; use a fresh non-zero tag_value / claim_value each time */
+ *   skr_adam_block_hot    ADVANCES the blocks the ids name to step_t (step_t0 < step_t <= step_t0 + 16): a block that
+ *                         d_claim says is at step c gets zero-gradient updates for steps c+1 .. step_t-1 and then
+ *                         step_t's update with its accumulated gradient, which is read and cleared; d_claim becomes
+ *                         step_t (duplicate ids: one wavefront wins).  Either name every hot block at every step, or
+ *                         at step t only the rows of batch t and of batch t+1 (which must read current rows) and
+ *                         every hot block at the LAST step of the k-step block -- all hot blocks must end at
+ *                         step_t0 + k.  Both orders of visiting apply the same updates in the same order.
+ *   d_tag, d_claim        int32[ceil(n / 64)], zero-initialised; use a fresh non-zero tag_value for every k-step block */
 int skr_adam_block_mark(const int32_t* d_ids, int64_t n_ids, int64_t offset_floats, int stride_floats, int32_t* d_tag,
-                        int32_t tag_value, void* stream);
+                        int32_t tag_value, int32_t* d_claim, int64_t step_t0, void* stream);
 int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
                         int64_t step_t0, int k, const int32_t* d_tag, int32_t hot_value, void* stream);
 int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
-                       float eps, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
-                       int stride_floats, int32_t* d_claim, int32_t claim_value, void* stream);
+                       float eps, int64_t step_t0, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
+                       int stride_floats, int32_t* d_claim, void* stream);
+
+/* The cold pass sorts each 64-float block, by the values it starts from, into one of three exact evaluations of
+ * the same k updates: AT REST (the update provably rounds to p + q == p for all k steps: only the moments decay),
+ * ORDINARY MAGNITUDES (square root and divisions without the scaling / fix-up steps that cannot act there), or the
+ * general form.  skr_selftest_cold_math checks the second one's building blocks against the compiler's sqrtf and
+ * division on the device.  h_mismatches (uint64[4], host): [0] differing results of the square root over EVERY float
+ * in [2^-96, FLT_MAX], [1] of the division over n_pairs hashed (n, d) pairs of its range -- both must be 0;
+ * [2] control: how often the raw v_sqrt_f32 differs from sqrtf over the same floats (> 0), [3] floats enumerated.
+ * (Test hook; synchronises the stream.) */
+int skr_selftest_cold_math(uint64_t n_pairs, uint64_t* h_mismatches, void* stream);
 
 /* Sparse exchange of a replicated table's gradient between ranks (no reference counterpart -- the
  * reference is single-process).  A BPR step touches at most 2*batch item rows, so instead of all-reducing the

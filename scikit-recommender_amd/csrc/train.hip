@@ -11,7 +11,9 @@
 // 256-byte global_atomic_add_f32 per row (the shape the memory-side atomic units like).
 #include "skr_common.h"
 
+#include <climits>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -378,12 +380,22 @@ struct AdamBlockArgs {
     float one_minus_b1, b2, one_minus_b2, eps;
     float neg_step_size[AB_KMAX], bc2_sqrt[AB_KMAX];
     int k;
+    // thresholds of the "parameter at rest" test of adam_cold_rows_kernel (0 switches the test off)
+    float rest_eps;   // 2^-28 * eps
+    float rest_b2k;   // a lower bound of beta2^k
+    // ranges of the "ordinary magnitudes" test (fast_mlo = +inf switches it off)
+    float fast_vlo, fast_mlo, fast_mhi;
 };
 
 __global__ __launch_bounds__(256) void adam_mark_kernel(const int32_t* __restrict__ ids, int64_t n, int64_t offset,
-                                                        int stride, int32_t* __restrict__ tag, int32_t value) {
+                                                        int stride, int32_t* __restrict__ tag, int32_t value,
+                                                        int32_t* __restrict__ claim, int32_t claim_value) {
     const int64_t g = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-    if (g < n) tag[(offset + static_cast<int64_t>(ids[g]) * stride) >> 6] = value;
+    if (g < n) {
+        const int64_t blk = (offset + static_cast<int64_t>(ids[g]) * stride) >> 6;
+        tag[blk] = value;
+        if (claim) claim[blk] = claim_value;
+    }
 }
 
 // cold pass: every float4 whose 64-float block is not tagged gets k zero-gradient updates
@@ -459,23 +471,232 @@ __global__ __launch_bounds__(256) void adam_cold_kernel(float* __restrict__ p, f
         if (tag[i >> 6] != hot_value) steps(p[i], m[i], v[i]);
 }
 
-// hot step: one wavefront per id; the block it names is claimed once per step and gets the ordinary update
+// Square root and division for ORDINARY MAGNITUDES, bit-identical to sqrtf(x) and n / d as compiled under
+// -fhip-fp32-correctly-rounded-divide-sqrt but cheaper:
+//   div_ordinary   the compiler's own expansion (v_rcp_f32, one Newton step, two quotient corrections, final fma)
+//                  minus v_div_scale_f32 and v_div_fixup_f32, which are the identity (VCC = 0) / a pass-through when
+//                  d is normal with |d| < 2^126, |n| >= 2^-103 and -125 <= exponent(n) - exponent(d) < 96
+//                  (CDNA3/4 ISA, V_DIV_SCALE_F32 / V_DIV_FIXUP_F32): same instructions on the same values;
+//   sqrt_ordinary  v_rsq_f32 and one fused correction s + (x - s*s) * r/2 instead of v_sqrt_f32 and two residual tests:
+//                  a different route to the correctly rounded root, so it is PROVEN BY ENUMERATION -- the self-test runs
+//                  it against sqrtf on every float of [2^-96, FLT_MAX] (the range it is used on is [2^-90, 2^20]).
+// skr_selftest_cold_math does that enumeration and tries the division on 2^32 hashed operand pairs of its range; as
+// a control it also counts how often the raw v_sqrt_f32 differs from sqrtf (it must: that is why a correction exists).
+__device__ __forceinline__ float sqrt_ordinary(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float s = x * r, h = 0.5f * r;
+    return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+}
+
+__device__ __forceinline__ float div_ordinary(float n, float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = n * r;
+    float t = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(t, r, q);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// one zero-gradient update of two rows of ordinary magnitudes (v > 0, so v*b2 + (c2*0)*0 == v*b2)
+template <bool UNIT_BC2>
+__device__ __forceinline__ void adam_pair_ordinary(f32x2& p, f32x2& m, f32x2& v, const AdamArgs& a) {
+    m = m + a.one_minus_b1 * (0.0f - m);
+    v = v * a.b2;
+    f32x2 sq;
+    sq.x = sqrt_ordinary(v.x);
+    sq.y = sqrt_ordinary(v.y);
+    if (!UNIT_BC2) {
+        sq.x = div_ordinary(sq.x, a.bc2_sqrt);
+        sq.y = div_ordinary(sq.y, a.bc2_sqrt);
+    }
+    const f32x2 d = sq + a.eps, n = a.neg_step_size * m;
+    f32x2 q;
+    q.x = div_ordinary(n.x, d.x);
+    q.y = div_ordinary(n.y, d.y);
+    p = p + q;
+}
+
+__global__ __launch_bounds__(256) void selftest_cold_math_kernel(uint32_t lo, uint32_t hi, uint64_t n_pairs,
+                                                                 unsigned long long* __restrict__ bad) {
+    const uint64_t tid = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    const uint64_t nth = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long bs = 0, bd = 0, b1 = 0, b2 = 0;
+    for (uint64_t b = lo + tid; b <= hi; b += nth) {
+        const float x = __uint_as_float(static_cast<uint32_t>(b));
+        const uint32_t want = __float_as_uint(sqrtf(x));
+        bs += __float_as_uint(sqrt_ordinary(x)) != want;
+        b1 += __float_as_uint(__builtin_amdgcn_sqrtf(x)) != want;   // control
+        b2 += 1;
+    }
+    for (uint64_t i = tid; i < n_pairs; i += nth) {
+        uint64_t h = (i + 1) * 0x9E3779B97F4A7C15ull;   // splitmix64
+        h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+        h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+        h ^= h >> 31;
+        // d: exponent in [-48, 21], n: exponent in [-100, 40], random mantissas and signs
+        const uint32_t hd = static_cast<uint32_t>(h), hn = static_cast<uint32_t>(h >> 32);
+        const uint32_t ed = 127 - 48 + (hd >> 23) % 70, en = 127 - 100 + ((hn >> 23) & 0xff) % 141;
+        const float d = __uint_as_float((hd & 0x807fffffu) | (ed << 23)), n = __uint_as_float((hn & 0x807fffffu) | (en << 23));
+        bd += __float_as_uint(div_ordinary(n, d)) != __float_as_uint(n / d);
+    }
+    if (bs) atomicAdd(&bad[0], bs);
+    if (bd) atomicAdd(&bad[1], bd);
+    if (b1) atomicAdd(&bad[2], b1);
+    if (b2) atomicAdd(&bad[3], b2);
+}
+
+// cold pass, one wavefront per 64-float block (= one embedding row), with a cheap exact path for rows AT REST.
+//
+// A zero-gradient update is p += (nss*m') / (sqrt(v')/bc2 + eps) with m' = m + c1*(0 - m), v' = v*b2.  A row that
+// no batch has touched for a few hundred steps has |m| decayed so far that the quotient q is below a quarter of
+// the spacing of the floats around p: then fl(p + q) == p and the correctly rounded sqrt and divisions (about 36 of
+// the ~41 issue slots of an update) decide nothing.  A block is AT REST for all k updates of the pass when every lane
+// passes, on the values the pass starts from,
+//     sign(v) = +, v not NaN;  |p| >= 2^-60;
+//     |nss[0]*m| < 2^-28 * |p| * eps            or    |nss[0]*m|^2 < 2^-58 * p^2 * v * lb(b2^k)   (and that bound is normal)
+// Proof sketch: |m| and |nss[s]| never grow over the pass and v never drops below v*b2^k, so for every
+// update |n| = |fl(nss[s]*m')| <= |fl(nss[0]*m)| and d = fl(fl(sqrt(v')/bc2) + eps) >= max(eps, sqrt(v*b2^k))*(1 - 2^-22);
+// hence |fl(n/d)| < 2^-27 |p| < spacing(p)/4 and p is unchanged, bit for bit, by each of the k updates.  m and v still get
+// their k decays in the arithmetic of adam_elem (v*b2 + (c2*0)*0 == v*b2 because v*b2 carries a + sign).  The thresholds
+// are zero (tests off) unless 0 < beta1, beta2 < 1, lr > 0, eps >= 0.  Blocks not at rest take adam_elem as before.
+template <int U>
+__global__ __launch_bounds__(256) void adam_cold_rows_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                             float* __restrict__ v, int64_t n, AdamBlockArgs a,
+                                                             const int32_t* __restrict__ tag, int32_t hot_value) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nb = n >> 6;
+    const int64_t n_waves = static_cast<int64_t>(gridDim.x) * 4;
+    const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto general = [&](float& pp, float& mm, float& vv) {
+        for (int s = 0; s < a.k; ++s) {
+            AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(one.bc2_sqrt)) == 0x3f800000)   // scalar branch, not a select
+                adam_elem_unit_bc2(pp, 0.0f, mm, vv, one);
+            else
+                adam_elem(pp, 0.0f, mm, vv, one);
+        }
+    };
+    // two rows of ordinary magnitudes advance together (packed fp32 for the element-wise parts, the two square
+    // root / division chains interleaved): the first waits in `held` until the wavefront meets the second
+    auto ordinary2 = [&](f32x2& p2, f32x2& m2, f32x2& v2) {
+        for (int s = 0; s < a.k; ++s) {
+            AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(one.bc2_sqrt)) == 0x3f800000)
+                adam_pair_ordinary<true>(p2, m2, v2, one);
+            else
+                adam_pair_ordinary<false>(p2, m2, v2, one);
+        }
+    };
+    bool have = false;
+    float hp = 0.0f, hm = 0.0f, hv = 0.0f;
+    int64_t hi = 0;
+    for (int64_t b0 = wave0; b0 < nb; b0 += n_waves * U) {
+        float pp[U], mm[U], vv[U];
+        bool cold[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t b = b0 + u * n_waves;
+            cold[u] = b < nb && tag[b] != hot_value;
+            if (cold[u]) {
+                const int64_t i = (b << 6) + lane;
+                pp[u] = __builtin_nontemporal_load(&p[i]);
+                mm[u] = __builtin_nontemporal_load(&m[i]);
+                vv[u] = __builtin_nontemporal_load(&v[i]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!cold[u]) continue;
+            const int64_t i = ((b0 + u * n_waves) << 6) + lane;
+            const float am = fabsf(mm[u]), ap = fabsf(pp[u]);
+            const float n0 = fabsf(a.neg_step_size[0]) * am;
+            const float r = ap * 0x1p-29f;
+            const float bound = (r * r) * (vv[u] * a.rest_b2k);
+            const bool small = n0 < ap * a.rest_eps || (n0 * n0 < bound && bound >= 0x1p-120f);
+            const bool lane_rest = __float_as_uint(vv[u]) <= 0x7f800000u && ap >= 0x1p-60f && small;
+            if (__builtin_amdgcn_ballot_w64(!lane_rest) == 0) {
+                float m1 = mm[u], v1 = vv[u];
+                for (int s = 0; s < a.k; ++s) {
+                    m1 = m1 + a.one_minus_b1 * (0.0f - m1);
+                    v1 = v1 * a.b2;
+                }
+                if (__builtin_amdgcn_ballot_w64(__float_as_uint(m1) != __float_as_uint(mm[u])) != 0)
+                    __builtin_nontemporal_store(m1, &m[i]);
+                if (__builtin_amdgcn_ballot_w64(__float_as_uint(v1) != __float_as_uint(vv[u])) != 0)
+                    __builtin_nontemporal_store(v1, &v[i]);
+                continue;
+            }
+            const bool lane_ord = vv[u] >= a.fast_vlo && vv[u] <= 0x1p20f && am >= a.fast_mlo && am <= a.fast_mhi;
+            if (__builtin_amdgcn_ballot_w64(!lane_ord) == 0) {
+                if (!have) {
+                    hp = pp[u], hm = mm[u], hv = vv[u], hi = i;
+                    have = true;
+                    continue;
+                }
+                f32x2 p2{hp, pp[u]}, m2{hm, mm[u]}, v2{hv, vv[u]};
+                ordinary2(p2, m2, v2);
+                __builtin_nontemporal_store(p2.x, &p[hi]);
+                __builtin_nontemporal_store(m2.x, &m[hi]);
+                __builtin_nontemporal_store(v2.x, &v[hi]);
+                __builtin_nontemporal_store(p2.y, &p[i]);
+                __builtin_nontemporal_store(m2.y, &m[i]);
+                __builtin_nontemporal_store(v2.y, &v[i]);
+                have = false;
+                continue;
+            }
+            general(pp[u], mm[u], vv[u]);
+            __builtin_nontemporal_store(pp[u], &p[i]);
+            __builtin_nontemporal_store(mm[u], &m[i]);
+            __builtin_nontemporal_store(vv[u], &v[i]);
+        }
+    }
+    if (have) {   // an odd one out
+        general(hp, hm, hv);
+        __builtin_nontemporal_store(hp, &p[hi]);
+        __builtin_nontemporal_store(hm, &m[hi]);
+        __builtin_nontemporal_store(hv, &v[hi]);
+    }
+    // tail (n not a multiple of 64)
+    const int64_t i = (nb << 6) + blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (i < n && tag[nb] != hot_value) general(p[i], m[i], v[i]);
+}
+
+// hot step: one wavefront per id.  claim[block] holds the optimiser step the block has been advanced to (the mark
+// kernel sets it to the step count the k-step block starts from).  The wavefront that raises it to step_t owns the
+// block for this launch and ADVANCES it: zero-gradient updates for the steps it has not seen yet, then step_t's update
+// with the accumulated gradient, which is consumed.  A caller that names every hot block at every step gets one
+// update per launch; a caller that names only the rows of batch t and of batch t+1 (the next batch must READ current
+// rows) visits a row when it matters and catches up there -- the same updates in the same order, fewer passes over
+// HBM.  The last step of a k-step block must name every hot block, so that all of them end at the same step.
 __global__ __launch_bounds__(256) void adam_hot_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                       float* __restrict__ v, int64_t n, AdamArgs a,
-                                                       const int32_t* __restrict__ ids, int64_t n_ids, int64_t offset,
-                                                       int stride, int32_t* __restrict__ claim, int32_t claim_value) {
+                                                       float* __restrict__ v, int64_t n, AdamBlockArgs a, int32_t t0,
+                                                       int32_t t, const int32_t* __restrict__ ids, int64_t n_ids,
+                                                       int64_t offset, int stride, int32_t* __restrict__ claim) {
     const int lane = threadIdx.x & 63;
     const int64_t e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= n_ids) return;
     const int64_t blk = (offset + static_cast<int64_t>(ids[e]) * stride) >> 6;
     int old = 0;
-    if (lane == 0) old = atomicExch(&claim[blk], claim_value);
-    old = __shfl(old, 0, 64);
-    if (old == claim_value) return;
+    if (lane == 0) old = atomicExch(&claim[blk], t);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old >= t) return;
+    if (old < t0) old = t0;
     const int64_t i = blk * 64 + lane;
     if (i < n) {
         float pp = p[i], mm = m[i], vv = v[i];
-        adam_elem(pp, g[i], mm, vv, a);
+        const float gg = g[i];
+        for (int s = old - t0; s < t - t0; ++s) {   // step t0 + s + 1
+            AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
+            const float gs = (s == t - t0 - 1) ? gg : 0.0f;
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(one.bc2_sqrt)) == 0x3f800000)
+                adam_elem_unit_bc2(pp, gs, mm, vv, one);
+            else
+                adam_elem(pp, gs, mm, vv, one);
+        }
         p[i] = pp;
         m[i] = mm;
         v[i] = vv;
@@ -726,12 +947,13 @@ static void adam_scalars(float lr, float beta1, float beta2, int64_t step_t, flo
 }
 
 int skr_adam_block_mark(const int32_t* d_ids, int64_t n_ids, int64_t offset_floats, int stride_floats, int32_t* d_tag,
-                        int32_t tag_value, void* stream) {
+                        int32_t tag_value, int32_t* d_claim, int64_t step_t0, void* stream) {
     SKR_REQUIRE(d_ids && d_tag, "skr_adam_block_mark: NULL argument");
     SKR_REQUIRE(n_ids >= 0 && offset_floats >= 0 && stride_floats >= 1, "skr_adam_block_mark: bad shape");
+    SKR_REQUIRE(step_t0 >= 0 && step_t0 < INT32_MAX - AB_KMAX, "skr_adam_block_mark: step_t0 out of range");
     if (n_ids == 0) return SKR_OK;
     hipLaunchKernelGGL(adam_mark_kernel, dim3(static_cast<unsigned>((n_ids + 255) / 256)), dim3(256), 0, skr::as_stream(stream),
-                       d_ids, n_ids, offset_floats, stride_floats, d_tag, tag_value);
+                       d_ids, n_ids, offset_floats, stride_floats, d_tag, tag_value, d_claim, static_cast<int32_t>(step_t0));
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
@@ -751,30 +973,77 @@ int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr,
     a.k = k;
     for (int s = 0; s < k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s]);
     static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // 8 measured best (tools/adam_block_sweep.sh)
-    int64_t blocks = ((n >> 2) + 255) / 256;
-    if (blocks > 256 * bpc) blocks = 256 * bpc;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_cold_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream), d_p, d_m,
-                       d_v, n, a, d_tag, hot_value);
+    // SKR_COLD_REST=0 keeps every cold block on the full update (the float4 kernel): the A/B switch of tools/microbench.py
+    static const bool rest = [] { const char* e = getenv("SKR_COLD_REST"); return !(e && atoi(e) == 0); }();
+    const bool sane = beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f && lr > 0.0f && eps >= 0.0f &&
+                      std::isfinite(lr) && std::isfinite(eps);
+    a.rest_eps = sane ? eps * 0x1p-28f : 0.0f;
+    a.rest_b2k = sane ? static_cast<float>(std::pow(static_cast<double>(beta2), k) * (1.0 - 1e-4)) : 0.0f;
+    // ordinary magnitudes for all k updates (ranges of sqrt_ordinary / div_ordinary with room to spare): v in
+    // [2^-90, 2^20] throughout, |nss*m| in [2^-100, 2^40] throughout, eps <= 2^20, sqrt(1 - beta2^t) >= 2^-10
+    const double nss_first = std::fabs(static_cast<double>(a.neg_step_size[0])), nss_last = std::fabs(static_cast<double>(a.neg_step_size[k - 1]));
+    const double m_lo = 0x1p-100 / (nss_last * std::pow(static_cast<double>(beta1), k) * 0.99), m_hi = 0x1p40 / nss_first;
+    const bool ord = sane && eps <= 0x1p20f && a.bc2_sqrt[0] >= 0x1p-10f && a.rest_b2k > 0.0f && m_lo < 1e30 && m_hi > 1e-30 &&
+                     std::isfinite(m_lo) && std::isfinite(m_hi);
+    a.fast_vlo = ord ? static_cast<float>(0x1p-90 / static_cast<double>(a.rest_b2k)) : 0.0f;
+    a.fast_mlo = ord ? static_cast<float>(m_lo) : INFINITY;
+    a.fast_mhi = ord ? static_cast<float>(std::fmin(m_hi, 1e38)) : 0.0f;
+    if (rest) {
+        int64_t blocks = ((n >> 6) + 4 * 4 - 1) / (4 * 4);
+        if (blocks > 256 * bpc) blocks = 256 * bpc;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(adam_cold_rows_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream),
+                           d_p, d_m, d_v, n, a, d_tag, hot_value);
+    } else {
+        int64_t blocks = ((n >> 2) + 255) / 256;
+        if (blocks > 256 * bpc) blocks = 256 * bpc;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(adam_cold_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream), d_p,
+                           d_m, d_v, n, a, d_tag, hot_value);
+    }
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
 
 int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
-                       float eps, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
-                       int stride_floats, int32_t* d_claim, int32_t claim_value, void* stream) {
+                       float eps, int64_t step_t0, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
+                       int stride_floats, int32_t* d_claim, void* stream) {
     SKR_REQUIRE(d_p && d_g && d_m && d_v && d_ids && d_claim, "skr_adam_block_hot: NULL argument");
-    SKR_REQUIRE(n >= 0 && step_t >= 1 && n_ids >= 0 && offset_floats >= 0 && stride_floats >= 1, "skr_adam_block_hot: bad shape");
+    SKR_REQUIRE(n >= 0 && step_t0 >= 0 && step_t > step_t0 && step_t - step_t0 <= AB_KMAX && step_t < INT32_MAX,
+                "skr_adam_block_hot: need step_t0 < step_t <= step_t0 + %d", AB_KMAX);
+    SKR_REQUIRE(n_ids >= 0 && offset_floats >= 0 && stride_floats >= 1, "skr_adam_block_hot: bad shape");
     if (n_ids == 0) return SKR_OK;
-    AdamArgs a;
+    AdamBlockArgs a{};
     a.one_minus_b1 = static_cast<float>(1.0 - static_cast<double>(beta1));
     a.b2 = beta2;
     a.one_minus_b2 = static_cast<float>(1.0 - static_cast<double>(beta2));
     a.eps = eps;
-    adam_scalars(lr, beta1, beta2, step_t, &a.neg_step_size, &a.bc2_sqrt);
+    a.k = static_cast<int>(step_t - step_t0);
+    for (int s = 0; s < a.k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s]);
     hipLaunchKernelGGL(adam_hot_kernel, dim3(static_cast<unsigned>((n_ids + 3) / 4)), dim3(256), 0, skr::as_stream(stream), d_p,
-                       d_g, d_m, d_v, n, a, d_ids, n_ids, offset_floats, stride_floats, d_claim, claim_value);
+                       d_g, d_m, d_v, n, a, static_cast<int32_t>(step_t0), static_cast<int32_t>(step_t), d_ids, n_ids,
+                       offset_floats, stride_floats, d_claim);
     SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_selftest_cold_math(uint64_t n_pairs, uint64_t* h_mismatches, void* stream) {
+    SKR_REQUIRE(h_mismatches, "skr_selftest_cold_math: NULL argument");
+    unsigned long long* d_bad = nullptr;
+    SKR_HIP(hipMalloc(&d_bad, 4 * sizeof(unsigned long long)));
+    SKR_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(unsigned long long), skr::as_stream(stream)));
+    // square root: every float in [2^-96, largest finite]
+    hipLaunchKernelGGL(selftest_cold_math_kernel, dim3(256 * 8), dim3(256), 0, skr::as_stream(stream), 0x0f800000u, 0x7f7fffffu,
+                       n_pairs, d_bad);
+    SKR_LAUNCH_CHECK();
+    unsigned long long h[4] = {0, 0, 0, 0};
+    SKR_HIP(hipMemcpyAsync(h, d_bad, sizeof(h), hipMemcpyDeviceToHost, skr::as_stream(stream)));
+    SKR_HIP(hipStreamSynchronize(skr::as_stream(stream)));
+    (void)hipFree(d_bad);
+    h_mismatches[0] = h[0];
+    h_mismatches[1] = h[1];
+    h_mismatches[2] = h[2];
+    h_mismatches[3] = h[3];
     return SKR_OK;
 }
 

@@ -32,9 +32,10 @@ SIGNATURES = {
     "skr_sample_epoch_exact": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, vp]),
     "skr_sample_epoch_exact_counts": (i32, [vp, i32, i32, vp, vp, i64, vp, i64, vp, vp]),
     "skr_sample_epoch_fast": (i32, [u64, u64, i64, i32, i32, vp, vp, i64, i32, vp, vp]),
-    "skr_adam_block_mark": (i32, [vp, i64, i64, i32, vp, i32, vp]),
+    "skr_adam_block_mark": (i32, [vp, i64, i64, i32, vp, i32, vp, i64, vp]),
     "skr_adam_block_cold": (i32, [vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, i32, vp]),
-    "skr_adam_block_hot": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, i64, i64, i32, vp, i32, vp]),
+    "skr_adam_block_hot": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i64, vp, i64, i64, i32, vp, vp]),
+    "skr_selftest_cold_math": (i32, [u64, C.POINTER(u64), vp]),
     "skr_pack_grad_rows": (i32, [vp, i32, vp, vp, i32, vp, vp]),
     "skr_unpack_grad_rows": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp]),
     "skr_gru_cell_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),

@@ -148,26 +148,31 @@ class BPRMF(AbstractRecommender):
         def block_ids(u_, i_, j_, dim):
             # 64-float blocks of the flat [U | V | b] buffer the batches touch: user rows, item rows, bias words
             return torch.cat([u_, i_ + nu, j_ + nu, (i_ >> 6) + (nu + ni), (j_ >> 6) + (nu + ni)], dim=dim)
-        # all full blocks of the epoch at once (one row of ids per block): no per-block tensor arithmetic in the loop
+        # all full blocks of the epoch at once (one row of ids per block, step-major: 5 * batch entries per step): no
+        # per-block tensor arithmetic in the loop, and a hot step can name just its own and the next batch's rows
         bsz = self.config.batch_size
         n_full_blocks = (len(cu) // bsz) // kblk
         rows = n_full_blocks * kblk * bsz
-        ids_all = block_ids(*(c[:rows].view(n_full_blocks, kblk * bsz) for c in (cu, ci, cj)), dim=1) if n_full_blocks else None
+        ids_all = block_ids(*(c[:rows].view(n_full_blocks, kblk, bsz) for c in (cu, ci, cj)), dim=2).view(n_full_blocks, -1) \
+            if n_full_blocks else None
         for s0 in range(0, len(bounds), kblk):
             blk = bounds[s0:s0 + kblk]
             lo, hi = blk[0][0], blk[-1][1]
             if s0 // kblk < n_full_blocks:
-                opt.begin_block(ids_all[s0 // kblk], len(blk))
+                opt.begin_block(ids_all[s0 // kblk], len(blk), per_step=5 * bsz)
             else:
                 opt.begin_block(block_ids(cu[lo:hi], ci[lo:hi], cj[lo:hi], 0), len(blk))
-            hot, pp, pg, pm, pv, n_par, pids, nids, pclaim, _ = opt._hot
+            hot, pp, pg, pm, pv, n_par, pids, nids, pclaim, _, t0, kk, per = opt._hot
             lr, b1, b2, eps, t = opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.t
             rc = 0
             for k, (a, b) in enumerate(blk, start=s0):      # two launches per step, on cached integer addresses
                 t += 1
                 rc |= bpr(pU, pV, pb, pU, pV, pcu + 4 * a, pci + 4 * a, pcj + 4 * a, b - a, 1.0, reg, 1.0,
                           pgU, pgV, pgb, pgU, pgV, ploss + 8 * k, None, None, st)
-                rc |= hot(pp, pg, pm, pv, n_par, lr, b1, b2, eps, t, pids, nids, 0, 64, pclaim, t, st)
+                if per is not None and t < t0 + kk:         # rows of this batch and of the next; the last step names all
+                    rc |= hot(pp, pg, pm, pv, n_par, lr, b1, b2, eps, t0, t, pids + 4 * per * (t - t0 - 1), 2 * per, 0, 64, pclaim, st)
+                else:
+                    rc |= hot(pp, pg, pm, pv, n_par, lr, b1, b2, eps, t0, t, pids, nids, 0, 64, pclaim, st)
             opt.t = t
             if rc:
                 _hip.check(rc)

@@ -78,10 +78,14 @@ class DenseAdam(object):
         self.t = 0
 
     # ---- temporally blocked stepping (bit-identical to step() after every batch) -----------------------------
-    def begin_block(self, block_ids, k):
+    def begin_block(self, block_ids, k, per_step=None):
         """``block_ids``: int32 device tensor with the index (float offset / 64) of every 64-float block that any
         of the coming k steps touches, duplicates allowed.  Tags those blocks and gives every OTHER block its k
-        zero-gradient updates in one pass; ``hot_step()`` must then be called once per step, k times."""
+        zero-gradient updates in one pass; ``hot_step()`` must then be called once per step, k times.
+
+        ``per_step``: the list is step-major with this many entries per step (k * per_step in all).  A hot step then
+        visits only the rows of its own batch and of the next one (which is about to read them) and lets every other
+        hot row catch up when its turn comes; the k-th step visits all of them.  Same updates, same order."""
         import torch
         from .. import _hip
         L, st = _hip.lib(), _hip.stream()
@@ -97,12 +101,13 @@ class DenseAdam(object):
             self._ev_marked, self._ev_cold = torch.cuda.Event(), torch.cuda.Event()
         else:
             cur.wait_event(self._ev_cold)    # the previous block's cold pass still reads the tags and writes cold rows
+        assert per_step is None or block_ids.numel() == int(k) * int(per_step)
         self._blk_serial += 1
         self._blk_ids = block_ids           # kept alive until the block is done
         _hip.check(L.skr_adam_block_mark(_hip.ptr(block_ids), block_ids.numel(), 0, 64, _hip.ptr(self._blk_tag),
-                                         self._blk_serial, st))
-        # the cold pass (ALU-bound: k correctly rounded sqrt/divide chains per element) touches no row the block's
-        # batches read or write, so it runs on a side stream underneath the k small bpr / hot-step launches
+                                         self._blk_serial, _hip.ptr(self._blk_claim), self.t, st))
+        # the cold pass touches no row the block's batches read or write, so it runs on a side stream underneath the
+        # k small bpr / hot-step launches
         self._ev_marked.record(cur)
         self._side.wait_event(self._ev_marked)
         _hip.check(L.skr_adam_block_cold(_hip.ptr(self.flat), _hip.ptr(self.m), _hip.ptr(self.v), self.flat.numel(), self.lr,
@@ -110,7 +115,8 @@ class DenseAdam(object):
                                          self._blk_serial, self._side.cuda_stream))
         self._ev_cold.record(self._side)
         self._hot = (L.skr_adam_block_hot, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                     self.flat.numel(), block_ids.data_ptr(), block_ids.numel(), self._blk_claim.data_ptr(), st)
+                     self.flat.numel(), block_ids.data_ptr(), block_ids.numel(), self._blk_claim.data_ptr(), st,
+                     self.t, int(k), None if per_step is None else int(per_step))
 
     def end_blocks(self):
         """join the side stream: call after the last block, before anything else reads the parameters"""
@@ -119,10 +125,13 @@ class DenseAdam(object):
             torch.cuda.current_stream().wait_event(self._ev_cold)
 
     def hot_step(self):
-        """the ordinary update of this step on the blocks tagged by begin_block (their gradients are consumed)"""
-        fn, pp, pg, pm, pv, n, pids, nids, pclaim, st = self._hot
+        """this step's update of the hot blocks (see begin_block); their gradients are consumed"""
+        fn, pp, pg, pm, pv, n, pids, nids, pclaim, st, t0, k, per = self._hot
         self.t += 1
-        rc = fn(pp, pg, pm, pv, n, self.lr, self.betas[0], self.betas[1], self.eps, self.t, pids, nids, 0, 64, pclaim, self.t, st)
+        s = self.t - t0 - 1                      # step inside the block
+        if per is not None and s < k - 1:        # rows of batch s and of batch s + 1
+            pids, nids = pids + 4 * s * per, 2 * per
+        rc = fn(pp, pg, pm, pv, n, self.lr, self.betas[0], self.betas[1], self.eps, t0, self.t, pids, nids, 0, 64, pclaim, st)
         if rc:
             from .. import _hip
             _hip.check(rc)

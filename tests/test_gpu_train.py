@@ -196,10 +196,12 @@ def test_gather_axpy_scale():
     _close(y.cpu().numpy(), (T + np.float32(0.5) * T) * np.float32(3.0), rtol=1e-6)
 
 
+@pytest.mark.parametrize("lazy", [True, False])
 @pytest.mark.parametrize("k,n_steps,t0", [(8, 37, 0), (1, 5, 0), (16, 16, 0), (3, 10, 0), (8, 20, 16595), (8, 16, 40000)])
-def test_blocked_adam_is_bit_identical(k, n_steps, t0):
+def test_blocked_adam_is_bit_identical(k, n_steps, t0, lazy):
     """temporally blocked dense Adam (cold blocks: k zero-gradient updates in one pass; hot blocks: the ordinary
-    update every step) == skr_adam_step after every batch, BIT FOR BIT: parameters and both moments"""
+    update every step -- or, `lazy`, when a batch is about to read them / has written their gradient, catching up
+    on the zero-gradient steps in between) == skr_adam_step after every batch, BIT FOR BIT: parameters and both moments"""
     import torch
     from skrec import _hip
     from skrec.recommender.base import DenseAdam
@@ -241,8 +243,9 @@ def test_blocked_adam_is_bit_identical(k, n_steps, t0):
     lc = torch.zeros(2, device="cuda")
     for s0 in range(0, n_steps, k):
         kk = min(k, n_steps - s0)
-        uu, ii, jj = (t[s0:s0 + kk].reshape(-1) for t in (u, i, j))
-        c.begin_block(torch.cat([uu, ii + nU, jj + nU, (ii >> 6) + (nU + nI), (jj >> 6) + (nU + nI)]), kk)
+        uu, ii, jj = (t[s0:s0 + kk] for t in (u, i, j))                  # [kk, b] each: step-major after the cat on dim 1
+        ids = torch.cat([uu, ii + nU, jj + nU, (ii >> 6) + (nU + nI), (jj >> 6) + (nU + nI)], dim=1).reshape(-1)
+        c.begin_block(ids, kk, per_step=5 * b if lazy else None)
         for s in range(s0, s0 + kk):
             bpr(c, s, lc, None)
             c.hot_step()
@@ -254,3 +257,84 @@ def test_blocked_adam_is_bit_identical(k, n_steps, t0):
     assert float(c.grad.abs().max()) == 0.0          # every gradient was consumed
     # the losses are sums of atomically accumulated terms: equal up to summation order
     np.testing.assert_allclose(la.cpu().numpy(), lc.cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,t0,eps,lr", [(8, 0, 1e-8, 1e-3), (16, 20000, 1e-8, 1e-3), (5, 16596, 1e-8, 5e-2), (8, 100, 0.0, 1e-3),
+                                         (8, 3, 1e-3, 1e-3)])
+def test_cold_pass_rest_regime_is_bit_identical(k, t0, eps, lr):
+    """cold pass (rows at rest skip the square root and the divisions of the update, see adam_cold_rows_kernel) == k
+    calls of skr_adam_step with a zero gradient, BIT FOR BIT, over rows of every age (moments decayed by 0 ... 3000
+    untouched steps, down to denormal and zero) and over special values (+-0, denormals, powers of two, tiny and huge
+    parameters, inf, NaN, v = +inf)"""
+    import torch
+    from skrec import _hip
+    L, st = _hip.lib(), _hip.stream
+    rng = np.random.default_rng(7 * k + t0)
+    rows = 6000
+    age = rng.integers(0, 3000, rows)
+    age[:200] = np.arange(200) * 5                                   # a dense sweep across the regime boundaries
+    m = (rng.standard_normal((rows, 64)) * 1e-3 * np.exp(np.log(0.9) * age)[:, None]).astype(np.float32)
+    v = (rng.random((rows, 64)) * 1e-6 * np.exp(np.log(0.999) * age)[:, None]).astype(np.float32)
+    p = (rng.standard_normal((rows, 64)) * 0.05).astype(np.float32)
+    sp = rows - 400                                                   # special rows at the end
+    m[sp:sp + 40] = 0.0
+    v[sp:sp + 40] = 0.0                                               # never touched
+    m[sp + 40:sp + 60] = np.float32(1e-44) * rng.integers(-6, 7, (20, 64)).astype(np.float32)   # stalled denormal moments
+    m[sp + 60:sp + 70] = -0.0
+    p[sp + 70:sp + 80] = -0.0
+    p[sp + 80:sp + 90] = 0.0
+    p[sp + 90:sp + 120] = (2.0 ** rng.integers(-70, 3, (30, 64))).astype(np.float32) * rng.choice([-1, 1], (30, 64))
+    p[sp + 120:sp + 140] *= np.float32(1e-30)
+    p[sp + 140:sp + 150] = np.float32(1e-42)
+    p[sp + 150:sp + 160] *= np.float32(1e30)
+    p[sp + 160:sp + 165] = np.inf
+    p[sp + 165:sp + 170] = np.nan
+    v[sp + 170:sp + 175] = np.inf
+    v[sp + 175:sp + 180] = np.nan
+    m[sp + 180:sp + 185] = np.inf
+    m[sp + 185:sp + 190] = np.nan
+    v[sp + 190:sp + 200] = np.float32(1e-44) * rng.integers(0, 9, (10, 64)).astype(np.float32)
+    v[sp + 200:sp + 220] *= np.float32(1e-25)
+    m[sp + 220:sp + 240, ::7] *= np.float32(1e20)                     # one lively lane keeps a row off the rest path
+    v[sp + 240:sp + 260] = -0.0
+    m[sp + 260:sp + 300] *= (10.0 ** rng.integers(-30, 30, (40, 64))).astype(np.float32)
+    v[sp + 300:sp + 340] *= (10.0 ** rng.integers(-30, 30, (40, 64))).astype(np.float32)
+    n = rows * 64 - 37                                                # a ragged tail
+    flat = lambda x: torch.from_numpy(x.reshape(-1)[:n].copy()).cuda()   # noqa: E731
+    p0, m0, v0 = flat(p), flat(m), flat(v)
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    g = torch.zeros(n, device="cuda")
+    for s in range(k):
+        _hip.check(L.skr_adam_step(_hip.ptr(pa), _hip.ptr(g), _hip.ptr(ma), _hip.ptr(va), n, lr, 0.9, 0.999, eps, t0 + 1 + s, 0,
+                                   None, st()))
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    tag = torch.zeros((n + 63) // 64, dtype=torch.int32, device="cuda")
+    tag[17] = 1                                                       # one hot block: must be left alone
+    _hip.check(L.skr_adam_block_cold(_hip.ptr(pb), _hip.ptr(mb), _hip.ptr(vb), n, lr, 0.9, 0.999, eps, t0, k, _hip.ptr(tag), 1, st()))
+    torch.cuda.synchronize()
+    bits = lambda t: t.view(torch.int32)                              # noqa: E731  (NaN-safe, sign-of-zero-exact)
+    hot = slice(17 * 64, 18 * 64)
+    for x0, xa, xb in ((p0, pa, pb), (m0, ma, mb), (v0, va, vb)):
+        assert torch.equal(bits(xb)[hot], bits(x0)[hot])
+        xa2 = xa.clone()
+        xa2[hot] = x0[hot]
+        assert int((bits(xa2) != bits(xb)).sum()) == 0
+    # the premise of the rest path, on the reference results themselves: old rows no longer move
+    if eps > 0:
+        old = torch.from_numpy(np.repeat(age[:sp] >= 400, 64)).cuda()
+        assert torch.equal(bits(pa)[:sp * 64][old], bits(p0)[:sp * 64][old])
+
+
+@pytest.mark.gpu
+def test_cold_pass_ordinary_math_matches_compiler_forms():
+    """the scaling-free square root over every float of its range and the scaling-free division over 2^32 hashed
+    operand pairs of its range == sqrtf / the fp32 division as compiled for the ordinary update"""
+    import ctypes as C
+    from skrec import _hip
+    _hip.require_gpu()
+    bad = (C.c_uint64 * 4)()
+    _hip.check(_hip.lib().skr_selftest_cold_math(1 << 32, bad, _hip.stream()))
+    assert bad[3] == 0x7f7fffff - 0x0f800000 + 1          # every float of [2^-96, FLT_MAX] was tried
+    assert bad[2] > 1000                                   # control: the raw hardware root is NOT sqrtf
+    assert bad[0] == 0 and bad[1] == 0
