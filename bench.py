@@ -221,6 +221,8 @@ def main():
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the whole-epoch leg (N = 1)")
+    ap.add_argument("--pre-steps", type=int, default=2048, help="untimed training steps before the warm-up (see main)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,8 +292,12 @@ def main():
         rp = (ds["rowptr"][start_user:end_user + 1] - lo).contiguous()
         return dict(rowptr=rp, users=ds["users"][lo:hi], items=ds["items"][lo:hi], n_users=end_user - start_user,
                     nnz=hi - lo, end_user=end_user)
-    warm = prefix(W * b, 0) if W > 0 else None
-    timed = prefix(K * b, warm["end_user"] if warm else 0)
+    # --pre-steps real training steps before the W warm-up steps (untimed, own user range): every kernel and torch
+    # helper of the loop has run at full queue depth, and the moments of the rows they touch are no longer all-zero
+    n_pre = max(0, min(args.pre_steps, (int(ds["rowptr"][-1]) // b - K - W) // 2))
+    pre = prefix(n_pre * b, 0) if n_pre > 0 else None
+    warm = prefix(W * b, pre["end_user"] if pre else 0) if W > 0 else None
+    timed = prefix(K * b, warm["end_user"] if warm else (pre["end_user"] if pre else 0))
     assert timed["nnz"] >= K * b, "dataset too small for --steps"
     sampler = DeviceSampler(2020)
     gperm = torch.Generator(device=dev).manual_seed(11 + rank)
@@ -310,8 +316,7 @@ def main():
         if exchange == "sparse":   # per step: the distinct item ids its 2*b gradient rows belong to (-1 = duplicate)
             step_ids = unique_padded_rows(torch.cat([ii.view(n_steps, b), jj.view(n_steps, b)], dim=1))
             pids = step_ids.data_ptr()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)] \
-            if events is not None else None
+        ev = event_pool[:n_steps] if events is not None else None    # created outside the timed region
         if kblk > 1:
             # Temporally blocked dense Adam (csrc/train.hip K2b; at N = 1 what skrec.recommender.BPRMF.train_epoch does).
             # Per block of kblk steps: rows no batch of the block touches get their kblk zero-gradient updates in ONE
@@ -417,8 +422,8 @@ def main():
         if events is not None:
             events.extend(ev)
     n_user_par = nU * D
-    # SKR_ADAM_BLOCK = k (default 8; N > 1 needs the sparse exchange): look k batches ahead and block the dense Adam; 1 = classic
-    kblk = max(1, min(16, int(os.environ.get("SKR_ADAM_BLOCK", "8")))) if (world == 1 or exchange == "sparse") else 1
+    # SKR_ADAM_BLOCK = k (default 24, at most 32; N > 1 needs the sparse exchange): look k batches ahead and block the dense Adam; 1 = classic
+    kblk = max(1, min(32, int(os.environ.get("SKR_ADAM_BLOCK", "24")))) if (world == 1 or exchange == "sparse") else 1
     blk_tag = torch.zeros((n_par + 63) // 64, dtype=torch.int32, device=dev)
     blk_claim = torch.zeros_like(blk_tag)
     keep_alive = []
@@ -456,7 +461,22 @@ def main():
     # size the sampler's scratch for the timed slice outside the timed region (consumes stream words)
     _scratch = torch.empty(timed["nnz"], dtype=torch.int32, device=dev)
     sampler.sample_epoch_exact(nI, timed["n_users"], timed["rowptr"], timed["items"], timed["nnz"], 1, _scratch)
-    del _scratch
+    # ... and run the slice preparation (permutation, gathers) once at the timed slice's size: above ~10^6 elements torch
+    # switches to other kernels, whose first use costs ~55 ms of code loading that is not part of a step
+    _p = torch.randperm(timed["nnz"], generator=torch.Generator(device=dev).manual_seed(1), device=dev)[:K * b]
+    _cols = [c.index_select(0, _p).contiguous() for c in (timed["users"], timed["items"], _scratch)]
+    if exchange == "sparse":
+        unique_padded_rows(torch.cat([_cols[1].view(K, b), _cols[2].view(K, b)], dim=1))
+    del _scratch, _p, _cols
+    # HIP-event pairs around the Adam launches of the timed steps (the roofline's per-launch time).  Created HERE:
+    # building 2K timing events costs ~30 us each once a pool of ~1000 is used up (+56 ms inside the region at K = 960)
+    event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if (kblk <= 1 or s % kblk == 0) else None
+                  for s in range(K)]
+    for pair in event_pool:
+        if pair is not None:
+            pair[0].record(); pair[1].record()       # first record creates the HIP event
+    if pre is not None:
+        run_slice(pre, n_pre)
     if W > 0:
         run_slice(warm, W)
     barrier()
@@ -471,6 +491,29 @@ def main():
         dt = float(tmax)
     adam_ms = float(np.mean([a.elapsed_time(z) for a, z in events]))
     value = K * b * world / dt
+    # ---- one WHOLE epoch through the same loop (N = 1): sampling of every user's negatives, the permutation, all
+    # nnz/b steps.  The K timed steps above draw their batches from a user prefix (so that their share of the sampling
+    # sits inside the timed region); an epoch's batches spread over all users -- more distinct hot rows per block, and
+    # moments of every age.  Reported beside `value`, never instead of it.
+    epoch_leg = None
+    if world == 1 and not args.no_epoch:
+        whole = prefix(int(ds["rowptr"][-1]), 0)
+        n_ep = whole["nnz"] // b
+        keep_alive.clear()
+        barrier()
+        t0e = time.perf_counter()
+        run_slice(whole, n_ep)
+        barrier()
+        te = time.perf_counter() - t0e
+        t1e = time.perf_counter()
+        run_slice(whole, n_ep)
+        barrier()
+        te2 = time.perf_counter() - t1e
+        keep_alive.clear()
+        epoch_leg = {"interactions_per_sec": n_ep * b / te2, "seconds": te2, "steps": n_ep, "first_epoch_seconds": te,
+                     "first_epoch_interactions_per_sec": n_ep * b / te,
+                     "note": "second of two consecutive full epochs (every row's moments aged by real training); includes "
+                             "sampling all negatives and the epoch permutation"}
 
     out = {
         "metric": "train interactions/sec + eval users/sec (HR@10/NDCG@10) at 1/2/4/8 MI355X",
@@ -485,6 +528,8 @@ def main():
                    + ({"sparse": f" + RCCL all-gather of the touched item-gradient rows per step ({2 * b * 66 * 4 / 1e6:.2f} MB per rank)",
                        "dense": " + RCCL all-reduce of the dense item gradient per step (26 MB)", "none": ""}[exchange])},
     }
+    if epoch_leg is not None:
+        out["full_epoch"] = epoch_leg
     # HBM traffic per launch comes from the rocprofv3 PMC passes of this same command (separate runs:
     # tools/profile_bench.sh -> tools/summarize_profiles.py -> profiles/<round>_pmc_summary.json)
     pmc = {}

@@ -249,7 +249,7 @@ int skr_scale(float a, float* d_x, int64_t n, void* stream);                 /* 
  *                         once per id list: user rows offset 0 stride 64, item rows offset U*64, bias offset
  *                         (U+I)*64 stride 1).  step_t0 = optimiser steps taken before the k-step block.
  *   skr_adam_block_cold   steps step_t0+1 .. step_t0+k with zero gradient on every block whose tag != hot_value
- *   skr_adam_block_hot    ADVANCES the blocks the ids name to step_t (step_t0 < step_t <= step_t0 + 16): a block that
+ *   skr_adam_block_hot    ADVANCES the blocks the ids name to step_t (step_t0 < step_t <= step_t0 + 32): a block that
  *                         d_claim says is at step c gets zero-gradient updates for steps c+1 .. step_t-1 and then
  *                         step_t's update with its accumulated gradient, which is read and cleared; d_claim becomes
  *                         step_t (duplicate ids: one wavefront wins).  Either name every hot block at every step, or

@@ -375,7 +375,7 @@ inline unsigned rows_to_blocks(int64_t n_rows) { return static_cast<unsigned>((n
 // Every parameter still receives every update, in the same arithmetic: results are bit-identical to calling
 // skr_adam_step after every step (tests/test_gpu_train.py::test_blocked_adam_is_bit_identical).
 // ------------------------------------------------------------------------------------------------
-constexpr int AB_KMAX = 16;
+constexpr int AB_KMAX = 32;
 struct AdamBlockArgs {
     float one_minus_b1, b2, one_minus_b2, eps;
     float neg_step_size[AB_KMAX], bc2_sqrt[AB_KMAX];

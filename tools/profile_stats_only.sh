@@ -3,7 +3,7 @@
 TAG=${1:-r01_train}; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o stats -- python3 $R/bench.py --steps 208 --warmup 16 --no-cpu-baseline --no-eval "$@" > $R/gpurun_out/prof_$TAG.stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o stats -- python3 $R/bench.py --steps 208 --warmup 16 --no-cpu-baseline --no-eval --no-epoch "$@" > $R/gpurun_out/prof_$TAG.stats.log 2>&1
 echo "profile exit $?"
 python3 - <<PY
 import csv,glob
