@@ -241,6 +241,13 @@ int skr_gather_rows(const float* d_table, const int32_t* d_idx, int64_t n, int d
 int skr_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
 int skr_scale(float a, float* d_x, int64_t n, void* stream);                 /* x *= a */
 
+/* HOST function (no GPU): np.random.permutation(n) of numpy's legacy global generator, restated natively.  The
+ * reference shuffles each epoch with it (skrec/io/batch_iterator.py:61-63).  key624 / pos: the generator's MT19937 state
+ * as np.random.get_state() returns it (uint32[624], position 0..624); both are advanced exactly as numpy advances
+ * them, so np.random.set_state() with the returned values leaves the generator where the reference's would be.
+ * h_out int32[n], n < 2^31.  Runs outside the GIL when called through ctypes. */
+int skr_host_permutation(uint32_t* h_key624, int* h_pos, int64_t n, int32_t* h_out);
+
 /* The same dense Adam, temporally blocked over k consecutive steps whose batches are known in advance (an epoch's
  * batches are: data_iterator.py:230-234).  64-float blocks of the flat buffer that none of the k steps touches get
  * their k zero-gradient updates in ONE pass; touched blocks get the ordinary update at every step.  Every

@@ -35,6 +35,7 @@ SIGNATURES = {
     "skr_adam_block_mark": (i32, [vp, i64, i64, i32, vp, i32, vp, i64, vp]),
     "skr_adam_block_cold": (i32, [vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, i32, vp]),
     "skr_adam_block_hot": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i64, vp, i64, i64, i32, vp, vp]),
+    "skr_host_permutation": (i32, [vp, C.POINTER(i32), i64, vp]),
     "skr_selftest_cold_math": (i32, [u64, C.POINTER(u64), vp]),
     "skr_pack_grad_rows": (i32, [vp, i32, vp, vp, i32, vp, vp]),
     "skr_unpack_grad_rows": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp]),
@@ -132,6 +133,20 @@ def score_matrix(user_table, users, item_table, bias):
     out = torch.empty((du.numel(), n_items), dtype=torch.float32, device=dev)
     check(lib().skr_score_matrix(ptr(user_table), ptr(du), du.numel(), ptr(item_table), ptr(bias), n_items, 64, ptr(out),
                                  n_items, stream()))
+    return out
+
+
+def host_permutation(n):
+    """np.random.permutation(n) of numpy's GLOBAL legacy generator, as int32, computed natively (skr_host_permutation):
+    same values, same generator state afterwards; the GIL is released while it runs"""
+    kind, key, pos, has_gauss, cached = np.random.get_state()
+    if kind != "MT19937":
+        return np.random.permutation(n).astype(np.int32)
+    key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+    cpos = i32(int(pos))
+    out = np.empty(int(n), dtype=np.int32)
+    check(lib().skr_host_permutation(key.ctypes.data, C.byref(cpos), int(n), out.ctypes.data))
+    np.random.set_state((kind, key, int(cpos.value), has_gauss, cached))
     return out
 
 

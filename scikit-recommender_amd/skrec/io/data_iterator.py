@@ -84,8 +84,16 @@ def _n_batches(n, batch_size, drop_last):
     return n // batch_size if drop_last else (n + batch_size - 1) // batch_size
 
 
-def _shuffled_columns(columns, shuffle, device_shuffle=False):
-    """whole epoch columns, shuffled once on the device (contract: see _device_batches)"""
+def _host_permutation(n):
+    """np.random.permutation(n) -- numpy's values and generator state, computed by the native library outside the GIL
+    (int32; csrc/host_random.hip)"""
+    from .. import _hip
+    return _hip.host_permutation(n)
+
+
+def _shuffled_columns(columns, shuffle, device_shuffle=False, host_perm=None):
+    """whole epoch columns, shuffled once on the device (contract: see _device_batches); ``host_perm``: the epoch's
+    np.random.permutation(n), if the caller has drawn it already"""
     import torch
     n = columns[0].shape[0]
     if shuffle:
@@ -95,9 +103,44 @@ def _shuffled_columns(columns, shuffle, device_shuffle=False):
             g.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
             perm = torch.randperm(n, generator=g, device=dev)
         else:
-            perm = torch.from_numpy(np.random.permutation(n)).to(dev)
+            perm = torch.from_numpy(_host_permutation(n) if host_perm is None else host_perm).to(dev)
         columns = [c.index_select(0, perm) for c in columns]
     return columns
+
+
+class _PermutationAhead(object):
+    """The reference draws ONE np.random.permutation(n) from numpy's global generator at the start of every epoch
+    (batch_iterator.py:61-63): ~1 s of numpy time at 50 M interactions, about half of that in the native form.  Inside a training
+    loop that is known to draw nothing else from that generator between epochs (``fit()``: train, evaluate, train ...),
+    the NEXT epoch's permutation is the next thing the generator will be asked for, so it can be drawn right after the
+    current one -- on a helper thread (the native shuffle runs outside the GIL) while the GPU trains.  Same numbers, same
+    order.  ``close()`` puts the generator back to where the reference's would be if the last one drawn ahead was
+    never used (early stop, last epoch)."""
+
+    def __init__(self, n):
+        self.n, self._thread, self._perm, self._state_before = n, None, None, None
+
+    def _draw(self):
+        self._perm = _host_permutation(self.n)
+
+    def take(self):
+        """this epoch's permutation; starts drawing the next one"""
+        import threading
+        if self._thread is not None:
+            self._thread.join()
+            perm = self._perm
+        else:
+            perm = _host_permutation(self.n)
+        self._state_before = np.random.get_state()
+        self._thread = threading.Thread(target=self._draw, daemon=True)
+        self._thread.start()
+        return perm
+
+    def close(self):
+        if self._thread is not None:
+            self._thread.join()
+            np.random.set_state(self._state_before)
+            self._thread = self._perm = None
 
 
 def _device_batches(columns, batch_size, shuffle, drop_last, device_shuffle=False):
@@ -115,7 +158,7 @@ def _device_batches(columns, batch_size, shuffle, drop_last, device_shuffle=Fals
             g.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
             perm = torch.randperm(n, generator=g, device=dev)
         else:
-            perm = torch.from_numpy(np.random.permutation(n)).to(dev)
+            perm = torch.from_numpy(_host_permutation(n)).to(dev)
         columns = [c.index_select(0, perm) for c in columns]
     for start in range(0, n, batch_size):
         stop = min(start + batch_size, n)
@@ -136,9 +179,20 @@ class PairwiseIterator(object):
         self.num_items = self._s.num_items
         self.user_n_pos = self._s.user_n_pos
         self.all_users, self.pos_items = self._s.users_ary, self._s.pos_items
+        self._ahead = None
 
     def __len__(self):
         return _n_batches(len(self.all_users), self.batch_size, self.drop_last)
+
+    def permutation_ahead(self, on=True):
+        """``True``: from now on epoch_columns() draws the next epoch's permutation ahead of time (see _PermutationAhead:
+        only valid while nothing else uses numpy's global generator between epochs).  ``False``: stop, and rewind the
+        generator over a permutation that was drawn ahead but never used."""
+        if on and self._ahead is None:
+            self._ahead = _PermutationAhead(len(self.all_users))
+        elif not on and self._ahead is not None:
+            self._ahead.close()
+            self._ahead = None
 
     def iter_device(self):
         neg = self._s.sample()
@@ -154,7 +208,8 @@ class PairwiseIterator(object):
         neg = self._s.sample()
         if self.num_neg > 1:
             neg = neg.view(-1, self.num_neg)
-        cols = _shuffled_columns([self._s.d_users, self._s.d_pos, neg], self.shuffle, self.device_shuffle)
+        ahead = self._ahead.take() if (self._ahead is not None and self.shuffle and not self.device_shuffle) else None
+        cols = _shuffled_columns([self._s.d_users, self._s.d_pos, neg], self.shuffle, self.device_shuffle, ahead)
         n, b = cols[0].shape[0], self.batch_size
         bounds = [(s, min(s + b, n)) for s in range(0, n, b) if not (self.drop_last and s + b > n)]
         return cols, bounds

@@ -184,13 +184,19 @@ class BPRMF(AbstractRecommender):
         log = self.logger.info if self.dist.rank == 0 else (lambda *_: None)
         log("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
         early_stopping = EarlyStopping(metric="NDCG@10", patience=self.config.early_stop)
-        for epoch in range(self.config.epochs):
-            self.train_epoch(data_iter)
-            cur_result = self.evaluate()
-            log(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
-            if early_stopping(cur_result):
-                log("early stop")
-                break
+        # between epochs this loop asks numpy's global generator for nothing but the epoch permutations: the next one
+        # is drawn on a helper thread while the GPU trains (same numbers, same generator state afterwards)
+        data_iter.permutation_ahead(True)
+        try:
+            for epoch in range(self.config.epochs):
+                self.train_epoch(data_iter)
+                cur_result = self.evaluate()
+                log(f"epoch {epoch}:".ljust(12) + f"\t{cur_result.values_str}")
+                if early_stopping(cur_result):
+                    log("early stop")
+                    break
+        finally:
+            data_iter.permutation_ahead(False)
         log("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
         return early_stopping.best_result
 

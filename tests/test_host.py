@@ -164,3 +164,21 @@ def test_unique_padded_rows():
     for row, src in zip(got.tolist(), ids.tolist()):
         real = [x for x in row if x >= 0]
         assert sorted(real) == sorted(set(x for x in src if x >= 0)) and len(real) == len(set(real))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 1000, 65536, 65537, 300_001])
+def test_native_host_permutation_is_numpys(n):
+    """skr_host_permutation == np.random.permutation(n) from the same generator state, and leaves the generator in the
+    same state (reference: batch_iterator.py:61-63 draws one per epoch)"""
+    from skrec import _hip
+    np.random.seed(5 + n)
+    np.random.random(n % 700)                      # somewhere inside a 624-word block
+    np.random.normal()                             # a cached gaussian must survive
+    a = np.random.permutation(n)
+    ra = np.random.normal(size=3)
+    np.random.seed(5 + n)
+    np.random.random(n % 700)
+    np.random.normal()
+    b = _hip.host_permutation(n)
+    rb = np.random.normal(size=3)
+    assert b.dtype == np.int32 and np.array_equal(a, b) and np.array_equal(ra, rb)
