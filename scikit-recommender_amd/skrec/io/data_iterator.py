@@ -108,39 +108,71 @@ def _shuffled_columns(columns, shuffle, device_shuffle=False, host_perm=None):
     return columns
 
 
-class _PermutationAhead(object):
-    """The reference draws ONE np.random.permutation(n) from numpy's global generator at the start of every epoch
-    (batch_iterator.py:61-63): ~1 s of numpy time at 50 M interactions, about half of that in the native form.  Inside a training
-    loop that is known to draw nothing else from that generator between epochs (``fit()``: train, evaluate, train ...),
-    the NEXT epoch's permutation is the next thing the generator will be asked for, so it can be drawn right after the
-    current one -- on a helper thread (the native shuffle runs outside the GIL) while the GPU trains.  Same numbers, same
-    order.  ``close()`` puts the generator back to where the reference's would be if the last one drawn ahead was
-    never used (early stop, last epoch)."""
+class _EpochAhead(object):
+    """Next epoch's negatives and permutation, produced while the GPU trains on the current epoch.
 
-    def __init__(self, n):
-        self.n, self._thread, self._perm, self._state_before = n, None, None, None
+    The reference starts every epoch with (a) the per-user negative sampling loop on the global std::mt19937 stream
+    (data_iterator.py:81-94) and (b) ONE np.random.permutation(n) from numpy's global generator
+    (batch_iterator.py:61-63).  Here (a) is a serial chain on ONE compute unit (0.32 s per 48 M draws, the other 255
+    idle) and (b) ~0.35 s of native host code: a third of an epoch between them.  Inside a training loop that is known
+    to ask neither generator for anything else between epochs (``fit()``: train, evaluate, train ...), the next
+    epoch's draws are the next thing both will be asked for, so they can be made right after the current ones -- on a
+    helper thread (both native calls run outside the GIL) and a side stream.  Same numbers, same order.  ``close()``
+    puts both generators back to where the reference's would be if what was drawn ahead is never used (early stop,
+    last epoch)."""
 
-    def _draw(self):
-        self._perm = _host_permutation(self.n)
+    def __init__(self, it):
+        import torch
+        self.it, self._thread, self._out, self._err, self._saved = it, None, None, None, None
+        self._side = torch.cuda.Stream(device=it._s.dev)
+
+    def _produce(self, stream=None):
+        import torch
+        it = self.it
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                neg = it._s.sample()
+        else:
+            neg = it._s.sample()
+        perm = _host_permutation(len(it.all_users)) if (it.shuffle and not it.device_shuffle) else None
+        return neg, perm
+
+    def _work(self):
+        try:
+            self._out = self._produce(self._side)
+        except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread by take()
+            self._err = e
 
     def take(self):
-        """this epoch's permutation; starts drawing the next one"""
+        """this epoch's (negatives, permutation or None); starts producing the next epoch's"""
         import threading
+        import torch
         if self._thread is not None:
             self._thread.join()
-            perm = self._perm
+            self._thread = None
+            if self._err is not None:
+                raise self._err
+            neg, perm = self._out
+            neg.record_stream(torch.cuda.current_stream())     # allocated under the side stream, consumed here
         else:
-            perm = _host_permutation(self.n)
-        self._state_before = np.random.get_state()
-        self._thread = threading.Thread(target=self._draw, daemon=True)
+            neg, perm = self._produce()
+        s = self.it._s
+        self._saved = (np.random.get_state(), global_sampler().get_state() if s.mode == "exact" else None, s.epoch)
+        self._out = self._err = None
+        self._thread = threading.Thread(target=self._work, daemon=True)
         self._thread.start()
-        return perm
+        return neg, perm
 
     def close(self):
         if self._thread is not None:
             self._thread.join()
-            np.random.set_state(self._state_before)
-            self._thread = self._perm = None
+            self._thread = None
+            np_state, sampler_state, epoch = self._saved
+            np.random.set_state(np_state)
+            if sampler_state is not None:
+                global_sampler().set_state(*sampler_state)
+            self.it._s.epoch = epoch
+            self._out = None
 
 
 def _device_batches(columns, batch_size, shuffle, drop_last, device_shuffle=False):
@@ -184,12 +216,12 @@ class PairwiseIterator(object):
     def __len__(self):
         return _n_batches(len(self.all_users), self.batch_size, self.drop_last)
 
-    def permutation_ahead(self, on=True):
-        """``True``: from now on epoch_columns() draws the next epoch's permutation ahead of time (see _PermutationAhead:
-        only valid while nothing else uses numpy's global generator between epochs).  ``False``: stop, and rewind the
-        generator over a permutation that was drawn ahead but never used."""
+    def epoch_ahead(self, on=True):
+        """``True``: from now on epoch_columns() produces the NEXT epoch's negatives and permutation in the background
+        (see _EpochAhead: only valid while nothing else uses the global sampler stream or numpy's global generator
+        between epochs).  ``False``: stop, and rewind both generators over what was drawn ahead but never used."""
         if on and self._ahead is None:
-            self._ahead = _PermutationAhead(len(self.all_users))
+            self._ahead = _EpochAhead(self)
         elif not on and self._ahead is not None:
             self._ahead.close()
             self._ahead = None
@@ -205,11 +237,10 @@ class PairwiseIterator(object):
         """One epoch as whole device columns: (users, pos, neg) after sampling and shuffling, plus the batch
         boundaries [(start, stop), ...] that iter_device() would walk.  Consumes the sampler stream and numpy's
         permutation exactly like one ``iter_device()`` pass; lets a trainer look k batches ahead."""
-        neg = self._s.sample()
+        neg, perm = self._ahead.take() if self._ahead is not None else (self._s.sample(), None)
         if self.num_neg > 1:
             neg = neg.view(-1, self.num_neg)
-        ahead = self._ahead.take() if (self._ahead is not None and self.shuffle and not self.device_shuffle) else None
-        cols = _shuffled_columns([self._s.d_users, self._s.d_pos, neg], self.shuffle, self.device_shuffle, ahead)
+        cols = _shuffled_columns([self._s.d_users, self._s.d_pos, neg], self.shuffle, self.device_shuffle, perm)
         n, b = cols[0].shape[0], self.batch_size
         bounds = [(s, min(s + b, n)) for s in range(0, n, b) if not (self.drop_last and s + b > n)]
         return cols, bounds

@@ -186,7 +186,7 @@ class BPRMF(AbstractRecommender):
         early_stopping = EarlyStopping(metric="NDCG@10", patience=self.config.early_stop)
         # between epochs this loop asks numpy's global generator for nothing but the epoch permutations: the next one
         # is drawn on a helper thread while the GPU trains (same numbers, same generator state afterwards)
-        data_iter.permutation_ahead(True)
+        data_iter.epoch_ahead(True)
         try:
             for epoch in range(self.config.epochs):
                 self.train_epoch(data_iter)
@@ -196,7 +196,7 @@ class BPRMF(AbstractRecommender):
                     log("early stop")
                     break
         finally:
-            data_iter.permutation_ahead(False)
+            data_iter.epoch_ahead(False)
         log("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
         return early_stopping.best_result
 

@@ -74,8 +74,8 @@ if ap_steps:   # graph models re-propagate the whole graph every step: time a bo
     orig_iter = it.iter_device
     it.iter_device = lambda: itertools.islice(orig_iter(), ap_steps)
     it.__class__.__len__ = lambda self: ap_steps
-if os.environ.get("E2E_PERM_AHEAD", "1") != "0":   # what BPRMF.fit() does: next epoch's permutation on a helper thread
-    it.permutation_ahead(True)
+if os.environ.get("E2E_EPOCH_AHEAD", "1") != "0":   # what BPRMF.fit() does: next epoch's negatives and permutation in the background
+    it.epoch_ahead(True)
 for ep in range(args.epochs):
     torch.cuda.synchronize()
     t0 = time.time()
@@ -90,4 +90,4 @@ for ep in range(args.epochs):
     n = len(it.all_users) if not ap_steps else ap_steps * args.batch
     print(f"[e2e] epoch {ep}: train {t1 - t0:.2f}s = {n / (t1 - t0) / 1e6:.2f} M interactions/s; "
           f"eval {t2 - t1:.2f}s = {args.users / (t2 - t1) / 1e6:.2f} M users/s; {rep.values_str}", flush=True)
-it.permutation_ahead(False)
+it.epoch_ahead(False)
