@@ -18,6 +18,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--states", default="fresh,lively,steady,old")
+    ap.add_argument("--ks", default="8,16")
+    ap.add_argument("--t0s", default="0,20000")
+    args = ap.parse_args()
     import torch
     from skrec import _hip
     L = _hip.lib()
@@ -46,10 +52,10 @@ def main():
         return m, v
 
     out = {"rest_path": os.environ.get("SKR_COLD_REST", "1") != "0", "n_params": n}
-    for kind in ("fresh", "lively", "steady", "old"):
+    for kind in args.states.split(","):
         m0, v0 = state(kind)
-        for k in (8, 16):
-            for t0 in (0, 20000):
+        for k in [int(x) for x in args.ks.split(",")]:
+            for t0 in [int(x) for x in args.t0s.split(",")]:
                 ms = []
                 for rep in range(4):
                     pp, mm, vv = p.clone(), m0.clone(), v0.clone()
