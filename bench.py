@@ -327,25 +327,34 @@ def main():
             # Per block of kblk steps: rows no batch of the block touches get their kblk zero-gradient updates in ONE
             # pass (adam_cold_kernel), touched rows get the ordinary update after every batch (adam_hot_kernel).
             # Every parameter receives every update in the same arithmetic -- bit-identical to a dense launch per step.
+            def block_ids(lo, hi, kk):
+                # 64-float blocks of the flat [U | V | bias] buffer the batches lo..hi touch, step-major (5b per step): a hot
+                # step names the rows of its own batch and of the next one
+                ub, bi, bj = uu[lo:hi].view(kk, -1), ii[lo:hi].view(kk, -1), jj[lo:hi].view(kk, -1)
+                return torch.cat([ub, bi + nU, bj + nU, (bi >> 6) + (nU + nI), (bj >> 6) + (nU + nI)], dim=-1).reshape(-1)
+            if world == 1:   # every full block of the slice in one vectorised op (as BPRMF.train_epoch does)
+                nfull = n_steps // kblk
+                blk_all = block_ids(0, nfull * kblk * b, nfull * kblk).view(nfull, kblk * 5 * b)
             for s0 in range(0, n_steps, kblk):
                 kk = min(kblk, n_steps - s0)
                 lo, hi = s0 * b, (s0 + kk) * b
                 if world > 1:
                     # the item table is replicated: its hot rows are those ANY rank's batches of the block touch -- the
-                    # ranks exchange the block's item ids once (kk * 2b int32 each), then every rank tags the same item rows
-                    mine = torch.cat([ii[lo:hi], jj[lo:hi]])
-                    every = torch.empty((world, mine.numel()), dtype=torch.int32, device=dev)
+                    # ranks exchange the block's item ids once (kk * 2b int32 each), then every rank tags the same item
+                    # rows.  Step-major like the N = 1 list: per step b own users + 2b item ids of every rank (+ their
+                    # bias words), so a hot step can name just the rows of batch s and s + 1 of ALL ranks.
+                    mine = torch.cat([ii[lo:hi].view(kk, b), jj[lo:hi].view(kk, b)], dim=1).contiguous()      # [kk, 2b]
+                    every = torch.empty((world, kk, 2 * b), dtype=torch.int32, device=dev)
                     if gather_into:
                         dist.all_gather_into_tensor(every, mine)
                     else:
                         dist.all_gather([every[r] for r in range(world)], mine)
-                    every = every.view(-1)
-                    # de-duplicated: at N = 8 the raw list has ~270 k entries for ~70 k distinct blocks, and the hot step walks it
-                    blk = torch.unique(torch.cat([uu[lo:hi], every + nU, (every >> 6) + (nU + nI)]))
+                    every = every.permute(1, 0, 2).reshape(kk, world * 2 * b)
+                    blk = torch.cat([uu[lo:hi].view(kk, b), every + nU, (every >> 6) + (nU + nI)], dim=1).view(-1)
+                    per = b + 4 * world * b
                 else:
-                    # step-major (5b entries per step): a hot step names the rows of its own batch and of the next one
-                    ub, bi, bj = uu[lo:hi].view(kk, b), ii[lo:hi].view(kk, b), jj[lo:hi].view(kk, b)
-                    blk = torch.cat([ub, bi + nU, bj + nU, (bi >> 6) + (nU + nI), (bj >> 6) + (nU + nI)], dim=1).view(-1)
+                    blk = blk_all[s0 // kblk] if s0 // kblk < blk_all.shape[0] else block_ids(lo, hi, kk)
+                    per = 5 * b
                 run_slice.serial += 1
                 cur = torch.cuda.current_stream()
                 if run_slice.serial > 1:
@@ -376,9 +385,9 @@ def main():
                         else:
                             dist.all_gather(gather_views, pack_buf)
                         rc |= L.skr_unpack_grad_rows(gather_buf.data_ptr(), 2 * b, world, P["gV"], P["gb"], D, None, None, stream)
-                    if world == 1 and s < s0 + kk - 1:      # the block's last step names every hot row: all end at t0 + kk
+                    if s < s0 + kk - 1:      # the block's last step names every hot row: all end at t0 + kk
                         rc |= L.skr_adam_block_hot(P["flat"], P["grad"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, t0,
-                                                   run_slice.t, pblk + 4 * 5 * b * (s - s0), 10 * b, 0, 64, blk_claim.data_ptr(), stream)
+                                                   run_slice.t, pblk + 4 * per * (s - s0), 2 * per, 0, 64, blk_claim.data_ptr(), stream)
                     else:
                         rc |= L.skr_adam_block_hot(P["flat"], P["grad"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, t0,
                                                    run_slice.t, pblk, nblk, 0, 64, blk_claim.data_ptr(), stream)

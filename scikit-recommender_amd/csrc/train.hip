@@ -41,6 +41,7 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float acc_loss = 0.0f, acc_l2 = 0.0f;
     const float rs = reg * reg_scale;
+    const bool same_tables = RP == P && RQ == Q && gRP == gP && gRQ == gQ;
     for (int b = blockIdx.x * BPR_WAVES + wv; b < n; b += gridDim.x * BPR_WAVES) {
         const int64_t u = u_ids[b], i = i_ids[b], j = j_ids[b];
         const float pu = P[u * D + lane], qi = Q[i * D + lane], qj = Q[j * D + lane];
@@ -60,17 +61,26 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
         // d/dx = -sigmoid(-x)
         const float sig_neg = (x >= 0.0f) ? z / (1.0f + z) : 1.0f / (1.0f + z);
         const float c = -sig_neg * loss_scale;
-        // score-part gradients
-        atomicAdd(&gP[u * D + lane], c * (qi - qj));
-        atomicAdd(&gQ[i * D + lane], c * pu);
-        atomicAdd(&gQ[j * D + lane], -c * pu);
-        // regulariser rows (may be other tables than the score tables)
-        const float ru = RP[u * D + lane], ri = RQ[i * D + lane], rj = RQ[j * D + lane];
-        float sq = skr::wave_sum(ru * ru + ri * ri + rj * rj);
-        if (rs != 0.0f) {
-            atomicAdd(&gRP[u * D + lane], rs * ru);
-            atomicAdd(&gRQ[i * D + lane], rs * ri);
-            atomicAdd(&gRQ[j * D + lane], rs * rj);
+        float sq;
+        if (same_tables) {
+            // BPRMF: the regulariser rows ARE the score rows -- no second read, one atomic per row for both gradient parts
+            sq = skr::wave_sum(pu * pu + qi * qi + qj * qj);
+            atomicAdd(&gP[u * D + lane], c * (qi - qj) + rs * pu);
+            atomicAdd(&gQ[i * D + lane], c * pu + rs * qi);
+            atomicAdd(&gQ[j * D + lane], -c * pu + rs * qj);
+        } else {
+            // score-part gradients
+            atomicAdd(&gP[u * D + lane], c * (qi - qj));
+            atomicAdd(&gQ[i * D + lane], c * pu);
+            atomicAdd(&gQ[j * D + lane], -c * pu);
+            // regulariser rows (other tables than the score tables: LightGCN's ego embeddings)
+            const float ru = RP[u * D + lane], ri = RQ[i * D + lane], rj = RQ[j * D + lane];
+            sq = skr::wave_sum(ru * ru + ri * ri + rj * rj);
+            if (rs != 0.0f) {
+                atomicAdd(&gRP[u * D + lane], rs * ru);
+                atomicAdd(&gRQ[i * D + lane], rs * ri);
+                atomicAdd(&gRQ[j * D + lane], rs * rj);
+            }
         }
         if (bias) {
             sq += bi * bi + bj * bj;
@@ -972,7 +982,7 @@ int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr,
     a.eps = eps;
     a.k = k;
     for (int s = 0; s < k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s]);
-    static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // 8 measured best (tools/adam_block_sweep.sh)
+    static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // workgroups per CU.  The pass is off the critical path (it runs beside the k-step block's small launches): 4 leaves them more of the chip than 8 and is still done in time (tools/cold_bpc_sweep.sh: 24.9 / 29.8 / 28.1 M interactions/s at 2 / 4 / 8)
     // SKR_COLD_REST=0 keeps every cold block on the full update (the float4 kernel): the A/B switch of tools/microbench.py
     static const bool rest = [] { const char* e = getenv("SKR_COLD_REST"); return !(e && atoi(e) == 0); }();
     const bool sane = beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f && lr > 0.0f && eps >= 0.0f &&
