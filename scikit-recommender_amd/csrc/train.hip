@@ -690,15 +690,22 @@ __global__ __launch_bounds__(256) void adam_hot_kernel(float* __restrict__ p, fl
     const int64_t e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= n_ids) return;
     const int64_t blk = (offset + static_cast<int64_t>(ids[e]) * stride) >> 6;
+    // the row is loaded while the claim is in flight (one memory round trip less on a latency-bound kernel); a
+    // wavefront that loses the claim drops what it loaded.  Nobody writes the row during this launch but its owner.
+    const int64_t i = blk * 64 + lane;
+    float pp = 0.0f, mm = 0.0f, vv = 0.0f, gg = 0.0f;
+    if (i < n) {
+        pp = p[i];
+        mm = m[i];
+        vv = v[i];
+        gg = g[i];
+    }
     int old = 0;
     if (lane == 0) old = atomicExch(&claim[blk], t);
     old = __builtin_amdgcn_readfirstlane(old);
     if (old >= t) return;
     if (old < t0) old = t0;
-    const int64_t i = blk * 64 + lane;
     if (i < n) {
-        float pp = p[i], mm = m[i], vv = v[i];
-        const float gg = g[i];
         for (int s = old - t0; s < t - t0; ++s) {   // step t0 + s + 1
             AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
             const float gs = (s == t - t0 - 1) ? gg : 0.0f;
