@@ -473,9 +473,20 @@ class ShardedBPRMF(object):
         world, rank, nl, ni = self.ctx.world, self.ctx.rank, self.n_local, self.num_items
         lo, hi = bounds[0][0], bounds[-1][1]
         ub, ib, jb = users[lo:hi], pos[lo:hi], neg[lo:hi]
-        mine = ub[(ub % world) == rank] if world > 1 else ub
-        local = torch.div(mine, world, rounding_mode="floor").int() if world > 1 else mine
-        self.optimizer.begin_block(torch.cat([local, ib + nl, jb + nl, (ib >> 6) + (nl + ni), (jb >> 6) + (nl + ni)]), len(bounds))
+        kk, bsz = len(bounds), bounds[0][1] - bounds[0][0]
+        if all(b - a == bsz for a, b in bounds):
+            # step-major list (5 * batch ids per step): a hot step names the rows of its own batch and of the next one.
+            # Users of other ranks are replaced by an id the step names anyway (its first positive item): duplicates
+            # are harmless, and every step keeps the same number of entries.
+            U, I, J = ub.view(kk, bsz), ib.view(kk, bsz), jb.view(kk, bsz)
+            if world > 1:
+                U = torch.where((U % world) == rank, torch.div(U, world, rounding_mode="floor").int(), I[:, :1] + nl)
+            ids = torch.cat([U, I + nl, J + nl, (I >> 6) + (nl + ni), (J >> 6) + (nl + ni)], dim=1).reshape(-1)
+            self.optimizer.begin_block(ids, kk, per_step=5 * bsz)
+        else:   # a ragged last batch: every hot step names the whole list
+            mine = ub[(ub % world) == rank] if world > 1 else ub
+            local = torch.div(mine, world, rounding_mode="floor").int() if world > 1 else mine
+            self.optimizer.begin_block(torch.cat([local, ib + nl, jb + nl, (ib >> 6) + (nl + ni), (jb >> 6) + (nl + ni)]), kk)
         for k, (a, b) in enumerate(bounds):
             self._step_grads(users[a:b], pos[a:b], neg[a:b])
             loss_out[k] = self.loss
