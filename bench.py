@@ -384,7 +384,7 @@ def main():
                             dist.all_gather_into_tensor(gather_buf, pack_buf)
                         else:
                             dist.all_gather(gather_views, pack_buf)
-                        rc |= L.skr_unpack_grad_rows(gather_buf.data_ptr(), 2 * b, world, P["gV"], P["gb"], D, None, None, stream)
+                        rc |= L.skr_unpack_grad_rows_sorted(gather_buf.data_ptr(), 2 * b, world, P["gV"], P["gb"], D, None, None, stream)
                     if s < s0 + kk - 1:      # the block's last step names every hot row: all end at t0 + kk
                         rc |= L.skr_adam_block_hot(P["flat"], P["grad"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, t0,
                                                    run_slice.t, pblk + 4 * per * (s - s0), 2 * per, 0, 64, blk_claim.data_ptr(), stream)
@@ -417,7 +417,7 @@ def main():
                                       run_slice.t, 1, P["touch"], stream)
                 work.wait()
                 if exchange == "sparse":
-                    rc |= L.skr_unpack_grad_rows(gather_buf.data_ptr(), 2 * b, world, P["gV"], P["gb"], D, P["touch"],
+                    rc |= L.skr_unpack_grad_rows_sorted(gather_buf.data_ptr(), 2 * b, world, P["gV"], P["gb"], D, P["touch"],
                                                  P["grad"], stream)
                 if ev is not None:
                     ev[s][0].record()

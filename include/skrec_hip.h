@@ -290,6 +290,10 @@ int skr_selftest_cold_math(uint64_t n_pairs, uint64_t* h_mismatches, void* strea
  *                         [id bits | dV[id] | db[id]]; the packed dense rows are CLEARED.  d_g_bias may be NULL.
  *   skr_unpack_grad_rows: d_in float32[n_ranks, n_per_rank, dim+2]; dense += every valid row, rank 0 first. */
 int skr_pack_grad_rows(const int32_t* d_ids, int n, float* d_g_table, float* d_g_bias, int dim, float* d_out, void* stream);
+/* skr_unpack_grad_rows_sorted: the same sum, same order of additions, same bits, in ONE launch instead of n_ranks -- for
+ * packs made from id lists whose valid ids ASCEND with the empty slots (-1) last (every rank's). */
+int skr_unpack_grad_rows_sorted(const float* d_in, int n_per_rank, int n_ranks, float* d_g_table, float* d_g_bias, int dim,
+                                uint8_t* d_touch, const float* d_touch_base, void* stream);
 int skr_unpack_grad_rows(const float* d_in, int n_per_rank, int n_ranks, float* d_g_table, float* d_g_bias, int dim,
                          uint8_t* d_touch, const float* d_touch_base, void* stream);
 

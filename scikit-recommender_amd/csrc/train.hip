@@ -776,6 +776,78 @@ __global__ __launch_bounds__(256) void unpack_grad_rows_kernel(const float* __re
     }
 }
 
+// The same sum in ONE launch, for packs whose valid ids ascend with the empty slots last.  One wavefront per (rank, slot):
+// it looks the id up in every other rank's id column (64 lanes probe a stride, then the 32 entries of the stride that
+// can hold it); the lowest rank that holds the id owns it and adds the ranks' rows to the dense row in rank order --
+// the order of the per-rank launches above, so the results are the same bits -- with a plain read-modify-write.
+constexpr int UP_MAX_RANKS = 16;
+
+__device__ __forceinline__ int pack_find(const float* __restrict__ col0, int n, int id, int lane) {
+    // col0: &in[rank][0][0]; ids sit PK_W floats apart.  -> slot of `id`, or -1
+    auto key = [&](int j) -> int {
+        const int v = j < n ? __float_as_int(col0[static_cast<int64_t>(j) * PK_W]) : -1;
+        return v < 0 ? 0x7fffffff : v;
+    };
+    const int stride = (n + 63) >> 6;                       // 64 probes cover the column
+    const int k0 = key(lane * stride);
+    // first probe whose key exceeds id -> the stride before it may hold id
+    const uint64_t gt = __builtin_amdgcn_ballot_w64(k0 > id);
+    const int first_gt = gt ? __builtin_ctzll(gt) : 64;
+    if (first_gt == 0) return -1;
+    const int base = (first_gt - 1) * stride;
+    int found = -1;
+    for (int off = 0; off < stride; off += 64) {
+        const int j = base + off + lane;
+        const bool hit = off + lane < stride && key(j) == id;
+        const uint64_t hb = __builtin_amdgcn_ballot_w64(hit);
+        if (hb) found = base + off + __builtin_ctzll(hb);
+    }
+    return found;
+}
+
+__global__ __launch_bounds__(256) void unpack_grad_rows_sorted_kernel(const float* __restrict__ in, int n, int n_ranks,
+                                                                      float* __restrict__ gV, float* __restrict__ gb,
+                                                                      uint8_t* __restrict__ touch, const float* touch_base) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= static_cast<int64_t>(n) * n_ranks) return;
+    const int r = static_cast<int>(w / n), k = static_cast<int>(w % n);
+    const float* mine = in + (static_cast<int64_t>(r) * n + k) * PK_W;
+    const int id = __float_as_int(mine[0]);
+    if (id < 0) return;
+    int pos[UP_MAX_RANKS];
+#pragma unroll
+    for (int q = 0; q < UP_MAX_RANKS; ++q)
+        pos[q] = (q < n_ranks && q != r) ? pack_find(in + static_cast<int64_t>(q) * n * PK_W, n, id, lane) : -1;
+#pragma unroll
+    for (int q = 0; q < UP_MAX_RANKS; ++q)
+        if (q < r && pos[q] >= 0) return;                    // a lower rank holds the id: that wavefront owns it
+    float* dst = gV + static_cast<int64_t>(id) * D;
+    float acc = dst[lane] + mine[1 + lane];
+    float accb = 0.0f;
+    if (gb && lane == 0) accb = gb[id] + mine[1 + D];
+#pragma unroll
+    for (int q = 0; q < UP_MAX_RANKS; ++q) {
+        if (q > r && pos[q] >= 0) {
+            const float* row = in + (static_cast<int64_t>(q) * n + pos[q]) * PK_W;
+            acc += row[1 + lane];
+            if (gb && lane == 0) accb += row[1 + D];
+        }
+    }
+    dst[lane] = acc;
+    if (lane == 0) {
+        if (gb) gb[id] = accb;
+        if (touch) {
+            uint8_t* t = &touch[(dst - touch_base) >> 6];
+            if (*t == 0) *t = 1;
+            if (gb) {
+                uint8_t* tb = &touch[(gb + id - touch_base) >> 6];
+                if (*tb == 0) *tb = 1;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -951,6 +1023,21 @@ int skr_unpack_grad_rows(const float* d_in, int n_per_rank, int n_ranks, float* 
                            d_touch_base);
         SKR_LAUNCH_CHECK();
     }
+    return SKR_OK;
+}
+
+int skr_unpack_grad_rows_sorted(const float* d_in, int n_per_rank, int n_ranks, float* d_g_table, float* d_g_bias, int dim,
+                                uint8_t* d_touch, const float* d_touch_base, void* stream) {
+    SKR_REQUIRE(d_in && d_g_table, "skr_unpack_grad_rows_sorted: NULL argument");
+    SKR_REQUIRE(dim == D, "skr_unpack_grad_rows_sorted: dim must be 64 (got %d)", dim);
+    SKR_REQUIRE((d_touch == nullptr) == (d_touch_base == nullptr), "touch: both pointers or neither");
+    if (n_per_rank <= 0 || n_ranks <= 0) return SKR_OK;
+    if (n_ranks > UP_MAX_RANKS)   // beyond the kernel's register table: the per-rank launches give the same bits
+        return skr_unpack_grad_rows(d_in, n_per_rank, n_ranks, d_g_table, d_g_bias, dim, d_touch, d_touch_base, stream);
+    const int64_t waves = static_cast<int64_t>(n_per_rank) * n_ranks;
+    hipLaunchKernelGGL(unpack_grad_rows_sorted_kernel, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0,
+                       skr::as_stream(stream), d_in, n_per_rank, n_ranks, d_g_table, d_g_bias, d_touch, d_touch_base);
+    SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
 

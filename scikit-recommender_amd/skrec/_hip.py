@@ -39,6 +39,7 @@ SIGNATURES = {
     "skr_selftest_cold_math": (i32, [u64, C.POINTER(u64), vp]),
     "skr_pack_grad_rows": (i32, [vp, i32, vp, vp, i32, vp, vp]),
     "skr_unpack_grad_rows": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp]),
+    "skr_unpack_grad_rows_sorted": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp]),
     "skr_gru_cell_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "skr_gru_cell_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "skr_session_loss": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]),

@@ -83,12 +83,14 @@ def init_from_env():
 
 
 def unique_padded_rows(ids):
-    """[S, C] integer ids -> int32 [S, C]: every row sorted, repeated ids replaced by -1 (an empty slot of
-    skr_pack_grad_rows)"""
-    srt = torch.sort(ids, dim=1).values
+    """[S, C] integer ids -> int32 [S, C]: every row's distinct non-negative ids in ascending order, then -1 (an empty
+    slot of skr_pack_grad_rows) -- the layout skr_unpack_grad_rows_sorted needs"""
+    big = torch.iinfo(torch.int32).max
+    srt = torch.sort(torch.where(ids < 0, torch.full_like(ids, big), ids), dim=1).values
     dup = torch.zeros_like(srt, dtype=torch.bool)
     dup[:, 1:] = srt[:, 1:] == srt[:, :-1]
-    return torch.where(dup, torch.full_like(srt, -1), srt).int().contiguous()
+    srt = torch.sort(torch.where(dup, torch.full_like(srt, big), srt), dim=1).values
+    return torch.where(srt == big, torch.full_like(srt, -1), srt).int().contiguous()
 
 
 def _csr_from_device_coo(rows, cols, vals, n_rows, n_cols):
@@ -462,7 +464,7 @@ class ShardedBPRMF(object):
         L, st = _hip.lib(), _hip.stream()
         _hip.check(L.skr_pack_grad_rows(_hip.ptr(ids), cap, _hip.ptr(self._gV), _hip.ptr(self._gb), 64, _hip.ptr(pack), st))
         self.ctx.all_gather_rows(gathered, pack)
-        _hip.check(L.skr_unpack_grad_rows(_hip.ptr(gathered), cap, world, _hip.ptr(self._gV), _hip.ptr(self._gb), 64,
+        _hip.check(L.skr_unpack_grad_rows_sorted(_hip.ptr(gathered), cap, world, _hip.ptr(self._gV), _hip.ptr(self._gb), 64,
                                           _hip.ptr(opt.touch), _hip.ptr(opt.grad) if opt.touch is not None else None, st))
 
     def train_block(self, users, pos, neg, bounds, loss_out):

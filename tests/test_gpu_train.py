@@ -338,3 +338,36 @@ def test_cold_pass_ordinary_math_matches_compiler_forms():
     assert bad[3] == 0x7f7fffff - 0x0f800000 + 1          # every float of [2^-96, FLT_MAX] was tried
     assert bad[2] > 1000                                   # control: the raw hardware root is NOT sqrtf
     assert bad[0] == 0 and bad[1] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,cap,n_items", [(2, 64, 500), (8, 2048, 100000), (3, 300, 200), (16, 128, 90), (5, 1, 10)])
+def test_unpack_grad_rows_sorted_equals_per_rank_launches(n_ranks, cap, n_items):
+    """one-launch ordered sum of the ranks' packed gradient rows == the n_ranks launches in rank order, bit for bit
+    (dense rows, bias words, touch bytes); packs built the way the exchange builds them (unique_padded_rows)"""
+    import torch
+    from skrec import _hip
+    from skrec.parallel import unique_padded_rows
+    L, st = _hip.lib(), _hip.stream
+    g = torch.Generator(device="cuda").manual_seed(n_ranks * 1000 + cap)
+    raw = torch.randint(0, n_items, (n_ranks, cap), generator=g, device="cuda", dtype=torch.int32)
+    raw[:, cap // 2:] = torch.where(torch.rand((n_ranks, cap - cap // 2), generator=g, device="cuda") < 0.3,
+                                    torch.full_like(raw[:, cap // 2:], -1), raw[:, cap // 2:])     # some empty slots
+    ids = unique_padded_rows(raw)
+    assert bool(((ids[:, 1:] > ids[:, :-1]) | (ids[:, 1:] < 0)).all())      # ascending, then -1
+    packs = torch.randn((n_ranks, cap, 66), generator=g, device="cuda")
+    packs[:, :, 0] = ids.view(torch.float32)
+    gV0 = torch.randn((n_items, 64), generator=g, device="cuda")
+    gb0 = torch.randn(n_items, generator=g, device="cuda")
+    flat = lambda: torch.cat([gV0.reshape(-1), gb0]).clone()           # noqa: E731  ([V | b] as in the optimiser's buffer)
+    outs = []
+    for fn in (L.skr_unpack_grad_rows, L.skr_unpack_grad_rows_sorted):
+        buf = flat()
+        gV, gb = buf[:n_items * 64].view(n_items, 64), buf[n_items * 64:]
+        touch = torch.zeros((buf.numel() + 63) // 64, dtype=torch.uint8, device="cuda")
+        _hip.check(fn(_hip.ptr(packs), cap, n_ranks, _hip.ptr(gV), _hip.ptr(gb), 64, _hip.ptr(touch), _hip.ptr(buf), st()))
+        torch.cuda.synchronize()
+        outs.append((buf, touch))
+    assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert not torch.equal(outs[0][0], flat())                             # something was added
