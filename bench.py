@@ -350,8 +350,12 @@ def main():
                     else:
                         dist.all_gather([every[r] for r in range(world)], mine)
                     every = every.permute(1, 0, 2).reshape(kk, world * 2 * b)
-                    blk = torch.cat([uu[lo:hi].view(kk, b), every + nU, (every >> 6) + (nU + nI)], dim=1).view(-1)
-                    per = b + 4 * world * b
+                    if bias_blocks is not None:   # fewer bias blocks than item ids per step: name them all, once each
+                        blk = torch.cat([uu[lo:hi].view(kk, b), every + nU, bias_blocks.expand(kk, -1)], dim=1).reshape(-1)
+                        per = b + 2 * world * b + bias_blocks.shape[1]
+                    else:
+                        blk = torch.cat([uu[lo:hi].view(kk, b), every + nU, (every >> 6) + (nU + nI)], dim=1).view(-1)
+                        per = b + 4 * world * b
                 else:
                     blk = blk_all[s0 // kblk] if s0 // kblk < blk_all.shape[0] else block_ids(lo, hi, kk)
                     per = 5 * b
@@ -446,6 +450,9 @@ def main():
     side = torch.cuda.Stream(device=dev) if os.environ.get("SKR_ADAM_OVERLAP", "1") != "0" else torch.cuda.current_stream()
     ev_marked, ev_cold = torch.cuda.Event(), torch.cuda.Event()
     run_slice.serial = 0
+    n_bias_blocks = (nI + 63) // 64
+    bias_blocks = (torch.arange(n_bias_blocks, dtype=torch.int32, device=dev) + (nU + nI)).view(1, -1) \
+        if n_bias_blocks <= 2 * b * world else None
     gather_into = world > 1 and dist.get_backend() == "nccl"    # gloo rehearsals use the list form
     if exchange == "sparse":
         # probe the collective once outside the timed region; every rank takes the same branch because a
