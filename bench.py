@@ -9,10 +9,13 @@
 
 A "step" is one mini-batch of 1024 interactions per rank through the whole training path: its share
 of the epoch's negative sampling (the sampler call that produces exactly the negatives these K steps
-consume sits INSIDE the timed region), skr_bpr_step, the item-gradient all-reduce (N > 1), and
-ONE skr_adam_step over every parameter of the flat [U|V|b] buffer (the reference's dense-Adam semantics).  Users are
-sharded u % N; the item table and bias are replicated and kept identical by one RCCL all-reduce of
-their gradients per step.  Per-rank batch fixed at 1024, global batch 1024*N ("weak" in the contract's terms; the user shard per rank is 1/N of the fixed dataset).
+consume sits INSIDE the timed region), skr_bpr_step, the exchange of the item gradient (N > 1: packed touched rows,
+all-gathered, summed in rank order on every rank), and the step's dense Adam update of every parameter of the flat
+[U|V|b] buffer (the reference's dense-Adam semantics) in its temporally blocked, bit-identical form: one cold pass per
+24 steps over the rows no batch of the block touches + one hot launch per step (SKR_ADAM_BLOCK=1: one skr_adam_step
+per step).  Users are sharded u % N; the item table and bias are replicated.  Per-rank batch fixed at 1024, global
+batch 1024*N ("weak" in the contract's terms; the user shard per rank is 1/N of the fixed dataset).  Beside the K
+timed steps, `full_epoch` reports whole epochs through the same loop (N = 1).
 Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
 """
 import argparse
@@ -325,7 +328,7 @@ def main():
         if kblk > 1:
             # Temporally blocked dense Adam (csrc/train.hip K2b; at N = 1 what skrec.recommender.BPRMF.train_epoch does).
             # Per block of kblk steps: rows no batch of the block touches get their kblk zero-gradient updates in ONE
-            # pass (adam_cold_kernel), touched rows get the ordinary update after every batch (adam_hot_kernel).
+            # pass (adam_cold_rows_kernel), touched rows are advanced when a batch is about to read them or has written their gradient (adam_hot_kernel).
             # Every parameter receives every update in the same arithmetic -- bit-identical to a dense launch per step.
             def block_ids(lo, hi, kk):
                 # 64-float blocks of the flat [U | V | bias] buffer the batches lo..hi touch, step-major (5b per step): a hot
