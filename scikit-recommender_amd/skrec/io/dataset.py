@@ -188,6 +188,14 @@ class KnowledgeGraph(object):
 
 def _read_table(path, sep, names, missing):
     if os.path.isfile(path):
+        # pandas' multi-threaded pyarrow parser (same dtypes and values as the C parser on these all-numeric tables,
+        # several times faster on 5e7 rows); anything it does not take -- multi-character separators, odd quoting,
+        # an empty file, a missing pyarrow -- goes to the C parser, as the reference reads it (dataset.py:400-417)
+        if isinstance(sep, str) and len(sep) == 1 and os.path.getsize(path) > (1 << 20):
+            try:
+                return pd.read_csv(path, sep=sep, header=None, names=names, engine="pyarrow")
+            except Exception:  # noqa: BLE001
+                pass
         return pd.read_csv(path, sep=sep, header=None, names=names)
     missing(f"'{path}' does not exist.")
     return pd.DataFrame()

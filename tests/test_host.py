@@ -1,5 +1,6 @@
 """CPU suite, part 3: host-side mirror of the reference interface (no GPU): configs, registry,
 dataset views, batch iterator contracts, evaluator bookkeeping."""
+import os
 import sys
 
 import numpy as np
@@ -182,3 +183,20 @@ def test_native_host_permutation_is_numpys(n):
     b = _hip.host_permutation(n)
     rb = np.random.normal(size=3)
     assert b.dtype == np.int32 and np.array_equal(a, b) and np.array_equal(ra, rb)
+
+
+def test_large_tables_parse_like_the_c_parser(tmp_path):
+    """files above 1 MB go through pandas' pyarrow parser: same frame (values and dtypes) as the C parser"""
+    import pandas as pd
+    from skrec.io.dataset import _read_table
+    rng = np.random.default_rng(3)
+    n = 80_000
+    df = pd.DataFrame({"user": rng.integers(0, 50_000, n), "item": rng.integers(0, 9_000, n),
+                       "rating": rng.integers(1, 6, n).astype(np.float64), "time": rng.integers(0, 10 ** 9, n)})
+    p = str(tmp_path / "big.train")
+    df.to_csv(p, sep="\t", header=False, index=False)
+    assert os.path.getsize(p) > (1 << 20)
+    names = ["user", "item", "rating", "time"]
+    got = _read_table(p, "\t", names, lambda m: None)
+    want = pd.read_csv(p, sep="\t", header=None, names=names)
+    assert got.dtypes.tolist() == want.dtypes.tolist() and got.equals(want)
