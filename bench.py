@@ -298,6 +298,10 @@ def main():
     # --pre-steps real training steps before the W warm-up steps (untimed, own user range): every kernel and torch
     # helper of the loop has run at full queue depth, and the moments of the rows they touch are no longer all-zero
     n_pre = max(0, min(args.pre_steps, (int(ds["rowptr"][-1]) // b - K - W) // 2))
+    if world > 1:   # every step holds collectives: all ranks must run the same number (shards differ in size)
+        t_pre = torch.tensor([n_pre], device=dev, dtype=torch.int64)
+        dist.all_reduce(t_pre, op=dist.ReduceOp.MIN)
+        n_pre = int(t_pre)
     pre = prefix(n_pre * b, 0) if n_pre > 0 else None
     warm = prefix(W * b, pre["end_user"] if pre else 0) if W > 0 else None
     timed = prefix(K * b, warm["end_user"] if warm else (pre["end_user"] if pre else 0))
