@@ -281,6 +281,10 @@ int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n
  * [2] control: how often the raw v_sqrt_f32 differs from sqrtf over the same floats (> 0), [3] floats enumerated.
  * (Test hook; synchronises the stream.) */
 int skr_selftest_cold_math(uint64_t n_pairs, uint64_t* h_mismatches, void* stream);
+/* With SKR_COLD_STATS=1 in the environment the cold passes count their blocks by evaluation: h_counts3 = {at rest,
+ * ordinary magnitudes, general} since the start / the last reset (all zero when the census is off).  Synchronises the
+ * device.  (Measurement hook: tools/e2e_scale.py prints the shares of a real epoch.) */
+int skr_cold_pass_census(uint64_t* h_counts3, int reset);
 
 /* Sparse exchange of a replicated table's gradient between ranks (no reference counterpart -- the
  * reference is single-process).  A BPR step touches at most 2*batch item rows, so instead of all-reducing the

@@ -395,6 +395,7 @@ struct AdamBlockArgs {
     float rest_b2k;   // a lower bound of beta2^k
     // ranges of the "ordinary magnitudes" test (fast_mlo = +inf switches it off)
     float fast_vlo, fast_mlo, fast_mhi;
+    unsigned long long* stats;   // optional census (SKR_COLD_STATS=1): cold blocks at rest / ordinary / general
 };
 
 __global__ __launch_bounds__(256) void adam_mark_kernel(const int32_t* __restrict__ ids, int64_t n, int64_t offset,
@@ -629,6 +630,7 @@ __global__ __launch_bounds__(256) void adam_cold_rows_kernel(float* __restrict__
             const bool small = n0 < ap * a.rest_eps || (n0 * n0 < bound && bound >= 0x1p-120f);
             const bool lane_rest = __float_as_uint(vv[u]) <= 0x7f800000u && ap >= 0x1p-60f && small;
             if (__builtin_amdgcn_ballot_w64(!lane_rest) == 0) {
+                if (a.stats && lane == 0) atomicAdd(&a.stats[0], 1ull);
                 float m1 = mm[u], v1 = vv[u];
                 for (int s = 0; s < a.k; ++s) {
                     m1 = m1 + a.one_minus_b1 * (0.0f - m1);
@@ -642,6 +644,7 @@ __global__ __launch_bounds__(256) void adam_cold_rows_kernel(float* __restrict__
             }
             const bool lane_ord = vv[u] >= a.fast_vlo && vv[u] <= 0x1p20f && am >= a.fast_mlo && am <= a.fast_mhi;
             if (__builtin_amdgcn_ballot_w64(!lane_ord) == 0) {
+                if (a.stats && lane == 0) atomicAdd(&a.stats[1], 1ull);
                 if (!have) {
                     hp = pp[u], hm = mm[u], hv = vv[u], hi = i;
                     have = true;
@@ -658,6 +661,7 @@ __global__ __launch_bounds__(256) void adam_cold_rows_kernel(float* __restrict__
                 have = false;
                 continue;
             }
+            if (a.stats && lane == 0) atomicAdd(&a.stats[2], 1ull);
             general(pp[u], mm[u], vv[u]);
             __builtin_nontemporal_store(pp[u], &p[i]);
             __builtin_nontemporal_store(mm[u], &m[i]);
@@ -1062,6 +1066,33 @@ int skr_adam_block_mark(const int32_t* d_ids, int64_t n_ids, int64_t offset_floa
     return SKR_OK;
 }
 
+// SKR_COLD_STATS=1: a device census of how the cold passes sorted their blocks (read with skr_cold_pass_census)
+static unsigned long long* cold_stats_buffer() {
+    static unsigned long long* buf = [] {
+        unsigned long long* p = nullptr;
+        const char* e = getenv("SKR_COLD_STATS");
+        if (e && atoi(e) == 1 && hipMalloc(&p, 4 * sizeof(unsigned long long)) == hipSuccess) {
+            (void)hipMemset(p, 0, 4 * sizeof(unsigned long long));
+            return p;
+        }
+        return static_cast<unsigned long long*>(nullptr);
+    }();
+    return buf;
+}
+
+int skr_cold_pass_census(uint64_t* h_counts3, int reset) {
+    SKR_REQUIRE(h_counts3, "skr_cold_pass_census: NULL argument");
+    unsigned long long* buf = cold_stats_buffer();
+    h_counts3[0] = h_counts3[1] = h_counts3[2] = 0;
+    if (!buf) return SKR_OK;
+    unsigned long long h[4];
+    SKR_HIP(hipDeviceSynchronize());
+    SKR_HIP(hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost));
+    if (reset) SKR_HIP(hipMemset(buf, 0, sizeof(h)));
+    for (int i = 0; i < 3; ++i) h_counts3[i] = h[i];
+    return SKR_OK;
+}
+
 int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
                         int64_t step_t0, int k, const int32_t* d_tag, int32_t hot_value, void* stream) {
     SKR_REQUIRE(d_p && d_m && d_v && d_tag, "skr_adam_block_cold: NULL argument");
@@ -1092,6 +1123,7 @@ int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr,
     a.fast_vlo = ord ? static_cast<float>(0x1p-90 / static_cast<double>(a.rest_b2k)) : 0.0f;
     a.fast_mlo = ord ? static_cast<float>(m_lo) : INFINITY;
     a.fast_mhi = ord ? static_cast<float>(std::fmin(m_hi, 1e38)) : 0.0f;
+    a.stats = cold_stats_buffer();
     if (rest) {
         int64_t blocks = ((n >> 6) + 4 * 4 - 1) / (4 * 4);
         if (blocks > 256 * bpc) blocks = 256 * bpc;

@@ -36,6 +36,7 @@ SIGNATURES = {
     "skr_adam_block_cold": (i32, [vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, i32, vp]),
     "skr_adam_block_hot": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i64, vp, i64, i64, i32, vp, vp]),
     "skr_host_permutation": (i32, [vp, C.POINTER(i32), i64, vp]),
+    "skr_cold_pass_census": (i32, [C.POINTER(u64), i32]),
     "skr_selftest_cold_math": (i32, [u64, C.POINTER(u64), vp]),
     "skr_pack_grad_rows": (i32, [vp, i32, vp, vp, i32, vp, vp]),
     "skr_unpack_grad_rows": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp]),

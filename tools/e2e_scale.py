@@ -88,6 +88,14 @@ for ep in range(args.epochs):
     torch.cuda.synchronize()
     t2 = time.time()
     n = len(it.all_users) if not ap_steps else ap_steps * args.batch
+    if os.environ.get("SKR_COLD_STATS") == "1":
+        import ctypes as C
+        from skrec import _hip
+        cen = (C.c_uint64 * 3)()
+        _hip.check(_hip.lib().skr_cold_pass_census(cen, 1))
+        tot = max(1, sum(cen))
+        print(f"[e2e] epoch {ep}: cold blocks at rest {cen[0] / tot:.3f}, ordinary magnitudes {cen[1] / tot:.3f}, "
+              f"general {cen[2] / tot:.3f} (of {tot} block visits)", flush=True)
     print(f"[e2e] epoch {ep}: train {t1 - t0:.2f}s = {n / (t1 - t0) / 1e6:.2f} M interactions/s; "
           f"eval {t2 - t1:.2f}s = {args.users / (t2 - t1) / 1e6:.2f} M users/s; {rep.values_str}", flush=True)
 it.epoch_ahead(False)
