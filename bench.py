@@ -356,12 +356,16 @@ def main():
                         dist.all_gather_into_tensor(every, mine)
                     else:
                         dist.all_gather([every[r] for r in range(world)], mine)
-                    every = every.permute(1, 0, 2).reshape(kk, world * 2 * b)
+                    # per step the DISTINCT item ids of all ranks (sorted, -1 = empty slot): at N = 8 a step's 16 k gathered
+                    # ids name ~2x fewer rows, and every entry of the hot list costs a wavefront
+                    every = unique_padded_rows(every.permute(1, 0, 2).reshape(kk, world * 2 * b))
                     if bias_blocks is not None:   # fewer bias blocks than item ids per step: name them all, once each
-                        blk = torch.cat([uu[lo:hi].view(kk, b), every + nU, bias_blocks.expand(kk, -1)], dim=1).reshape(-1)
+                        blk = torch.cat([uu[lo:hi].view(kk, b), torch.where(every < 0, every, every + nU),
+                                         bias_blocks.expand(kk, -1)], dim=1).reshape(-1)
                         per = b + 2 * world * b + bias_blocks.shape[1]
                     else:
-                        blk = torch.cat([uu[lo:hi].view(kk, b), every + nU, (every >> 6) + (nU + nI)], dim=1).view(-1)
+                        blk = torch.cat([uu[lo:hi].view(kk, b), torch.where(every < 0, every, every + nU),
+                                         torch.where(every < 0, every, (every >> 6) + (nU + nI))], dim=1).view(-1)
                         per = b + 4 * world * b
                 else:
                     blk = blk_all[s0 // kblk] if s0 // kblk < blk_all.shape[0] else block_ids(lo, hi, kk)

@@ -263,7 +263,8 @@ int skr_host_permutation(uint32_t* h_key624, int* h_pos, int64_t n, int32_t* h_o
  *                         at step t only the rows of batch t and of batch t+1 (which must read current rows) and
  *                         every hot block at the LAST step of the k-step block -- all hot blocks must end at
  *                         step_t0 + k.  Both orders of visiting apply the same updates in the same order.
- *   d_tag, d_claim        int32[ceil(n / 64)], zero-initialised; use a fresh non-zero tag_value for every k-step block */
+ *   d_tag, d_claim        int32[ceil(n / 64)], zero-initialised; use a fresh non-zero tag_value for every k-step block
+ *   ids                   negative entries are skipped by _mark and _hot (empty slots of a de-duplicated list) */
 int skr_adam_block_mark(const int32_t* d_ids, int64_t n_ids, int64_t offset_floats, int stride_floats, int32_t* d_tag,
                         int32_t tag_value, int32_t* d_claim, int64_t step_t0, void* stream);
 int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void adam_mark_kernel(const int32_t* __restric
                                                         int stride, int32_t* __restrict__ tag, int32_t value,
                                                         int32_t* __restrict__ claim, int32_t claim_value) {
     const int64_t g = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-    if (g < n) {
+    if (g < n && ids[g] >= 0) {   // negative id: an empty slot of a de-duplicated list
         const int64_t blk = (offset + static_cast<int64_t>(ids[g]) * stride) >> 6;
         tag[blk] = value;
         if (claim) claim[blk] = claim_value;
@@ -693,7 +693,9 @@ __global__ __launch_bounds__(256) void adam_hot_kernel(float* __restrict__ p, fl
     const int lane = threadIdx.x & 63;
     const int64_t e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= n_ids) return;
-    const int64_t blk = (offset + static_cast<int64_t>(ids[e]) * stride) >> 6;
+    const int32_t id = ids[e];
+    if (id < 0) return;                            // an empty slot of a de-duplicated list
+    const int64_t blk = (offset + static_cast<int64_t>(id) * stride) >> 6;
     // the row is loaded while the claim is in flight (one memory round trip less on a latency-bound kernel); a
     // wavefront that loses the claim drops what it loaded.  Nobody writes the row during this launch but its owner.
     const int64_t i = blk * 64 + lane;
