@@ -443,7 +443,7 @@ class ShardedBPRMF(object):
         """sum the [V | b] gradient over the ranks; every replica ends with bit-identical values"""
         world, ni = self.ctx.world, self.num_items
         opt = self.optimizer
-        cap = 2 * int(torch.bincount(users.long() % world, minlength=world).max())   # same number on every rank
+        cap = 2 * int(users.numel())     # slots per rank: a rank holds at most the whole global batch (no device read-back)
         sparse = self.exchange == "sparse" or (self.exchange == "auto" and world * cap * 66 < ni * 65)
         if not sparse:
             if opt.touch is not None and not self._dense_marked:
