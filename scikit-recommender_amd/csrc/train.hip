@@ -1109,7 +1109,7 @@ int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr,
     a.eps = eps;
     a.k = k;
     for (int s = 0; s < k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s]);
-    static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // workgroups per CU.  The pass is off the critical path (it runs beside the k-step block's small launches): 3 leaves them more of the chip than 8 and is still done in time (tools/cold_bpc_sweep.sh: 24.9 / 31.3 / 30.3 / 28.1 M interactions/s at 2 / 3 / 4 / 8)
+    static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // workgroups per CU.  The pass is off the critical path (it runs beside the k-step block's small launches): 4 leaves them more of the chip than 8 and is still done in time (tools/cold_bpc_sweep.sh, 960 timed steps: 24.9 / 31.3 / 30.3 / 28.1 M interactions/s at 2 / 3 / 4 / 8; at 200 timed steps 3 and 4 are level, and 3 makes the pass itself 15 % slower)
     // SKR_COLD_REST=0 keeps every cold block on the full update (the float4 kernel): the A/B switch of tools/microbench.py
     static const bool rest = [] { const char* e = getenv("SKR_COLD_REST"); return !(e && atoi(e) == 0); }();
     const bool sane = beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f && lr > 0.0f && eps >= 0.0f &&
