@@ -371,3 +371,45 @@ def test_unpack_grad_rows_sorted_equals_per_rank_launches(n_ranks, cap, n_items)
     assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
     assert torch.equal(outs[0][1], outs[1][1])
     assert not torch.equal(outs[0][0], flat())                             # something was added
+
+
+@pytest.mark.gpu
+def test_blocked_adam_lists_may_hold_empty_slots():
+    """negative ids in the lists of skr_adam_block_mark / skr_adam_block_hot are skipped (de-duplicated lists carry
+    -1 in their empty slots); argument checks of the blocked-Adam entry points"""
+    import torch
+    from skrec import _hip
+    L, st = _hip.lib(), _hip.stream
+    n = 64 * 50
+    g0 = torch.Generator(device="cuda").manual_seed(5)
+    p0, m0, v0 = (torch.randn(n, generator=g0, device="cuda") * 0.1 for _ in range(3))
+    v0 = v0.abs() * 1e-4
+    grad0 = torch.randn(n, generator=g0, device="cuda") * 1e-2
+
+    def run(ids):
+        p, m, v, g = p0.clone(), m0.clone(), v0.clone(), grad0.clone()
+        tag = torch.zeros(50, dtype=torch.int32, device="cuda")
+        claim = torch.zeros(50, dtype=torch.int32, device="cuda")
+        d = torch.tensor(ids, dtype=torch.int32, device="cuda")
+        _hip.check(L.skr_adam_block_mark(_hip.ptr(d), d.numel(), 0, 64, _hip.ptr(tag), 7, _hip.ptr(claim), 10, st()))
+        _hip.check(L.skr_adam_block_hot(_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 10, 11,
+                                        _hip.ptr(d), d.numel(), 0, 64, _hip.ptr(claim), st()))
+        torch.cuda.synchronize()
+        return p, m, v, g, tag
+    a = run([3, 17, 17, 41])
+    b = run([-1, 3, -1, 17, 41, -1, 17, -5])
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert a[4].nonzero().flatten().tolist() == [3, 17, 41]
+    assert float(a[3][3 * 64:4 * 64].abs().max()) == 0.0 and float(a[3][0:64].abs().max()) > 0.0   # consumed / untouched
+    # argument checks
+    d = torch.tensor([1], dtype=torch.int32, device="cuda")
+    claim = torch.zeros(50, dtype=torch.int32, device="cuda")
+    p, m, v, g = p0.clone(), m0.clone(), v0.clone(), grad0.clone()
+    args = (_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8)
+    assert L.skr_adam_block_hot(*args, 10, 10, _hip.ptr(d), 1, 0, 64, _hip.ptr(claim), st()) == -1      # step_t must exceed step_t0
+    assert L.skr_adam_block_hot(*args, 10, 43, _hip.ptr(d), 1, 0, 64, _hip.ptr(claim), st()) == -1      # more than 32 steps
+    assert L.skr_adam_block_hot(*args, 10, 11, None, 1, 0, 64, _hip.ptr(claim), st()) == -1
+    tag = torch.zeros(50, dtype=torch.int32, device="cuda")
+    assert L.skr_adam_block_cold(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0, 33, _hip.ptr(tag), 1, st()) == -1
+    assert L.skr_adam_block_cold(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0, 0, _hip.ptr(tag), 1, st()) == -1

@@ -200,3 +200,19 @@ def test_large_tables_parse_like_the_c_parser(tmp_path):
     got = _read_table(p, "\t", names, lambda m: None)
     want = pd.read_csv(p, sep="\t", header=None, names=names)
     assert got.dtypes.tolist() == want.dtypes.tolist() and got.equals(want)
+
+
+def test_native_host_permutation_argument_checks():
+    import ctypes as C
+    from skrec import _hip
+    L = _hip.lib()
+    key = np.zeros(624, np.uint32)
+    pos = C.c_int(624)
+    out = np.zeros(4, np.int32)
+    assert L.skr_host_permutation(None, C.byref(pos), 4, out.ctypes.data) == -1           # NULL state
+    assert L.skr_host_permutation(key.ctypes.data, C.byref(pos), -1, out.ctypes.data) == -1  # negative n
+    assert L.skr_host_permutation(key.ctypes.data, C.byref(pos), 1 << 31, out.ctypes.data) == -1
+    bad = C.c_int(700)
+    assert L.skr_host_permutation(key.ctypes.data, C.byref(bad), 4, out.ctypes.data) == -1   # position beyond the state
+    assert L.skr_host_permutation(key.ctypes.data, C.byref(pos), 0, None) == 0               # empty permutation
+    assert pos.value == 624
