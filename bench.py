@@ -524,6 +524,22 @@ def main():
     adam_ms = float(np.mean([a.elapsed_time(z) for a, z in events]))
     value = K * b * world / dt
     n_hot_blocks = int((blk_tag == run_slice.serial).sum()) if kblk > 1 else 0     # hot blocks of the last timed k-step block
+    # the same pass ALONE on the chip (copies of the buffers, same tags, same step count): what the kernel does when it
+    # does not share HBM and CUs with the step kernels -- its own quality, next to the live (overlapped) figure
+    cold_alone_ms = None
+    if kblk > 1 and world == 1:
+        cp, cm, cv = flat.clone(), m1.clone(), m2.clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for rep in range(4):
+            e0.record()
+            _hip.check(L.skr_adam_block_cold(cp.data_ptr(), cm.data_ptr(), cv.data_ptr(), n_par, 1e-3, 0.9, 0.999, 1e-8,
+                                             run_slice.t + rep * kblk, kblk, blk_tag.data_ptr(), run_slice.serial, st()))
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        cold_alone_ms = float(np.mean(ts[1:]))
+        del cp, cm, cv
     # ---- one WHOLE epoch through the same loop (N = 1): sampling of every user's negatives, the permutation, all
     # nnz/b steps.  The K timed steps above draw their batches from a user prefix (so that their share of the sampling
     # sits inside the timed region); an epoch's batches spread over all users -- more distinct hot rows per block, and
@@ -626,6 +642,12 @@ def main():
                            "optimizer_steps_per_launch": kblk,
                            "overlapped_with_step_kernels": side != torch.cuda.current_stream(),
                            "dense_equivalent_GBps": float(n_par) * 28.0 * kblk / (adam_ms * 1e-3) / 1e9}
+        if cold_alone_ms:
+            out["roofline"]["alone"] = {"avg_launch_ms": cold_alone_ms, "achieved": cold_bytes / (cold_alone_ms * 1e-3) / 1e9,
+                                        "frac": cold_bytes / (cold_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "note": "the same pass with nothing beside it (copies of the buffers after the timed "
+                                                "region, same tags): `achieved` / `frac` above are the live figures, with "
+                                                "the pass held to 4 workgroups per CU underneath the step kernels"}
     else:
         adam_bytes = float(n_par if world == 1 else n_par - nU * D) * 28.0
         ach = adam_bytes / (adam_ms * 1e-3) / 1e9
