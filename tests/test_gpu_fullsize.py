@@ -106,3 +106,76 @@ def test_fused_eval_full_size_against_independent_path(big, K, n_eval, fused_mod
     hit = (ids == big["test_item"][:nu, None]).any(1).double().sum()
     assert abs(float(sums[K - 1]) - float(hit)) < 0.5                        # Recall@10 == HR@10 on leave-one-out
     np.testing.assert_allclose(sums.cpu().numpy(), rows.double().sum(0).cpu().numpy(), rtol=1e-9)
+
+
+def test_blocked_adam_full_size_is_bit_identical(big):
+    """the training path at full table size (1 M user rows + 100 k item rows + biases = 70.5 M parameters), batches
+    of 1024 real interactions of the data set with exact-stream negatives: 72 steps with the temporally blocked Adam
+    (k = 24, hot steps naming their own and the next batch) == one dense Adam launch per step, BIT FOR BIT, after
+    moments have been aged so that rows at rest, ordinary and lively rows all occur.  Gradient atomics are ordered
+    differently from launch to launch, so both runs take their gradients from the same recorded buffers."""
+    import torch
+    from skrec import _hip
+    from skrec.recommender.base import DenseAdam
+    from skrec.utils.py.random import DeviceSampler
+    L, st = _hip.lib(), _hip.stream
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    n_par = (U + I) * 64 + I
+    b, k, n_steps = 1024, 24, 72
+    init = torch.randn(n_par, generator=g, device=dev) * 0.05
+    # aged moments: every row last touched Exp(mean 977) steps ago (as in tools/microbench_cold.py "steady")
+    age = torch.empty(U + I, device=dev).exponential_(1.0 / 977.0, generator=g)
+    age = torch.cat([age.repeat_interleave(64), torch.zeros(I, device=dev)])
+    m0 = torch.randn(n_par, generator=g, device=dev) * 1e-3 * torch.exp(age * float(np.log(0.9)))
+    v0 = torch.rand(n_par, generator=g, device=dev) * 1e-6 * torch.exp(age * float(np.log(0.999)))
+    del age
+    # batches: a random sample of the data set's interactions + exact-stream negatives of a user prefix
+    n_pref = 40_000
+    nnz = int(big["rowptr"][n_pref])
+    neg = torch.empty(nnz, dtype=torch.int32, device=dev)
+    DeviceSampler(2020).sample_epoch_exact(I, n_pref, big["rowptr"][:n_pref + 1].contiguous(), big["items"][:nnz], nnz, 1, neg)
+    perm = torch.randperm(nnz, generator=g, device=dev)[:n_steps * b]
+    u = big["users"][:nnz][perm].view(n_steps, b).contiguous()
+    i = big["items"][:nnz][perm].view(n_steps, b).contiguous()
+    j = neg[perm].view(n_steps, b).contiguous()
+    t_start = 20_000
+
+    def views(t):
+        return t[:U * 64].view(U, 64), t[U * 64:(U + I) * 64].view(I, 64), t[(U + I) * 64:]
+    # reference: dense launch per step; the gradient buffer of every step is recorded sparsely (touched blocks only)
+    a = DenseAdam(init.clone(), lr=1e-3)
+    a.m.copy_(m0)
+    a.v.copy_(v0)
+    a.t = t_start
+    loss = torch.zeros(2, device=dev)
+    recorded = []
+    for s in range(n_steps):
+        (P, Q, Bi), (gP, gQ, gB) = views(a.flat), views(a.grad)
+        _hip.check(L.skr_bpr_step(_hip.ptr(P), _hip.ptr(Q), _hip.ptr(Bi), _hip.ptr(P), _hip.ptr(Q), _hip.ptr(u[s]), _hip.ptr(i[s]),
+                                  _hip.ptr(j[s]), b, 1.0, 1e-3, 1.0, _hip.ptr(gP), _hip.ptr(gQ), _hip.ptr(gB), _hip.ptr(gP),
+                                  _hip.ptr(gQ), _hip.ptr(loss), None, None, st()))
+        idx = a.grad.nonzero().flatten()
+        recorded.append((idx, a.grad[idx].clone()))
+        a.step()
+    # blocked: same parameters at every step (bit-identical so far, by induction), so the recorded gradients are its own
+    c = DenseAdam(init.clone(), lr=1e-3)
+    c.m.copy_(m0)
+    c.v.copy_(v0)
+    c.t = t_start
+    for s0 in range(0, n_steps, k):
+        uu, ii, jj = (t[s0:s0 + k] for t in (u, i, j))
+        ids = torch.cat([uu, ii + U, jj + U, (ii >> 6) + (U + I), (jj >> 6) + (U + I)], dim=1).reshape(-1)
+        c.begin_block(ids, k, per_step=5 * b)
+        for s in range(s0, s0 + k):
+            idx, val = recorded[s]
+            c.grad[idx] = val
+            c.hot_step()
+    c.end_blocks()
+    torch.cuda.synchronize()
+    assert c.t == a.t == t_start + n_steps
+    for x, y in ((a.flat, c.flat), (a.m, c.m), (a.v, c.v)):
+        assert int((x.view(torch.int32) != y.view(torch.int32)).sum()) == 0
+    assert float(c.grad.abs().max()) == 0.0
+    moved = (a.flat != init).view(-1)[:U * 64].view(U, 64).any(1).float().mean()
+    assert 0.01 < float(moved) < 0.9          # rows at rest did not move, touched and lively rows did
