@@ -456,8 +456,9 @@ def main():
     blk_tag = torch.zeros((n_par + 63) // 64, dtype=torch.int32, device=dev)
     blk_claim = torch.zeros_like(blk_tag)
     keep_alive = []
-    # the cold pass (vector-ALU-bound) runs on a side stream underneath the small, latency-bound bpr / hot-step launches
-    # of its block, as in BPRMF.train_epoch: +9 % here, +13 % through the API (SKR_ADAM_OVERLAP=0 turns it off)
+    # the cold pass (one sweep over nearly all parameters per k steps, HBM-bound) runs on a side stream underneath the
+    # small, latency-bound bpr / hot-step launches of its block, as in BPRMF.train_epoch: 30 vs 24 M interactions/s
+    # (SKR_ADAM_OVERLAP=0 turns it off)
     side = torch.cuda.Stream(device=dev) if os.environ.get("SKR_ADAM_OVERLAP", "1") != "0" else torch.cuda.current_stream()
     ev_marked, ev_cold = torch.cuda.Event(), torch.cuda.Event()
     run_slice.serial = 0
