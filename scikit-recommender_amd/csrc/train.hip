@@ -531,6 +531,15 @@ __device__ __forceinline__ void adam_pair_ordinary(f32x2& p, f32x2& m, f32x2& v,
     p = p + q;
 }
 
+template <bool UNIT_BC2>
+__device__ __forceinline__ void adam_one_ordinary(float& p, float& m, float& v, const AdamArgs& a) {
+    m = m + a.one_minus_b1 * (0.0f - m);
+    v = v * a.b2;
+    float sq = sqrt_ordinary(v);
+    if (!UNIT_BC2) sq = div_ordinary(sq, a.bc2_sqrt);
+    p = p + div_ordinary(a.neg_step_size * m, sq + a.eps);
+}
+
 __global__ __launch_bounds__(256) void selftest_cold_math_kernel(uint32_t lo, uint32_t hi, uint64_t n_pairs,
                                                                  unsigned long long* __restrict__ bad) {
     const uint64_t tid = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
@@ -558,6 +567,21 @@ __global__ __launch_bounds__(256) void selftest_cold_math_kernel(uint32_t lo, ui
     if (bd) atomicAdd(&bad[1], bd);
     if (b1) atomicAdd(&bad[2], b1);
     if (b2) atomicAdd(&bad[3], b2);
+}
+
+// the two per-lane tests of the cold pass (and of the hot step's catch-up): see the comment below.  nss0 = |neg_step_size|
+// of the FIRST of the zero-gradient updates in question (the largest in magnitude of them)
+__device__ __forceinline__ bool lane_at_rest(float pp, float mm, float vv, float nss0, const AdamBlockArgs& a) {
+    const float ap = fabsf(pp), n0 = nss0 * fabsf(mm);
+    const float r = ap * 0x1p-29f;
+    const float bound = (r * r) * (vv * a.rest_b2k);
+    const bool small = n0 < ap * a.rest_eps || (n0 * n0 < bound && bound >= 0x1p-120f);
+    return __float_as_uint(vv) <= 0x7f800000u && ap >= 0x1p-60f && small;
+}
+
+__device__ __forceinline__ bool lane_ordinary(float mm, float vv, const AdamBlockArgs& a) {
+    const float am = fabsf(mm);
+    return vv >= a.fast_vlo && vv <= 0x1p20f && am >= a.fast_mlo && am <= a.fast_mhi;
 }
 
 // cold pass, one wavefront per 64-float block (= one embedding row), with a cheap exact path for rows AT REST.
@@ -623,12 +647,7 @@ __global__ __launch_bounds__(256) void adam_cold_rows_kernel(float* __restrict__
         for (int u = 0; u < U; ++u) {
             if (!cold[u]) continue;
             const int64_t i = ((b0 + u * n_waves) << 6) + lane;
-            const float am = fabsf(mm[u]), ap = fabsf(pp[u]);
-            const float n0 = fabsf(a.neg_step_size[0]) * am;
-            const float r = ap * 0x1p-29f;
-            const float bound = (r * r) * (vv[u] * a.rest_b2k);
-            const bool small = n0 < ap * a.rest_eps || (n0 * n0 < bound && bound >= 0x1p-120f);
-            const bool lane_rest = __float_as_uint(vv[u]) <= 0x7f800000u && ap >= 0x1p-60f && small;
+            const bool lane_rest = lane_at_rest(pp[u], mm[u], vv[u], fabsf(a.neg_step_size[0]), a);
             if (__builtin_amdgcn_ballot_w64(!lane_rest) == 0) {
                 if (a.stats && lane == 0) atomicAdd(&a.stats[0], 1ull);
                 float m1 = mm[u], v1 = vv[u];
@@ -642,7 +661,7 @@ __global__ __launch_bounds__(256) void adam_cold_rows_kernel(float* __restrict__
                     __builtin_nontemporal_store(v1, &v[i]);
                 continue;
             }
-            const bool lane_ord = vv[u] >= a.fast_vlo && vv[u] <= 0x1p20f && am >= a.fast_mlo && am <= a.fast_mhi;
+            const bool lane_ord = lane_ordinary(mm[u], vv[u], a);
             if (__builtin_amdgcn_ballot_w64(!lane_ord) == 0) {
                 if (a.stats && lane == 0) atomicAdd(&a.stats[1], 1ull);
                 if (!have) {
@@ -699,7 +718,7 @@ __global__ __launch_bounds__(256) void adam_hot_kernel(float* __restrict__ p, fl
     // the row is loaded while the claim is in flight (one memory round trip less on a latency-bound kernel); a
     // wavefront that loses the claim drops what it loaded.  Nobody writes the row during this launch but its owner.
     const int64_t i = blk * 64 + lane;
-    float pp = 0.0f, mm = 0.0f, vv = 0.0f, gg = 0.0f;
+    float pp = 1.0f, mm = 0.0f, vv = 0.0f, gg = 0.0f;   // lanes beyond n: values that pass every wavefront-wide test
     if (i < n) {
         pp = p[i];
         mm = m[i];
@@ -711,10 +730,32 @@ __global__ __launch_bounds__(256) void adam_hot_kernel(float* __restrict__ p, fl
     old = __builtin_amdgcn_readfirstlane(old);
     if (old >= t) return;
     if (old < t0) old = t0;
+    // The steps the block is behind are zero-gradient updates, and they sit on the critical path of the training step
+    // (the slowest wavefront of this launch is one with a row that is 20 steps behind).  The same three exact evaluations
+    // as in the cold pass: AT REST (a row no batch has touched for long -- most user rows when their turn comes: only the
+    // moments decay), ORDINARY MAGNITUDES (scaling-free square root / division: a dependent chain 2.5x shorter), general.
+    const int s_grad = t - t0 - 1;                 // the step that takes the gradient
+    int s = old - t0;
+    if (s < s_grad) {
+        if (__builtin_amdgcn_ballot_w64(!lane_at_rest(pp, mm, vv, fabsf(a.neg_step_size[s]), a)) == 0) {
+            for (; s < s_grad; ++s) {
+                mm = mm + a.one_minus_b1 * (0.0f - mm);
+                vv = vv * a.b2;
+            }
+        } else if (__builtin_amdgcn_ballot_w64(!lane_ordinary(mm, vv, a)) == 0) {
+            for (; s < s_grad; ++s) {
+                AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
+                if (__builtin_amdgcn_readfirstlane(__float_as_int(one.bc2_sqrt)) == 0x3f800000)
+                    adam_one_ordinary<true>(pp, mm, vv, one);
+                else
+                    adam_one_ordinary<false>(pp, mm, vv, one);
+            }
+        }
+    }
     if (i < n) {
-        for (int s = old - t0; s < t - t0; ++s) {   // step t0 + s + 1
+        for (; s < t - t0; ++s) {   // step t0 + s + 1: what is left of the zero-gradient steps, then the gradient step
             AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
-            const float gs = (s == t - t0 - 1) ? gg : 0.0f;
+            const float gs = (s == s_grad) ? gg : 0.0f;
             if (__builtin_amdgcn_readfirstlane(__float_as_int(one.bc2_sqrt)) == 0x3f800000)
                 adam_elem_unit_bc2(pp, gs, mm, vv, one);
             else
@@ -1082,6 +1123,24 @@ static unsigned long long* cold_stats_buffer() {
     return buf;
 }
 
+// thresholds of the at-rest / ordinary-magnitude tests for a run of up to k zero-gradient updates whose scalars sit in
+// a.neg_step_size[0 .. k-1] / a.bc2_sqrt[0 .. k-1] (|neg_step_size| falls, bc2_sqrt rises with the step)
+static void adam_block_thresholds(AdamBlockArgs& a, float lr, float beta1, float beta2, float eps, int k) {
+    const bool sane = beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f && lr > 0.0f && eps >= 0.0f &&
+                      std::isfinite(lr) && std::isfinite(eps);
+    a.rest_eps = sane ? eps * 0x1p-28f : 0.0f;
+    a.rest_b2k = sane ? static_cast<float>(std::pow(static_cast<double>(beta2), k) * (1.0 - 1e-4)) : 0.0f;
+    // ordinary magnitudes for all k updates (ranges of sqrt_ordinary / div_ordinary with room to spare): v in
+    // [2^-90, 2^20] throughout, |nss*m| in [2^-100, 2^40] throughout, eps <= 2^20, sqrt(1 - beta2^t) >= 2^-10
+    const double nss_first = std::fabs(static_cast<double>(a.neg_step_size[0])), nss_last = std::fabs(static_cast<double>(a.neg_step_size[k - 1]));
+    const double m_lo = 0x1p-100 / (nss_last * std::pow(static_cast<double>(beta1), k) * 0.99), m_hi = 0x1p40 / nss_first;
+    const bool ord = sane && eps <= 0x1p20f && a.bc2_sqrt[0] >= 0x1p-10f && a.rest_b2k > 0.0f && m_lo < 1e30 && m_hi > 1e-30 &&
+                     std::isfinite(m_lo) && std::isfinite(m_hi);
+    a.fast_vlo = ord ? static_cast<float>(0x1p-90 / static_cast<double>(a.rest_b2k)) : 0.0f;
+    a.fast_mlo = ord ? static_cast<float>(m_lo) : INFINITY;
+    a.fast_mhi = ord ? static_cast<float>(std::fmin(m_hi, 1e38)) : 0.0f;
+}
+
 int skr_cold_pass_census(uint64_t* h_counts3, int reset) {
     SKR_REQUIRE(h_counts3, "skr_cold_pass_census: NULL argument");
     unsigned long long* buf = cold_stats_buffer();
@@ -1112,19 +1171,7 @@ int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr,
     static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // workgroups per CU.  The pass is off the critical path (it runs beside the k-step block's small launches): 4 leaves them more of the chip than 8 and is still done in time (tools/cold_bpc_sweep.sh, 960 timed steps: 24.9 / 31.3 / 30.3 / 28.1 M interactions/s at 2 / 3 / 4 / 8; at 200 timed steps 3 and 4 are level, and 3 makes the pass itself 15 % slower)
     // SKR_COLD_REST=0 keeps every cold block on the full update (the float4 kernel): the A/B switch of tools/microbench.py
     static const bool rest = [] { const char* e = getenv("SKR_COLD_REST"); return !(e && atoi(e) == 0); }();
-    const bool sane = beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f && lr > 0.0f && eps >= 0.0f &&
-                      std::isfinite(lr) && std::isfinite(eps);
-    a.rest_eps = sane ? eps * 0x1p-28f : 0.0f;
-    a.rest_b2k = sane ? static_cast<float>(std::pow(static_cast<double>(beta2), k) * (1.0 - 1e-4)) : 0.0f;
-    // ordinary magnitudes for all k updates (ranges of sqrt_ordinary / div_ordinary with room to spare): v in
-    // [2^-90, 2^20] throughout, |nss*m| in [2^-100, 2^40] throughout, eps <= 2^20, sqrt(1 - beta2^t) >= 2^-10
-    const double nss_first = std::fabs(static_cast<double>(a.neg_step_size[0])), nss_last = std::fabs(static_cast<double>(a.neg_step_size[k - 1]));
-    const double m_lo = 0x1p-100 / (nss_last * std::pow(static_cast<double>(beta1), k) * 0.99), m_hi = 0x1p40 / nss_first;
-    const bool ord = sane && eps <= 0x1p20f && a.bc2_sqrt[0] >= 0x1p-10f && a.rest_b2k > 0.0f && m_lo < 1e30 && m_hi > 1e-30 &&
-                     std::isfinite(m_lo) && std::isfinite(m_hi);
-    a.fast_vlo = ord ? static_cast<float>(0x1p-90 / static_cast<double>(a.rest_b2k)) : 0.0f;
-    a.fast_mlo = ord ? static_cast<float>(m_lo) : INFINITY;
-    a.fast_mhi = ord ? static_cast<float>(std::fmin(m_hi, 1e38)) : 0.0f;
+    adam_block_thresholds(a, lr, beta1, beta2, eps, k);
     a.stats = cold_stats_buffer();
     if (rest) {
         int64_t blocks = ((n >> 6) + 4 * 4 - 1) / (4 * 4);
@@ -1158,6 +1205,7 @@ int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n
     a.eps = eps;
     a.k = static_cast<int>(step_t - step_t0);
     for (int s = 0; s < a.k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s]);
+    adam_block_thresholds(a, lr, beta1, beta2, eps, a.k);   // for the zero-gradient steps a block may be behind
     hipLaunchKernelGGL(adam_hot_kernel, dim3(static_cast<unsigned>((n_ids + 3) / 4)), dim3(256), 0, skr::as_stream(stream), d_p,
                        d_g, d_m, d_v, n, a, static_cast<int32_t>(step_t0), static_cast<int32_t>(step_t), d_ids, n_ids,
                        offset_floats, stride_floats, d_claim);

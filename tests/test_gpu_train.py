@@ -313,13 +313,14 @@ def test_cold_pass_rest_regime_is_bit_identical(k, t0, eps, lr):
     tag[17] = 1                                                       # one hot block: must be left alone
     _hip.check(L.skr_adam_block_cold(_hip.ptr(pb), _hip.ptr(mb), _hip.ptr(vb), n, lr, 0.9, 0.999, eps, t0, k, _hip.ptr(tag), 1, st()))
     torch.cuda.synchronize()
-    bits = lambda t: t.view(torch.int32)                              # noqa: E731  (NaN-safe, sign-of-zero-exact)
+    bits = lambda t: t.view(torch.int32)                              # noqa: E731  (sign-of-zero-exact)
     hot = slice(17 * 64, 18 * 64)
     for x0, xa, xb in ((p0, pa, pb), (m0, ma, mb), (v0, va, vb)):
         assert torch.equal(bits(xb)[hot], bits(x0)[hot])
         xa2 = xa.clone()
         xa2[hot] = x0[hot]
-        assert int((bits(xa2) != bits(xb)).sum()) == 0
+        differ = (bits(xa2) != bits(xb)) & ~(torch.isnan(xa2) & torch.isnan(xb))    # any NaN equals any NaN: which sign /
+        assert int(differ.sum()) == 0                                               # payload survives is the compiler's choice
     # the premise of the rest path, on the reference results themselves: old rows no longer move
     if eps > 0:
         old = torch.from_numpy(np.repeat(age[:sp] >= 400, 64)).cuda()
