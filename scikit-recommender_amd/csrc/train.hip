@@ -764,8 +764,9 @@ __global__ __launch_bounds__(256) void adam_hot_kernel(float* __restrict__ p, fl
         p[i] = pp;
         m[i] = mm;
         v[i] = vv;
-        g[i] = 0.0f;
     }
+    // a row named only because the NEXT batch reads it has no gradient yet: nothing to clear
+    if (__builtin_amdgcn_ballot_w64(gg != 0.0f) != 0 && i < n) g[i] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
