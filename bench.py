@@ -284,7 +284,7 @@ def main():
         pack_buf = torch.empty((2 * b, D + 2), device=dev)
         gather_buf = torch.empty((world, 2 * b, D + 2), device=dev)
         gather_views = [gather_buf[r] for r in range(world)]
-    loss = torch.zeros(2, device=dev)
+    loss = torch.zeros(2 * 32, device=dev)      # skr_bpr_step_spread: SKR_LOSS_SLOTS pairs of loss words
 
     # ---- the slice of the epoch these W+K steps consume: a user prefix of the local shard ---------
     def prefix(n_need, start_user):
@@ -390,7 +390,7 @@ def main():
                 pblk, nblk = blk.data_ptr(), blk.numel()
                 for s in range(s0, s0 + kk):
                     o = s * b * 4
-                    rc |= L.skr_bpr_step(P["U"], P["V"], P["bias"], P["U"], P["V"], pu + o, pi + o, pj + o, b, 1.0, 1e-3, 1.0,
+                    rc |= L.skr_bpr_step_spread(P["U"], P["V"], P["bias"], P["U"], P["V"], pu + o, pi + o, pj + o, b, 1.0, 1e-3, 1.0,
                                          P["gU"], P["gV"], P["gb"], P["gU"], P["gV"], P["loss"], None, None, stream)
                     run_slice.t += 1
                     if world > 1:   # the step's one exchange: packed item-gradient rows, summed in rank order on every rank
@@ -415,7 +415,7 @@ def main():
             return
         for s in range(n_steps):
             o = s * b * 4
-            rc = L.skr_bpr_step(P["U"], P["V"], P["bias"], P["U"], P["V"], pu + o, pi + o, pj + o, b, 1.0, 1e-3, 1.0,
+            rc = L.skr_bpr_step_spread(P["U"], P["V"], P["bias"], P["U"], P["V"], pu + o, pi + o, pj + o, b, 1.0, 1e-3, 1.0,
                                 P["gU"], P["gV"], P["gb"], P["gU"], P["gV"], P["loss"], P["touch"], P["grad"], stream)
             run_slice.t += 1
             if world > 1:

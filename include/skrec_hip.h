@@ -207,6 +207,16 @@ int skr_bpr_step(const float* d_P, const float* d_Q, const float* d_bias,
                  float loss_scale, float reg, float reg_scale,
                  float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ,
                  float* d_loss, uint8_t* d_touch, const float* d_touch_base, void* stream);
+/* skr_bpr_step with the two loss sums spread over SKR_LOSS_SLOTS pairs: d_loss64 is float[2 * SKR_LOSS_SLOTS], pair q
+ * receives the sums of the workgroups q, q + SKR_LOSS_SLOTS, ...; the batch's sums are the sums over the pairs.  (One
+ * pair of words for all workgroups makes their atomics serialise: 4.5 us of a 10.9 us launch at batch 1024.) */
+#define SKR_LOSS_SLOTS 32
+int skr_bpr_step_spread(const float* d_P, const float* d_Q, const float* d_bias,
+                 const float* d_RP, const float* d_RQ,
+                 const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n,
+                 float loss_scale, float reg, float reg_scale,
+                 float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ,
+                 float* d_loss64, uint8_t* d_touch, const float* d_touch_base, void* stream);
 
 /* torch.optim.Adam.step for one dense parameter (single-tensor path): for every element
  *   m = m + (g-m)*(1-b1);  v = v*b2 + (1-b2)*g*g;

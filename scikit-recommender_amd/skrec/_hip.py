@@ -53,6 +53,7 @@ SIGNATURES = {
     "skr_score_matrix": (i32, [vp, vp, i32, vp, vp, i32, i32, vp, i64, vp]),
     "skr_rank_metrics": (i32, [vp, i32, i32, vp, vp, vp, C.POINTER(i32), i32, vp, vp, vp]),
     "skr_bpr_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "skr_bpr_step_spread": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "skr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, vp]),
     "skr_csr_spmm": (i32, [i32, vp, vp, vp, vp, i32, i64, vp, vp, vp, f32, vp]),
     "skr_layer_refine_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp]),
@@ -63,6 +64,7 @@ SIGNATURES = {
 }
 
 SKR_MAX_TOPK = 128
+SKR_LOSS_SLOTS = 32      # skr_bpr_step_spread: pairs of loss words per batch
 
 
 class HipError(RuntimeError):

@@ -116,10 +116,13 @@ class BPRMF(AbstractRecommender):
                 self.step_losses[k] = eng.loss
             return
         L, st, opt = _hip.lib(), _hip.stream(), self.optimizer
+        # the batches' loss sums land in 32 pairs of words each (skr_bpr_step_spread) and are added up once per epoch
+        S = _hip.SKR_LOSS_SLOTS
+        spread = torch.zeros((len(data_iter), S, 2), dtype=torch.float32, device=self.device)
         gU, gV, gb = self._grads
         pU, pV, pb = self.user_embeddings.data_ptr(), self.item_embeddings.data_ptr(), self.item_biases.data_ptr()
         pgU, pgV, pgb = gU.data_ptr(), gV.data_ptr(), gb.data_ptr()
-        ploss, reg = self.step_losses.data_ptr(), self.config.reg
+        ploss, reg = spread.data_ptr(), self.config.reg
         kblk = self.adam_block
         if kblk <= 1 or data_iter.num_neg != 1:
             pgrad, pflat, pm, pv = (t.data_ptr() for t in (opt.grad, opt.flat, opt.m, opt.v))
@@ -128,13 +131,14 @@ class BPRMF(AbstractRecommender):
             n_par = opt.flat.numel()
             for k, (u, i, j) in enumerate(data_iter.iter_device()):
                 # slices of the contiguous epoch columns are themselves contiguous (num_neg == 1)
-                rc = L.skr_bpr_step(pU, pV, pb, pU, pV, u.data_ptr(), i.data_ptr(), j.data_ptr(), u.numel(), 1.0, reg, 1.0,
-                                    pgU, pgV, pgb, pgU, pgV, ploss + 8 * k, ptouch, pgrad_base, st)
+                rc = L.skr_bpr_step_spread(pU, pV, pb, pU, pV, u.data_ptr(), i.data_ptr(), j.data_ptr(), u.numel(), 1.0, reg, 1.0,
+                                           pgU, pgV, pgb, pgU, pgV, ploss + 8 * S * k, ptouch, pgrad_base, st)
                 opt.t += 1
                 rc |= L.skr_adam_step(pflat, pgrad, pm, pv, n_par, opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.t, 1,
                                       ptouch, st)
                 if rc:
                     _hip.check(rc)
+            self.step_losses = spread.sum(1)
             return
         # Temporally blocked dense Adam (csrc/train.hip, K2b): the epoch's batches are known, so for every block of
         # `kblk` steps the rows no batch of the block touches get their kblk zero-gradient updates in one pass and
@@ -143,7 +147,7 @@ class BPRMF(AbstractRecommender):
         (cu, ci, cj), bounds = data_iter.epoch_columns()
         nu, ni = self.num_users, self.num_items
         pcu, pci, pcj = cu.data_ptr(), ci.data_ptr(), cj.data_ptr()
-        bpr = L.skr_bpr_step
+        bpr = L.skr_bpr_step_spread
 
         def block_ids(u_, i_, j_, dim):
             # 64-float blocks of the flat [U | V | b] buffer the batches touch: user rows, item rows, bias words
@@ -168,7 +172,7 @@ class BPRMF(AbstractRecommender):
             for k, (a, b) in enumerate(blk, start=s0):      # two launches per step, on cached integer addresses
                 t += 1
                 rc |= bpr(pU, pV, pb, pU, pV, pcu + 4 * a, pci + 4 * a, pcj + 4 * a, b - a, 1.0, reg, 1.0,
-                          pgU, pgV, pgb, pgU, pgV, ploss + 8 * k, None, None, st)
+                          pgU, pgV, pgb, pgU, pgV, ploss + 8 * S * k, None, None, st)
                 if per is not None and t < t0 + kk:         # rows of this batch and of the next; the last step names all
                     rc |= hot(pp, pg, pm, pv, n_par, lr, b1, b2, eps, t0, t, pids + 4 * per * (t - t0 - 1), 2 * per, 0, 64, pclaim, st)
                 else:
@@ -177,6 +181,7 @@ class BPRMF(AbstractRecommender):
             if rc:
                 _hip.check(rc)
         opt.end_blocks()
+        self.step_losses = spread.sum(1)
 
     def fit(self):
         data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
