@@ -12,7 +12,7 @@ of the epoch's negative sampling (the sampler call that produces exactly the neg
 consume sits INSIDE the timed region), skr_bpr_step, the exchange of the item gradient (N > 1: packed touched rows,
 all-gathered, summed in rank order on every rank), and the step's dense Adam update of every parameter of the flat
 [U|V|b] buffer (the reference's dense-Adam semantics) in its temporally blocked, bit-identical form: one cold pass per
-24 steps over the rows no batch of the block touches + one hot launch per step (SKR_ADAM_BLOCK=1: one skr_adam_step
+32 steps over the rows no batch of the block touches + one hot launch per step (SKR_ADAM_BLOCK=1: one skr_adam_step
 per step).  Users are sharded u % N; the item table and bias are replicated.  Per-rank batch fixed at 1024, global
 batch 1024*N ("weak" in the contract's terms; the user shard per rank is 1/N of the fixed dataset).  Beside the K
 timed steps, `full_epoch` reports whole epochs through the same loop (N = 1).
@@ -451,8 +451,8 @@ def main():
         if events is not None:
             events.extend(ev)
     n_user_par = nU * D
-    # SKR_ADAM_BLOCK = k (default 24, at most 32; N > 1 needs the sparse exchange): look k batches ahead and block the dense Adam; 1 = classic
-    kblk = max(1, min(32, int(os.environ.get("SKR_ADAM_BLOCK", "24")))) if (world == 1 or exchange == "sparse") else 1
+    # SKR_ADAM_BLOCK = k (default 32 = the most; N > 1 needs the sparse exchange): look k batches ahead and block the dense Adam; 1 = classic
+    kblk = max(1, min(32, int(os.environ.get("SKR_ADAM_BLOCK", "32")))) if (world == 1 or exchange == "sparse") else 1
     blk_tag = torch.zeros((n_par + 63) // 64, dtype=torch.int32, device=dev)
     blk_claim = torch.zeros_like(blk_tag)
     keep_alive = []

@@ -431,7 +431,7 @@ class ShardedBPRMF(object):
         self.item_rows = self.flat[nl * 64:(nl + ni) * 64].view(ni, 64)
         self.item_bias = self.flat[(nl + ni) * 64:]
         # SKR_ADAM_BLOCK = k > 1: temporally blocked dense Adam through train_block() (no touch bytes then)
-        self.adam_block = max(1, min(32, int(os.environ.get("SKR_ADAM_BLOCK", "24"))))
+        self.adam_block = max(1, min(32, int(os.environ.get("SKR_ADAM_BLOCK", "32"))))
         self.optimizer = DenseAdam(self.flat, lr=lr, track_touch=self.adam_block <= 1)
         g = self.optimizer.grad
         self._gU, self._gV, self._gb = g[:nl * 64].view(nl, 64), g[nl * 64:(nl + ni) * 64].view(ni, 64), g[(nl + ni) * 64:]

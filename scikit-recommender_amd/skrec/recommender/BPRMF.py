@@ -84,7 +84,7 @@ class BPRMF(AbstractRecommender):
         self.item_embeddings = self._flat[nu * d:(nu + ni) * d].view(ni, d)
         self.item_biases = self._flat[(nu + ni) * d:]
         # SKR_ADAM_BLOCK = k: look k batches ahead and block the dense Adam over them (1: one dense launch per step)
-        self.adam_block = max(1, min(32, int(os.environ.get("SKR_ADAM_BLOCK", "24"))))
+        self.adam_block = max(1, min(32, int(os.environ.get("SKR_ADAM_BLOCK", "32"))))
         self.optimizer = DenseAdam(self._flat, lr=self.config.lr, track_touch=self.adam_block <= 1)
         self._grads = (self.optimizer.grad_view(0, (nu, d)), self.optimizer.grad_view(nu * d, (ni, d)),
                        self.optimizer.grad_view((nu + ni) * d, (ni,)))

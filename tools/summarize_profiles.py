@@ -19,7 +19,7 @@ def short(n):
 # 1. --kernel-trace --stats summary (top kernels)
 rows = list(csv.DictReader(open(f"{src}/stats_kernel_stats.csv")))
 with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 192 --warmup 24 --no-cpu-baseline --no-epoch (MI355X)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 192 --warmup 32 --no-cpu-baseline --no-epoch (MI355X)\n")
     f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for r in rows[:25]:
         f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
@@ -33,7 +33,7 @@ for name in ("fetch", "write"):
     for r in csv.DictReader(open(f"{src}/{name}_counter_collection.csv")):
         agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     pmc[name] = agg
-summary = {"tag": tag, "command": "python3 bench.py --steps 192 --warmup 24 --no-cpu-baseline --no-epoch", "kernels": {}}
+summary = {"tag": tag, "command": "python3 bench.py --steps 192 --warmup 32 --no-cpu-baseline --no-epoch", "kernels": {}}
 for k in ("adam_cold_rows_kernel<4>", "adam_cold_kernel<2>", "adam_hot_kernel", "adam_kernel<true, 4, true>", "fused_topk_kernel_v4<true>", "fused_topk_kernel_v3<true>", "split_items_kernel",
           "bpr_step_kernel", "exact_assign_kernel<false>",
           "mt_generate_kernel"):
