@@ -251,6 +251,23 @@ int skr_gather_rows(const float* d_table, const int32_t* d_idx, int64_t n, int d
 int skr_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
 int skr_scale(float a, float* d_x, int64_t n, void* stream);                 /* x *= a */
 
+/* ---------------------------------------------------------------------------------------------
+ * Epoch shuffle + batch assembly.  replaces: BatchIterator's per-element Python batching
+ * (utils/py/batch_iterator.py:48-66,132-155: idx = np.random.permutation(n); [data[i] for i in idx] per column) and
+ * the zip of the users / pos / neg columns (io/data_iterator.py:226-234).
+ * ONE launch per epoch: for r < n_out, row r of every output column = row src(r) of its input column, with
+ *   src(r) = d_perm[r]     when d_perm != NULL (int32[>= n_out], values in [0, n_src): the numpy-compatible contract --
+ *                          the values of the epoch's np.random.permutation(n), e.g. from skr_host_permutation), or
+ *   src(r) = pi_seed(r)    when d_perm == NULL: a keyed bijection of [0, n_src) evaluated in registers (no permutation
+ *                          array, no sort; equal to the reference's shuffle in law only).
+ * d_cols / d_outs: HOST arrays of n_cols (1..4) DEVICE pointers; widths[k] = 32-bit words per row of column k (1 for an
+ * id or label column, num_neg for a [n, num_neg] block).  Input and output must not alias.  n_out <= n_src < 2^31. */
+int skr_shuffle_gather(const int32_t* d_perm, uint64_t seed, int64_t n_src, int64_t n_out, int n_cols,
+                       const void* const* d_cols, const int* widths, void* const* d_outs, void* stream);
+/* pi_seed(0 .. n_out-1) itself (int32), on the device / on the host (the host form needs no GPU) */
+int skr_shuffle_permutation(uint64_t seed, int64_t n, int64_t n_out, int32_t* d_out, void* stream);
+int skr_shuffle_permutation_host(uint64_t seed, int64_t n, int64_t n_out, int32_t* h_out);
+
 /* HOST function (no GPU): np.random.permutation(n) of numpy's legacy global generator, restated natively.  The
  * reference shuffles each epoch with it (skrec/io/batch_iterator.py:61-63).  key624 / pos: the generator's MT19937 state
  * as np.random.get_state() returns it (uint32[624], position 0..624); both are advanced exactly as numpy advances

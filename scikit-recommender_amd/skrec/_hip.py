@@ -36,6 +36,9 @@ SIGNATURES = {
     "skr_adam_block_cold": (i32, [vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, i32, vp]),
     "skr_adam_block_hot": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i64, vp, i64, i64, i32, vp, vp]),
     "skr_host_permutation": (i32, [vp, C.POINTER(i32), i64, vp]),
+    "skr_shuffle_gather": (i32, [vp, u64, i64, i64, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), vp]),
+    "skr_shuffle_permutation": (i32, [u64, i64, i64, vp, vp]),
+    "skr_shuffle_permutation_host": (i32, [u64, i64, i64, vp]),
     "skr_cold_pass_census": (i32, [C.POINTER(u64), i32]),
     "skr_selftest_cold_math": (i32, [u64, C.POINTER(u64), vp]),
     "skr_pack_grad_rows": (i32, [vp, i32, vp, vp, i32, vp, vp]),
@@ -152,6 +155,26 @@ def host_permutation(n):
     check(lib().skr_host_permutation(key.ctypes.data, C.byref(cpos), int(n), out.ctypes.data))
     np.random.set_state((kind, key, int(cpos.value), has_gauss, cached))
     return out
+
+
+def shuffle_gather(columns, perm=None, seed=0, n_out=None):
+    """One launch for all columns (skr_shuffle_gather): row r of every result = row perm[r] of the column, or row
+    pi_seed(r) when ``perm`` is None.  ``columns``: contiguous 4-byte-element device tensors [n] or [n, w]."""
+    import torch
+    n = int(columns[0].shape[0])
+    n_out = n if n_out is None else int(n_out)
+    outs = []
+    for s in range(0, len(columns), 4):
+        cols = columns[s:s + 4]
+        for c in cols:
+            assert c.is_contiguous() and c.element_size() == 4 and c.shape[0] == n
+        res = [torch.empty((n_out,) + tuple(c.shape[1:]), dtype=c.dtype, device=c.device) for c in cols]
+        k = len(cols)
+        check(lib().skr_shuffle_gather(ptr(perm), int(seed), n, n_out, k, (vp * k)(*[c.data_ptr() for c in cols]),
+                                       (i32 * k)(*[max(1, c.numel() // max(n, 1)) for c in cols]),
+                                       (vp * k)(*[r.data_ptr() for r in res]), stream()))
+        outs.extend(res)
+    return outs
 
 
 def metric_array(ids):

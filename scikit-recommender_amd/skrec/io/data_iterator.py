@@ -98,13 +98,14 @@ def _shuffled_columns(columns, shuffle, device_shuffle=False, host_perm=None):
     n = columns[0].shape[0]
     if shuffle:
         dev = columns[0].device
+        columns = [c.contiguous() for c in columns]
         if device_shuffle:
-            g = torch.Generator(device=dev)
-            g.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
-            perm = torch.randperm(n, generator=g, device=dev)
+            # the permutation is a keyed bijection evaluated inside the gather kernel; numpy's global
+            # generator supplies the key (one integer per epoch), so np.random.seed still fixes the run
+            columns = _hip.shuffle_gather(columns, None, seed=int(np.random.randint(0, 2 ** 31 - 1)))
         else:
             perm = torch.from_numpy(_host_permutation(n) if host_perm is None else host_perm).to(dev)
-        columns = [c.index_select(0, perm) for c in columns]
+            columns = _hip.shuffle_gather(columns, perm)
     return columns
 
 
@@ -178,20 +179,12 @@ class _EpochAhead(object):
 def _device_batches(columns, batch_size, shuffle, drop_last, device_shuffle=False):
     """Shuffle whole epoch columns once on the device, then yield consecutive slices.
     Default: the reference's contract -- ONE np.random.permutation(n) from numpy's global generator per
-    epoch (batch_iterator.py:61-63), uploaded.  ``device_shuffle=True`` draws the
-    permutation on the GPU instead; numpy's global generator still seeds it (one integer per epoch), so
-    ``np.random.seed`` keeps runs reproducible, but the order differs from the reference's."""
-    import torch
+    epoch (batch_iterator.py:61-63), uploaded.  ``device_shuffle=True`` evaluates a
+    keyed bijection inside the gather kernel instead (skr_shuffle_gather, no permutation array); numpy's global generator
+    still seeds it (one integer per epoch), so ``np.random.seed`` keeps runs reproducible, but the order differs from the
+    reference's.  Either way all columns move in ONE launch of the library's own kernel."""
     n = columns[0].shape[0]
-    if shuffle:
-        dev = columns[0].device
-        if device_shuffle:
-            g = torch.Generator(device=dev)
-            g.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
-            perm = torch.randperm(n, generator=g, device=dev)
-        else:
-            perm = torch.from_numpy(_host_permutation(n)).to(dev)
-        columns = [c.index_select(0, perm) for c in columns]
+    columns = _shuffled_columns(columns, shuffle, device_shuffle)
     for start in range(0, n, batch_size):
         stop = min(start + batch_size, n)
         if stop - start < batch_size and drop_last:

@@ -10,10 +10,17 @@ hand-derived backward; A is symmetric so the backward propagation is the same ke
 Edge dropout (``dropout > 0``, :133-152): once per epoch a fraction of the edges is pruned --
 alternately by degree-weighted sampling without replacement (``torch.multinomial`` of the normalised
 edge values, first epoch) and uniformly at random -- and the kept graph is re-normalised; training
-uses the pruned adjacency, evaluation the full one.  The pruning draws come from torch's device
-generator, so they match the reference in law, not bit for bit (the reference's own draws differ
-between its CPU and CUDA runs as well).
+uses the pruned adjacency, evaluation the full one.  ``prune_draws="reference"`` (the default; env
+``SKR_PRUNE_DRAWS``) makes the two draws exactly as the reference's CPU run makes them -- Python's
+``random.sample`` (:141) and ``torch.multinomial`` of the CPU edge values on torch's global CPU
+generator (:144) -- so the pruned graphs, and with them the whole trajectory, replay the reference's
+(tests/golden/golden_layergcn_dropout.npz); everything after the draw (gather of the kept edges,
+re-normalisation, CSR build, training) stays on the device.  ``prune_draws="device"`` draws on the GPU
+instead (the library's keyed-bijection shuffle for the uniform epoch, torch's device multinomial for
+the weighted one): equal in law only, for graphs where a host-side draw per epoch is too slow.
 """
+import os
+import random
 from typing import Dict
 
 import numpy as np
@@ -33,7 +40,7 @@ __all__ = ["LayerGCN", "LayerGCNConfig"]
 
 class LayerGCNConfig(ModelConfig):
     def __init__(self, lr=1e-3, reg=1e-2, embed_dim=64, n_layers=4, dropout=0.0, batch_size=2048, epochs=1000,
-                 early_stop=200, **kwargs):
+                 early_stop=200, prune_draws=None, **kwargs):
         super().__init__()
         self.lr: float = lr
         self.reg: float = reg
@@ -43,6 +50,8 @@ class LayerGCNConfig(ModelConfig):
         self.batch_size: int = batch_size
         self.epochs: int = epochs
         self.early_stop: int = early_stop
+        # how the edge-pruning draws are made when dropout > 0 (not a reference option): "reference" | "device"
+        self.prune_draws: str = prune_draws or os.environ.get("SKR_PRUNE_DRAWS", "reference")
 
     @classmethod
     def param_space(cls):
@@ -73,6 +82,8 @@ class LayerGCN(AbstractRecommender):
             raise NotImplementedError("the MI355X kernels are specialised for embed_dim=64")
         if not 0.0 <= cfg.dropout < 1.0:
             raise ValueError("dropout must be in [0, 1)")
+        if cfg.prune_draws not in ("reference", "device"):
+            raise ValueError("prune_draws must be 'reference' or 'device'")
         self.device = _hip.require_gpu()
         from ..parallel import init_from_env, ShardedLayerGCN
         self.dist = init_from_env()      # one process per GPU under torchrun; world 1 otherwise
@@ -148,6 +159,17 @@ class LayerGCN(AbstractRecommender):
         col_sum = 1e-7 + torch.zeros(self.num_items, device=u.device).index_add_(0, i, ones)
         return torch.pow(row_sum, -0.5)[u] * torch.pow(col_sum, -0.5)[i]
 
+    def _edge_values_host(self):
+        """edge_values exactly as the reference's CPU run holds them (get_edge_info -> _normalize_adj_m, LayerGCN.py:
+        154-171: integer degree sums, + 1e-7 in float32, torch-CPU pow) -- torch.multinomial's result depends on every bit"""
+        if getattr(self, "_edge_values_cpu", None) is None:
+            u, i = self._edge_u.cpu(), self._edge_i.cpu()
+            ones = torch.ones(u.numel(), dtype=torch.float32)
+            row_sum = 1e-7 + torch.zeros(self.num_users).index_add_(0, u, ones)
+            col_sum = 1e-7 + torch.zeros(self.num_items).index_add_(0, i, ones)
+            self._edge_values_cpu = torch.pow(row_sum, -0.5)[u] * torch.pow(col_sum, -0.5)[i]
+        return self._edge_values_cpu
+
     def pre_epoch_processing(self):
         """edge pruning, once per epoch (LayerGCN.py:133-152); a no-op when dropout == 0"""
         if self.config.dropout <= 0.0:
@@ -158,8 +180,17 @@ class LayerGCN(AbstractRecommender):
             return
         n_edges = self._edge_values.numel()
         keep_len = int(n_edges * (1.0 - self.config.dropout))
-        if self.pruning_random:
-            keep = torch.randperm(n_edges, device=self.device)[:keep_len]
+        if self.config.prune_draws == "reference":
+            # the reference's own draws, on the host like its CPU run: same generators, same calls, same order
+            if self.pruning_random:
+                keep = torch.tensor(random.sample(range(n_edges), keep_len)).to(self.device)      # LayerGCN.py:141
+            else:
+                keep = torch.multinomial(self._edge_values_host(), keep_len).to(self.device)     # LayerGCN.py:144
+        elif self.pruning_random:
+            keep = torch.empty(keep_len, dtype=torch.int32, device=self.device)
+            _hip.check(_hip.lib().skr_shuffle_permutation(random.getrandbits(63), n_edges, keep_len, _hip.ptr(keep),
+                                                          _hip.stream()))
+            keep = keep.long()
         else:   # prune edges of high-degree nodes preferentially: keep ~ normalised edge value
             keep = torch.multinomial(self._edge_values, keep_len)
         self.pruning_random = True ^ self.pruning_random

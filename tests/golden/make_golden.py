@@ -310,6 +310,44 @@ def make_layergcn():
     print("layergcn: steps", len(losses), "first/last", losses[0], losses[-1])
 
 
+def make_layergcn_dropout():
+    """dropout > 0 (LayerGCN.py:133-152): three epochs = degree-weighted pruning (torch.multinomial on the CPU
+    generator), uniform pruning (Python's random.sample), degree-weighted again; the pruned + re-normalised
+    adjacency of every epoch, the loss trajectory, the reports (evaluation runs on the FULL graph) and the final tables"""
+    _install()
+    import torch
+    torch.set_num_threads(1)
+    import skrec.recommender.LayerGCN as M
+    _seed_all()
+    model = M.LayerGCN(_run_config(recommender="LayerGCN"),
+                       dict(lr=1e-3, reg=1e-2, embed_dim=64, n_layers=3, dropout=0.2, batch_size=256, epochs=3))
+    out = {"U0": model.model.user_embeddings.detach().numpy().copy(),
+           "V0": model.model.item_embeddings.detach().numpy().copy(),
+           "edge_values": model.model.edge_values.numpy().copy(),
+           "edge_indices": model.model.edge_indices.numpy().copy()}
+    losses, masked = [], []
+    oc, op = model.model.calculate_loss, model.model.pre_epoch_processing
+
+    def rc(u, i, j):
+        r = oc(u, i, j); losses.append(float(r)); return r
+
+    def rp():
+        op()
+        a = model.model.masked_adj.coalesce()
+        masked.append((a.indices().numpy().copy(), a.values().numpy().copy()))
+    model.model.calculate_loss, model.model.pre_epoch_processing = rc, rp
+    reports = _record_reports(model)
+    best = model.fit()
+    for e, (idx, val) in enumerate(masked):
+        out[f"masked{e}_idx"], out[f"masked{e}_val"] = idx, val
+    out.update(loss=np.float32(losses), reports=np.stack(reports), names=np.array(model.evaluator.metrics_list),
+               best=np.array(list(best.values()), np.float32), n_epochs=np.int32(len(masked)),
+               U1=model.model.user_embeddings.detach().numpy(), V1=model.model.item_embeddings.detach().numpy())
+    np.savez_compressed(os.path.join(HERE, "golden_layergcn_dropout.npz"), **out)
+    print("layergcn dropout: epochs", len(masked), "steps", len(losses), "kept", [len(v) // 2 for _, v in masked],
+          "first/last", losses[0], losses[-1])
+
+
 def make_iterators():
     """SURVEY 8f-3: the sequential and knowledge-graph iterators, shuffle=False, one process = one stream;
     tests/test_gpu_iterators.py replays the same constructions in the same order."""
@@ -358,7 +396,8 @@ def make_iterators():
 
 
 SECTIONS = {"dataset": make_dataset, "sampler": make_sampler, "eval": make_eval, "bprmf": make_bprmf,
-            "lightgcn": make_lightgcn, "layergcn": make_layergcn, "iterators": make_iterators}
+            "lightgcn": make_lightgcn, "layergcn": make_layergcn, "layergcn_dropout": make_layergcn_dropout,
+            "iterators": make_iterators}
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"

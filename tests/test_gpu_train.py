@@ -197,7 +197,8 @@ def test_gather_axpy_scale():
 
 
 @pytest.mark.parametrize("lazy", [True, False])
-@pytest.mark.parametrize("k,n_steps,t0", [(8, 37, 0), (1, 5, 0), (16, 16, 0), (3, 10, 0), (8, 20, 16595), (8, 16, 40000)])
+@pytest.mark.parametrize("k,n_steps,t0", [(8, 37, 0), (1, 5, 0), (16, 16, 0), (3, 10, 0), (8, 20, 16595), (8, 16, 40000),
+                                          (32, 70, 0), (32, 64, 16580), (32, 32, 300)])
 def test_blocked_adam_is_bit_identical(k, n_steps, t0, lazy):
     """temporally blocked dense Adam (cold blocks: k zero-gradient updates in one pass; hot blocks: the ordinary
     update every step -- or, `lazy`, when a batch is about to read them / has written their gradient, catching up
@@ -261,7 +262,8 @@ def test_blocked_adam_is_bit_identical(k, n_steps, t0, lazy):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,t0,eps,lr", [(8, 0, 1e-8, 1e-3), (16, 20000, 1e-8, 1e-3), (5, 16596, 1e-8, 5e-2), (8, 100, 0.0, 1e-3),
-                                         (8, 3, 1e-3, 1e-3)])
+                                         (8, 3, 1e-3, 1e-3), (32, 0, 1e-8, 1e-3), (32, 16580, 1e-8, 1e-3), (32, 777, 1e-8, 1e-2),
+                                         (32, 50000, 0.0, 1e-3)])
 def test_cold_pass_rest_regime_is_bit_identical(k, t0, eps, lr):
     """cold pass (rows at rest skip the square root and the divisions of the update, see adam_cold_rows_kernel) == k
     calls of skr_adam_step with a zero gradient, BIT FOR BIT, over rows of every age (moments decayed by 0 ... 3000

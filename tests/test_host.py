@@ -216,3 +216,29 @@ def test_native_host_permutation_argument_checks():
     assert L.skr_host_permutation(key.ctypes.data, C.byref(bad), 4, out.ctypes.data) == -1   # position beyond the state
     assert L.skr_host_permutation(key.ctypes.data, C.byref(pos), 0, None) == 0               # empty permutation
     assert pos.value == 624
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 65, 1000, 4097, 262_144, 300_001])
+def test_device_shuffle_bijection_on_the_host(n):
+    """skr_shuffle_permutation_host = the keyed bijection skr_shuffle_gather evaluates per output row:
+    a permutation of [0, n) for every n and seed, different for different seeds, no structure a mini-batch could see"""
+    from skrec import _hip
+    L = _hip.lib()
+    a, b = np.empty(n, np.int32), np.empty(n, np.int32)
+    _hip.check(L.skr_shuffle_permutation_host(2021, n, n, a.ctypes.data))
+    _hip.check(L.skr_shuffle_permutation_host(2022, n, n, b.ctypes.data))
+    assert np.array_equal(np.sort(a), np.arange(n)) and np.array_equal(np.sort(b), np.arange(n))
+    half = np.empty(n // 2, np.int32)
+    _hip.check(L.skr_shuffle_permutation_host(2021, n, n // 2, half.ctypes.data))
+    assert np.array_equal(half, a[:n // 2])                       # a prefix of the same permutation
+    if n >= 1000:
+        assert (a == b).mean() < 0.01 and (a == np.arange(n)).mean() < 0.01
+        x = a.astype(np.float64)
+        assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 0.1
+        # where do the elements of each 1/16 of the source land?  every 1/16 of the output gets its share
+        H = np.zeros((16, 16))
+        np.add.at(H, (np.minimum(np.arange(n) * 16 // n, 15), np.minimum(a.astype(np.int64) * 16 // n, 15)), 1)
+        exp = n / 256
+        assert ((H - exp) ** 2 / exp).sum() / 255 < 2.0           # chi-square per degree of freedom ~ 1
+    assert L.skr_shuffle_permutation_host(1, 5, 6, a.ctypes.data) == -1
+    assert L.skr_shuffle_permutation_host(1, 1 << 31, 1, a.ctypes.data) == -1
