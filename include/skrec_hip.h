@@ -237,6 +237,24 @@ int skr_csr_spmm(int n_rows, const int64_t* d_rowptr, const int32_t* d_col, cons
                  const float* d_X, int dim, int64_t nnz, const float* d_addend, float* d_Y,
                  float* d_accum, float accum_scale, void* stream);
 
+/* The same product through a per-matrix PLAN (csrc/spmm.hip): rows shorter than `long_rows_from` entries are gathered
+ * one wavefront per row with 16 bytes per lane; longer rows are cut into tasks of <= 256 entries inside one block of
+ * 16 384 columns, run block by block on the workgroups that share an XCD's L2, and their partial rows are added in a
+ * fixed order (no float atomics: results do not depend on timing).  Same epilogues as skr_csr_spmm.
+ *   skr_spmm_plan_create  analyses the CSR once (device work, synchronises the stream twice); the plan keeps the three
+ *                         CSR pointers -- the arrays must outlive it and keep their contents -- plus a task list and a
+ *                         scratch buffer of its own.  Columns must ascend within a row and be < n_cols.
+ *                         long_rows_from: 0 = default (512), otherwise >= 2.
+ *   skr_spmm_plan_info    h_info4 = {long rows, tasks, column blocks, long_rows_from}
+ * A plan may be run any number of times, by one stream at a time (the scratch buffer is shared between runs). */
+typedef struct skr_spmm_plan skr_spmm_plan;
+int skr_spmm_plan_create(int n_rows, int n_cols, const int64_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                         int64_t nnz, int long_rows_from, skr_spmm_plan** out, void* stream);
+int skr_spmm_plan_run(const skr_spmm_plan* plan, const float* d_X, int dim, const float* d_addend, float* d_Y,
+                      float* d_accum, float accum_scale, void* stream);
+int skr_spmm_plan_info(const skr_spmm_plan* plan, int64_t* h_info4);
+int skr_spmm_plan_destroy(skr_spmm_plan* plan);
+
 /* LayerGCN layer refinement (LayerGCN.py:214-216): w_r = cos(Y_r, E_r) (torch eps 1e-8),
  * Z_r = w_r * Y_r; d_accum += Z (may be NULL); d_w[n_rows] keeps w for the backward. */
 int skr_layer_refine_fwd(const float* d_Y, const float* d_E, int64_t n_rows, int dim,

@@ -1,0 +1,403 @@
+// spmm.hip -- T7 / T10: the sparse propagation  Y = A X  (d = 64) with a per-matrix PLAN.
+//
+// Replaces torch.sparse.mm of the reference, called once per layer and direction on the full graph for every mini-batch:
+//   recommender/LightGCN.py:89-100   (_forward_gcn: K x torch.sparse.mm + the autograd backward of each)
+//   recommender/LayerGCN.py:207-220  (forward: sparse.mm per layer)
+//
+// A bipartite recommendation graph has two very different kinds of rows.  User rows are short (tens of entries) and
+// gather from the small, popularity-skewed item table, which mostly sits in the XCDs' L2.  Item rows are long (hundreds
+// to ~10^6 entries) and gather from the user table (256 MB at 1 M users), far larger than any cache.  Measured on the
+// 1 M x 100 k x 48 M graph (tools/spmm_lab.py, profiles/r02_spmm_lab.txt), one dword per lane and four row gathers in
+// flight (the round-1 kernel) moved rows at 8.6 / 7.3 TB/s (user / item side).  This file:
+//   * short rows (< SPMM_LONG entries): one wavefront per row, 16 BYTES per lane -- a 16-lane group fetches one 256-byte
+//     row, a wave instruction four rows -- with four such instructions in flight: 15.3 TB/s on the user side;
+//   * long rows: cut into TASKS of <= 256 consecutive entries whose columns lie in one COLUMN BLOCK of 16 384 columns
+//     (a 4 MB slice of X).  Tasks are ordered by block, and launch g lets the workgroups with blockIdx % 8 == x -- which
+//     share an XCD, hence an L2, under the round-robin placement (a speed assumption only) -- work through block 8 g + x:
+//     the slice is fetched into that L2 once and the rows' entries gather from it.  11 TB/s instead of 7 on the long
+//     rows of the item side.  A task leaves a partial row in a scratch buffer; a third kernel adds a row's partial rows
+//     in a fixed order, so results do not depend on timing (the round-1 kernel combined split rows with float atomics).
+// Entries stay where they are in the caller's CSR: a plan is a task list (16 bytes per task), not a copy of the matrix.
+#include "skr_common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int D = 64;
+constexpr int SPMM_LONG = 512;       // rows with at least this many entries are cut into column-blocked tasks
+constexpr int SPMM_CBLK = 16384;     // columns per block: 16 384 rows of X = 4 MB
+constexpr int SPMM_TASK = 256;       // entries per task at most
+constexpr int ROW_WAVES = 4;         // wavefronts per workgroup, both kernels
+constexpr int ROW_NF = 4;            // 16-byte gathers in flight per lane
+constexpr int BLK_WGS_PER_XCD = 256;
+
+struct Task {
+    int64_t beg;     // first entry (index into the caller's col / val)
+    int32_t len;     // 1 .. SPMM_TASK
+    int32_t part;    // slot of its partial row (row-major over the long rows)
+};
+
+// accumulate entries [e, e + m) (m <= 64, held one per lane in cl / vl; lanes >= m hold a valid column and value 0)
+__device__ __forceinline__ void gather_block(const float4* __restrict__ X4, int cl, float vl, int m, int grp, int sub, float4& acc) {
+    int k = 0;
+    for (; k + 4 * ROW_NF <= m; k += 4 * ROW_NF) {
+        float4 x[ROW_NF];
+        float v[ROW_NF];
+#pragma unroll
+        for (int q = 0; q < ROW_NF; ++q) {
+            x[q] = X4[static_cast<int64_t>(__shfl(cl, k + 4 * q + grp)) * 16 + sub];
+            v[q] = __shfl(vl, k + 4 * q + grp);
+        }
+#pragma unroll
+        for (int q = 0; q < ROW_NF; ++q) {
+            acc.x = fmaf(v[q], x[q].x, acc.x); acc.y = fmaf(v[q], x[q].y, acc.y);
+            acc.z = fmaf(v[q], x[q].z, acc.z); acc.w = fmaf(v[q], x[q].w, acc.w);
+        }
+    }
+    for (; k < m; k += 4) {   // every lane takes part in both shuffles (a bpermute reads 0 from a masked-off lane)
+        const float4 x = X4[static_cast<int64_t>(__shfl(cl, k + grp)) * 16 + sub];
+        const float v = __shfl(vl, k + grp);
+        acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y); acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
+    }
+}
+
+// the four 16-lane groups hold partial sums of the same four dims: add them up (afterwards every group holds the total)
+__device__ __forceinline__ void sum_groups(float4& acc) {
+    acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+    acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+}
+
+__device__ __forceinline__ void finish_row(float4 y, int64_t r, int sub, const float* __restrict__ addend, float* __restrict__ Y,
+                                           float* __restrict__ accum, float accum_scale) {
+    if (addend) {
+        const float4 a = reinterpret_cast<const float4*>(addend)[r * 16 + sub];
+        y.x += a.x; y.y += a.y; y.z += a.z; y.w += a.w;
+    }
+    reinterpret_cast<float4*>(Y)[r * 16 + sub] = y;
+    if (accum) {
+        float4 c = reinterpret_cast<float4*>(accum)[r * 16 + sub];
+        c.x += accum_scale * y.x; c.y += accum_scale * y.y; c.z += accum_scale * y.z; c.w += accum_scale * y.w;
+        reinterpret_cast<float4*>(accum)[r * 16 + sub] = c;
+    }
+}
+
+// rows shorter than `long_thr`: one wavefront per row (empty rows included: Y = addend)
+__global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, int long_thr, const int64_t* __restrict__ rowptr,
+                                                                   const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                                   const float* __restrict__ X, const float* __restrict__ addend,
+                                                                   float* __restrict__ Y, float* __restrict__ accum, float accum_scale) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int grp = lane >> 4, sub = lane & 15;
+    const float4* X4 = reinterpret_cast<const float4*>(X);
+    for (int64_t r = blockIdx.x * ROW_WAVES + wv; r < n_rows; r += static_cast<int64_t>(gridDim.x) * ROW_WAVES) {
+        const int64_t rb = rowptr[r], re = rowptr[r + 1];
+        if (re - rb >= long_thr) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t e = rb; e < re; e += 64) {
+            const int m = static_cast<int>(re - e < 64 ? re - e : 64);
+            int cl = 0;
+            float vl = 0.0f;
+            if (lane < m) { cl = col[e + lane]; vl = val[e + lane]; }
+            gather_block(X4, cl, vl, m, grp, sub, acc);
+        }
+        sum_groups(acc);
+        if (grp == 0) finish_row(acc, r, sub, addend, Y, accum, accum_scale);
+    }
+}
+
+// long rows: the tasks of column block 8 * group + (blockIdx % 8)
+__global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_t* __restrict__ first_task, int n_long, int n_blocks, int group,
+                                                                    const Task* __restrict__ tasks, const int32_t* __restrict__ col,
+                                                                    const float* __restrict__ val, const float* __restrict__ X,
+                                                                    float* __restrict__ part) {
+    const int b = group * 8 + (blockIdx.x & 7);
+    if (b >= n_blocks) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int grp = lane >> 4, sub = lane & 15;
+    const float4* X4 = reinterpret_cast<const float4*>(X);
+    const int64_t n_w = static_cast<int64_t>(gridDim.x >> 3) * ROW_WAVES;
+    const int64_t t_end = first_task[static_cast<int64_t>(b + 1) * n_long];
+    for (int64_t t = first_task[static_cast<int64_t>(b) * n_long] + (blockIdx.x >> 3) * ROW_WAVES + wv; t < t_end; t += n_w) {
+        const Task tk = tasks[t];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e0 = 0; e0 < tk.len; e0 += 64) {
+            const int m = tk.len - e0 < 64 ? tk.len - e0 : 64;
+            int cl = col[tk.beg];          // padding lanes gather the task's first column: an address inside the block
+            float vl = 0.0f;
+            if (lane < m) { cl = col[tk.beg + e0 + lane]; vl = val[tk.beg + e0 + lane]; }
+            gather_block(X4, cl, vl, m, grp, sub, acc);
+        }
+        sum_groups(acc);
+        if (grp == 0) reinterpret_cast<float4*>(part)[static_cast<int64_t>(tk.part) * 16 + sub] = acc;
+    }
+}
+
+// a long row = the sum of its partial rows, added in slot order by one workgroup: every wavefront sums a contiguous
+// quarter of the row's slots (8 loads in flight), the four sums are combined in wave order
+__global__ __launch_bounds__(256) void spmm_reduce_kernel(const int32_t* __restrict__ long_rows, const int64_t* __restrict__ part_ptr,
+                                                          const float* __restrict__ part, const float* __restrict__ addend,
+                                                          float* __restrict__ Y, float* __restrict__ accum, float accum_scale) {
+    __shared__ float s[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t b = part_ptr[blockIdx.x], n = part_ptr[blockIdx.x + 1] - b;
+    const int64_t q0 = b + n * wv / 4, q1 = b + n * (wv + 1) / 4;
+    float acc = 0.0f;
+    int64_t t = q0;
+    for (; t + 8 <= q1; t += 8) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = part[(t + j) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += x[j];
+    }
+    for (; t < q1; ++t) acc += part[t * 64 + lane];
+    s[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0) {
+        const int64_t r = long_rows[blockIdx.x];
+        float y = ((s[0][lane] + s[1][lane]) + s[2][lane]) + s[3][lane];
+        if (addend) y += addend[r * D + lane];
+        Y[r * D + lane] = y;
+        if (accum) accum[r * D + lane] += accum_scale * y;
+    }
+}
+
+// ---- plan construction --------------------------------------------------------------------------------------------
+__global__ void flag_long_kernel(int n_rows, int thr, const int64_t* __restrict__ rowptr, int64_t* __restrict__ flag) {
+    const int64_t r = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (r < n_rows) flag[r] = (rowptr[r + 1] - rowptr[r] >= thr) ? 1 : 0;
+    if (r == n_rows) flag[r] = 0;
+}
+
+// in-place exclusive scan of n int64 values by ONE workgroup (plan construction only: n is a few 10^5 .. 10^6)
+__global__ __launch_bounds__(1024) void scan_kernel(int64_t* __restrict__ a, int64_t n) {
+    __shared__ int64_t s_wave[16];
+    __shared__ int64_t s_carry;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < n ? a[i] : 0;
+        int64_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) s_wave[wv] = inc;
+        __syncthreads();
+        int64_t before = s_carry;
+        for (int w = 0; w < wv; ++w) before += s_wave[w];
+        if (i < n) a[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + inc;
+        __syncthreads();
+    }
+}
+
+__global__ void compact_long_kernel(int n_rows, const int64_t* __restrict__ rowptr, int thr, const int64_t* __restrict__ slot_of,
+                                    int32_t* __restrict__ long_rows) {
+    const int64_t r = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (r < n_rows && rowptr[r + 1] - rowptr[r] >= thr) long_rows[slot_of[r]] = static_cast<int32_t>(r);
+}
+
+// first entry of long row `s` whose column is >= c  (columns ascend within a row)
+__device__ __forceinline__ int64_t lower_col(const int32_t* __restrict__ col, int64_t lo, int64_t hi, int64_t c) {
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (col[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// tasks per (block, long row) segment, written twice: block-major (the order the tasks run in) and row-major (the order
+// the partial rows are stored and added in)
+__global__ void count_tasks_kernel(int n_long, int n_blocks, int cblk, const int32_t* __restrict__ long_rows,
+                                   const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                   int64_t* __restrict__ cnt_block_major, int64_t* __restrict__ cnt_row_major) {
+    const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (i >= static_cast<int64_t>(n_long) * n_blocks) return;
+    const int s = static_cast<int>(i / n_blocks), b = static_cast<int>(i % n_blocks);
+    const int64_t r = long_rows[s], rb = rowptr[r], re = rowptr[r + 1];
+    const int64_t e0 = lower_col(col, rb, re, static_cast<int64_t>(b) * cblk);
+    const int64_t e1 = lower_col(col, e0, re, static_cast<int64_t>(b + 1) * cblk);
+    const int64_t nt = (e1 - e0 + SPMM_TASK - 1) / SPMM_TASK;
+    cnt_block_major[static_cast<int64_t>(b) * n_long + s] = nt;
+    cnt_row_major[i] = nt;
+}
+
+__global__ void fill_tasks_kernel(int n_long, int n_blocks, int cblk, const int32_t* __restrict__ long_rows,
+                                  const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                  const int64_t* __restrict__ first_block_major, const int64_t* __restrict__ first_row_major,
+                                  Task* __restrict__ tasks) {
+    const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (i >= static_cast<int64_t>(n_long) * n_blocks) return;
+    const int s = static_cast<int>(i / n_blocks), b = static_cast<int>(i % n_blocks);
+    const int64_t r = long_rows[s], rb = rowptr[r], re = rowptr[r + 1];
+    const int64_t e0 = lower_col(col, rb, re, static_cast<int64_t>(b) * cblk);
+    const int64_t e1 = lower_col(col, e0, re, static_cast<int64_t>(b + 1) * cblk);
+    int64_t t = first_block_major[static_cast<int64_t>(b) * n_long + s];
+    int64_t p = first_row_major[i];
+    for (int64_t e = e0; e < e1; e += SPMM_TASK, ++t, ++p) {
+        Task tk;
+        tk.beg = e;
+        tk.len = static_cast<int32_t>(e1 - e < SPMM_TASK ? e1 - e : SPMM_TASK);
+        tk.part = static_cast<int32_t>(p);
+        tasks[t] = tk;
+    }
+}
+
+__global__ void part_ptr_kernel(int n_long, int n_blocks, const int64_t* __restrict__ first_row_major, int64_t* __restrict__ part_ptr) {
+    const int64_t s = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (s <= n_long) part_ptr[s] = first_row_major[s * n_blocks];
+}
+
+}  // namespace
+
+struct skr_spmm_plan {
+    int n_rows = 0, n_cols = 0;
+    int64_t nnz = 0;
+    const int64_t* rowptr = nullptr;     // the caller's CSR (device memory, must outlive the plan)
+    const int32_t* col = nullptr;
+    const float* val = nullptr;
+    int long_thr = SPMM_LONG, cblk = SPMM_CBLK, n_blocks = 0, n_long = 0;
+    int64_t n_tasks = 0;
+    int32_t* long_rows = nullptr;        // [n_long] row ids, ascending
+    int64_t* first_task = nullptr;       // [n_blocks * n_long + 1] block-major
+    int64_t* part_ptr = nullptr;         // [n_long + 1] a row's partial-row slots
+    Task* tasks = nullptr;               // [n_tasks] block-major
+    float* part = nullptr;               // [n_tasks, 64]
+};
+
+namespace {
+void free_plan(skr_spmm_plan* p) {
+    if (!p) return;
+    (void)hipFree(p->long_rows);
+    (void)hipFree(p->first_task);
+    (void)hipFree(p->part_ptr);
+    (void)hipFree(p->tasks);
+    (void)hipFree(p->part);
+    delete p;
+}
+}  // namespace
+
+extern "C" {
+
+int skr_spmm_plan_create(int n_rows, int n_cols, const int64_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t nnz,
+                         int long_rows_from, skr_spmm_plan** out, void* stream) {
+    SKR_REQUIRE(out, "skr_spmm_plan_create: NULL output");
+    *out = nullptr;
+    SKR_REQUIRE(d_rowptr && d_col && d_val, "skr_spmm_plan_create: NULL argument");
+    SKR_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "skr_spmm_plan_create: negative size");
+    SKR_REQUIRE(long_rows_from == 0 || long_rows_from >= 2, "skr_spmm_plan_create: long_rows_from must be 0 (default) or >= 2");
+    hipStream_t st = skr::as_stream(stream);
+    skr_spmm_plan* p = new skr_spmm_plan();
+    p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = nnz;
+    p->rowptr = d_rowptr; p->col = d_col; p->val = d_val;
+    if (long_rows_from) p->long_thr = long_rows_from;
+    p->n_blocks = (n_cols + p->cblk - 1) / p->cblk;
+    *out = p;
+    if (n_rows == 0 || nnz == 0 || p->n_blocks == 0) return SKR_OK;
+    // 1. the long rows, in ascending order
+    int64_t* slot_of = nullptr;
+#define PLAN_HIP(call)                                                                                     \
+    do {                                                                                                   \
+        hipError_t e__ = (call);                                                                           \
+        if (e__ != hipSuccess) {                                                                           \
+            (void)hipFree(slot_of); (void)hipFree(cnt_rm);                                                 \
+            free_plan(p); *out = nullptr;                                                                  \
+            return skr::fail(SKR_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+        }                                                                                                  \
+    } while (0)
+    int64_t* cnt_rm = nullptr;
+    PLAN_HIP(hipMalloc(&slot_of, sizeof(int64_t) * (static_cast<size_t>(n_rows) + 1)));
+    hipLaunchKernelGGL(flag_long_kernel, dim3(static_cast<unsigned>((n_rows + 1 + 255) / 256)), dim3(256), 0, st, n_rows, p->long_thr,
+                       d_rowptr, slot_of);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, slot_of, static_cast<int64_t>(n_rows) + 1);
+    int64_t n_long = 0;
+    PLAN_HIP(hipMemcpyAsync(&n_long, slot_of + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PLAN_HIP(hipStreamSynchronize(st));
+    p->n_long = static_cast<int>(n_long);
+    if (n_long > 0) {
+        PLAN_HIP(hipMalloc(&p->long_rows, sizeof(int32_t) * n_long));
+        hipLaunchKernelGGL(compact_long_kernel, dim3(static_cast<unsigned>((n_rows + 255) / 256)), dim3(256), 0, st, n_rows, d_rowptr,
+                           p->long_thr, slot_of, p->long_rows);
+        // 2. tasks per (block, row) segment, both orders, and their prefix sums
+        const int64_t n_seg = n_long * p->n_blocks;
+        PLAN_HIP(hipMalloc(&p->first_task, sizeof(int64_t) * (n_seg + 1)));
+        PLAN_HIP(hipMalloc(&cnt_rm, sizeof(int64_t) * (n_seg + 1)));
+        PLAN_HIP(hipMemsetAsync(p->first_task + n_seg, 0, sizeof(int64_t), st));
+        PLAN_HIP(hipMemsetAsync(cnt_rm + n_seg, 0, sizeof(int64_t), st));
+        const dim3 sgrid(static_cast<unsigned>((n_seg + 255) / 256));
+        hipLaunchKernelGGL(count_tasks_kernel, sgrid, dim3(256), 0, st, p->n_long, p->n_blocks, p->cblk, p->long_rows, d_rowptr, d_col,
+                           p->first_task, cnt_rm);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, p->first_task, n_seg + 1);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, cnt_rm, n_seg + 1);
+        PLAN_HIP(hipMemcpyAsync(&p->n_tasks, p->first_task + n_seg, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        PLAN_HIP(hipStreamSynchronize(st));
+        if (p->n_tasks >= (int64_t{1} << 31)) {
+            (void)hipFree(slot_of); (void)hipFree(cnt_rm);
+            free_plan(p); *out = nullptr;
+            return skr::fail(SKR_EINVAL, "skr_spmm_plan_create: too many tasks (%lld)", static_cast<long long>(p->n_tasks));
+        }
+        PLAN_HIP(hipMalloc(&p->tasks, sizeof(Task) * std::max<int64_t>(p->n_tasks, 1)));
+        PLAN_HIP(hipMalloc(&p->part, sizeof(float) * D * std::max<int64_t>(p->n_tasks, 1)));
+        PLAN_HIP(hipMalloc(&p->part_ptr, sizeof(int64_t) * (n_long + 1)));
+        hipLaunchKernelGGL(fill_tasks_kernel, sgrid, dim3(256), 0, st, p->n_long, p->n_blocks, p->cblk, p->long_rows, d_rowptr, d_col,
+                           p->first_task, cnt_rm, p->tasks);
+        hipLaunchKernelGGL(part_ptr_kernel, dim3(static_cast<unsigned>((n_long + 1 + 255) / 256)), dim3(256), 0, st, p->n_long, p->n_blocks,
+                           cnt_rm, p->part_ptr);
+        PLAN_HIP(hipStreamSynchronize(st));
+    }
+    PLAN_HIP(hipGetLastError());
+    (void)hipFree(slot_of);
+    (void)hipFree(cnt_rm);
+#undef PLAN_HIP
+    return SKR_OK;
+}
+
+int skr_spmm_plan_destroy(skr_spmm_plan* plan) {
+    free_plan(plan);
+    return SKR_OK;
+}
+
+int skr_spmm_plan_info(const skr_spmm_plan* plan, int64_t* h_info4) {
+    SKR_REQUIRE(plan && h_info4, "skr_spmm_plan_info: NULL argument");
+    h_info4[0] = plan->n_long;
+    h_info4[1] = plan->n_tasks;
+    h_info4[2] = plan->n_blocks;
+    h_info4[3] = plan->long_thr;
+    return SKR_OK;
+}
+
+int skr_spmm_plan_run(const skr_spmm_plan* plan, const float* d_X, int dim, const float* d_addend, float* d_Y, float* d_accum,
+                      float accum_scale, void* stream) {
+    SKR_REQUIRE(plan && d_X && d_Y, "skr_spmm_plan_run: NULL argument");
+    SKR_REQUIRE(dim == D, "skr_spmm_plan_run: dim must be 64 (got %d)", dim);
+    SKR_REQUIRE(d_Y != d_X, "skr_spmm_plan_run: in-place propagation is not supported");
+    if (plan->n_rows == 0) return SKR_OK;
+    hipStream_t st = skr::as_stream(stream);
+    int64_t wgs = (static_cast<int64_t>(plan->n_rows) + ROW_WAVES - 1) / ROW_WAVES;
+    if (wgs > 8192) wgs = 8192;
+    hipLaunchKernelGGL(spmm_rows_kernel, dim3(static_cast<unsigned>(wgs)), dim3(ROW_WAVES * 64), 0, st, plan->n_rows, plan->long_thr,
+                       plan->rowptr, plan->col, plan->val, d_X, d_addend, d_Y, d_accum, accum_scale);
+    SKR_LAUNCH_CHECK();
+    if (plan->n_long > 0) {
+        if (plan->n_tasks > 0) {
+            const int groups = (plan->n_blocks + 7) / 8;
+            for (int g = 0; g < groups; ++g)
+                hipLaunchKernelGGL(spmm_tasks_kernel, dim3(8 * BLK_WGS_PER_XCD), dim3(ROW_WAVES * 64), 0, st, plan->first_task, plan->n_long,
+                                   plan->n_blocks, g, plan->tasks, plan->col, plan->val, d_X, plan->part);
+            SKR_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(spmm_reduce_kernel, dim3(plan->n_long), dim3(256), 0, st, plan->long_rows, plan->part_ptr, plan->part, d_addend,
+                           d_Y, d_accum, accum_scale);
+        SKR_LAUNCH_CHECK();
+    }
+    return SKR_OK;
+}
+
+}  // extern "C"

@@ -59,6 +59,10 @@ SIGNATURES = {
     "skr_bpr_step_spread": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "skr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, vp]),
     "skr_csr_spmm": (i32, [i32, vp, vp, vp, vp, i32, i64, vp, vp, vp, f32, vp]),
+    "skr_spmm_plan_create": (i32, [i32, i32, vp, vp, vp, i64, i32, C.POINTER(vp), vp]),
+    "skr_spmm_plan_run": (i32, [vp, vp, i32, vp, vp, vp, f32, vp]),
+    "skr_spmm_plan_info": (i32, [vp, C.POINTER(i64)]),
+    "skr_spmm_plan_destroy": (i32, [vp]),
     "skr_layer_refine_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp]),
     "skr_layer_refine_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "skr_gather_rows": (i32, [vp, vp, i64, i32, vp, vp]),

@@ -88,8 +88,44 @@ class DeviceCSR(object):
             self.val = torch.zeros(1, dtype=torch.float32, device=rows.device)
         return self
 
+    # matrices with at least this many non-zeros are multiplied through a plan (skr_spmm_plan_*: 16-byte gathers, long rows
+    # column-blocked); smaller ones through the plan-free kernel.  SKR_SPMM_PLAN=0 / 1 forces one or the other.
+    PLAN_MIN_NNZ = 1 << 16
+
+    def _plan_handle(self, long_rows_from=0):
+        """the matrix's plan, built at the first product (one-time analysis on the device)"""
+        h = getattr(self, "_plan", None)
+        if h is None:
+            import ctypes
+            h = ctypes.c_void_p()
+            _hip.check(_hip.lib().skr_spmm_plan_create(self.shape[0], self.shape[1], _hip.ptr(self.rowptr), _hip.ptr(self.col),
+                                                       _hip.ptr(self.val), self.nnz, int(long_rows_from), ctypes.byref(h),
+                                                       _hip.stream()))
+            self._plan = h
+        return h
+
+    def plan_info(self):
+        import ctypes
+        info = (ctypes.c_int64 * 4)()
+        _hip.check(_hip.lib().skr_spmm_plan_info(self._plan_handle(), info))
+        return dict(long_rows=info[0], tasks=info[1], column_blocks=info[2], long_rows_from=info[3])
+
+    def __del__(self):
+        h = getattr(self, "_plan", None)
+        if h is not None:
+            try:
+                _hip.lib().skr_spmm_plan_destroy(h)
+            except Exception:   # noqa: BLE001 -- interpreter shutdown
+                pass
+            self._plan = None
+
     def spmm(self, X, Y, addend=None, accum=None, accum_scale=1.0):
         """Y = A @ X (+ addend); accum += accum_scale * Y"""
+        mode = os.environ.get("SKR_SPMM_PLAN", "auto")
+        if mode == "1" or (mode != "0" and self.nnz >= self.PLAN_MIN_NNZ):
+            _hip.check(_hip.lib().skr_spmm_plan_run(self._plan_handle(), _hip.ptr(X), 64, _hip.ptr(addend), _hip.ptr(Y),
+                                                    _hip.ptr(accum), float(accum_scale), _hip.stream()))
+            return Y
         _hip.check(_hip.lib().skr_csr_spmm(self.shape[0], _hip.ptr(self.rowptr), _hip.ptr(self.col), _hip.ptr(self.val),
                                            _hip.ptr(X), 64, self.nnz, _hip.ptr(addend), _hip.ptr(Y), _hip.ptr(accum),
                                            float(accum_scale), _hip.stream()))

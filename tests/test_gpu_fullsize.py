@@ -179,3 +179,94 @@ def test_blocked_adam_full_size_is_bit_identical(big):
     assert float(c.grad.abs().max()) == 0.0
     moved = (a.flat != init).view(-1)[:U * 64].view(U, 64).any(1).float().mean()
     assert 0.01 < float(moved) < 0.9          # rows at rest did not move, touched and lively rows did
+
+
+def test_lightgcn_full_size_propagation_and_step(big):
+    """BASELINE configs[2] at size: LightGCN, 3 layers, 'pre' adjacency of the 1 M-user / 100 k-item / 48 M-interaction
+    graph (1.1 M rows, 97 M non-zeros), reference LightGCN.py:89-100,180-199.
+    (1) the propagation kernel: skr_spmm_plan_* (and the plan-free skr_csr_spmm) on the full adjacency vs a float64 host
+        computation of sampled rows -- user rows, the ten longest item rows (~10^5..10^6 entries, cut into thousands of
+        column-blocked tasks), short item rows, an empty row;
+    (2) the layer mean of `propagate()` on all 1.1 M rows vs the oracle's fp32 propagation (oracle.lightgcn_propagate);
+    (3) one train_step of the user-sharded engine (world = 1): its (bpr mean, l2) against the oracle's BPR maths on the
+        oracle's propagated tables, 1e-5 relative; its gradient of the ego table against the oracle's explicit backward
+        (oracle.lightgcn_step) on sampled rows."""
+    import scipy.sparse as sp
+    import torch
+    from skrec import _hip
+    from skrec.parallel import DistContext, ShardedLightGCN
+    from skrec.recommender.LightGCN import build_adjacency_device
+    from skrec.utils.py.random import DeviceSampler
+    dev = torch.device("cuda", 0)
+    N = U + I
+    users, items = big["users"], big["items"]
+    adj, adj_t = build_adjacency_device(users, items, U, I, "pre", dev)
+    assert adj_t is adj and adj.shape == (N, N) and adj.nnz == 2 * users.numel()
+    rp, col, val = (t.cpu().numpy() for t in (adj.rowptr, adj.col, adj.val))
+    A = sp.csr_matrix((val, col, rp), shape=(N, N))
+    g = torch.Generator(device=dev).manual_seed(11)
+    X = torch.randn(N, 64, generator=g, device=dev) * 0.1
+    Xh = X.cpu().numpy()
+    lens = np.diff(rp)
+    rng = np.random.default_rng(3)
+    rows = np.unique(np.concatenate([rng.integers(0, U, 1500), U + rng.integers(0, I, 1500), np.argsort(lens)[-10:],
+                                     np.flatnonzero(lens == 0)[:3], np.flatnonzero((lens >= 500) & (lens <= 520))[:20]]))
+    want = np.stack([(val[rp[r]:rp[r + 1]].astype(np.float64)[:, None] * Xh[col[rp[r]:rp[r + 1]]].astype(np.float64)).sum(0) for r in rows])
+    mass = np.stack([(np.abs(val[rp[r]:rp[r + 1]]).astype(np.float64)[:, None] * np.abs(Xh[col[rp[r]:rp[r + 1]]])).sum(0) for r in rows])
+    info = adj.plan_info()
+    assert info["long_rows"] == int((lens >= 512).sum()) > 1000 and info["tasks"] > info["long_rows"]
+    Y = torch.empty_like(X)
+    for plan in ("1", "0"):
+        import os
+        os.environ["SKR_SPMM_PLAN"] = plan
+        try:
+            Y.fill_(7.0)
+            adj.spmm(X, Y)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SKR_SPMM_PLAN")
+        got = Y[torch.from_numpy(rows).to(dev)].cpu().numpy()
+        assert np.all(np.abs(got - want) <= 2e-6 * mass + 1e-7), (plan, np.abs(got - want).max())
+    # (2) + (3): the engine
+    ctx = DistContext(0, 1)
+    bound_u, bound_i = (6.0 / (U + 64)) ** 0.5, (6.0 / (I + 64)) ** 0.5
+    user0 = (torch.rand(U, 64, generator=torch.Generator().manual_seed(1)) * 2 - 1) * bound_u
+    item0 = (torch.rand(I, 64, generator=torch.Generator().manual_seed(2)) * 2 - 1) * bound_i
+    b, reg = 1024, 1e-3
+    eng = ShardedLightGCN.from_device_edges(ctx, users, items, U, I, user0, item0, 3, 1e-3, reg, b)
+    E0 = torch.cat([user0, item0]).numpy()
+    Ebar = O.lightgcn_propagate(A, E0, 3)                       # the oracle's fp32 propagation (scipy, ~10 s per layer)
+    final = eng.propagate().cpu().numpy()
+    np.testing.assert_allclose(final, Ebar, rtol=0, atol=5e-6 * np.abs(Ebar).max())
+    n_pref = 2000
+    nnz = int(big["rowptr"][n_pref])
+    neg = torch.empty(nnz, dtype=torch.int32, device=dev)
+    DeviceSampler(2020).sample_epoch_exact(I, n_pref, big["rowptr"][:n_pref + 1].contiguous(), items[:nnz], nnz, 1, neg)
+    sel = torch.from_numpy(rng.permutation(nnz)[:b]).to(dev)
+    bu, bi, bj = users[:nnz][sel].contiguous(), items[:nnz][sel].contiguous(), neg[sel].contiguous()
+    g_before = eng._g_ego.clone()
+    assert float(g_before.abs().max()) == 0.0
+    # take the gradient before Adam consumes it: run the step with the optimiser's step() disabled
+    step = eng.optimizer.step
+    eng.optimizer.step = lambda: None
+    try:
+        eng.train_step(bu, bi, bj)
+    finally:
+        eng.optimizer.step = step
+    torch.cuda.synchronize()
+    hu, hi, hj = bu.cpu().numpy(), bi.cpu().numpy(), bj.cpu().numpy()
+    loss, l2, _, _, _, _, _ = O.bpr_batch(Ebar[:U], Ebar[U:], None, E0[:U], E0[U:], hu, hi, hj, 1.0 / b, reg, 1.0 / b)
+    got = eng.loss.cpu().numpy()
+    np.testing.assert_allclose(got[0], loss, rtol=1e-5)
+    np.testing.assert_allclose(got[1], l2, rtol=1e-5)
+    # the oracle's explicit backward (oracle.lightgcn_step's steps, re-using Ebar; A is symmetric, so A^T = A)
+    _, _, gPu, gQi, _, gRu, gRi = O.bpr_batch(Ebar[:U], Ebar[U:], None, E0[:U], E0[U:], hu, hi, hj, 1.0 / b, reg, 1.0 / b)
+    H = (np.concatenate([gPu, gQi], 0) * np.float32(0.25)).astype(np.float32)
+    G = H
+    for _ in range(3):
+        G = (A @ G).astype(np.float32) + H
+    G = G + np.concatenate([gRu, gRi], 0)
+    probe = np.unique(np.concatenate([hu[:200], U + hi[:200], U + hj[:200], rng.integers(0, N, 2000), np.argsort(lens)[-5:]]))
+    gg = eng._g_ego[torch.from_numpy(probe).to(dev)].cpu().numpy()
+    scale = np.abs(G).max()
+    np.testing.assert_allclose(gg, G[probe], rtol=2e-5, atol=2e-6 * scale)

@@ -110,11 +110,15 @@ def test_bpr_step_marks_touched_blocks():
     assert np.all(t[nz]) and t.sum() <= len(set(u)) + 2 * len(set(i) | set(j)) + 2
 
 
+@pytest.mark.parametrize("plan", ["0", "1"])
 @pytest.mark.parametrize("n_rows,density,heavy", [(50, 0.2, 0), (3000, 0.004, 2), (20000, 0.0005, 3)])
-def test_csr_spmm_vs_scipy(n_rows, density, heavy):
+def test_csr_spmm_vs_scipy(n_rows, density, heavy, plan, monkeypatch):
+    """both forms of the product: the plan-free kernel (plan = "0") and skr_spmm_plan_* (plan = "1": the heavy rows
+    here exceed 512 entries, so they are cut into column-blocked tasks and re-assembled from partial rows)"""
     import torch
     from gpu_utils import dev
     from skrec.recommender.LightGCN import DeviceCSR
+    monkeypatch.setenv("SKR_SPMM_PLAN", plan)
     rng = np.random.default_rng(n_rows)
     A = sp.random(n_rows, n_rows, density=density, format="lil", random_state=rng, dtype=np.float32)
     for h in range(heavy):  # rows far longer than one 512-nnz chunk -> split rows + atomics
@@ -143,6 +147,75 @@ def test_csr_spmm_vs_scipy(n_rows, density, heavy):
     torch.cuda.synchronize()
     close(Y.cpu().numpy(), want + add)
     close(dacc.cpu().numpy(), acc0 + 0.25 * (want + add))
+    if plan == "1":
+        info = csr.plan_info()
+        assert info["long_rows"] == heavy and (info["tasks"] > 0) == (heavy > 0), info
+
+
+@pytest.mark.parametrize("n_rows,n_cols,long_from", [(300, 40_000, 2), (1000, 70_000, 8), (64, 200_000, 100), (5000, 33_000, 0), (7, 5, 2)])
+def test_spmm_plan_rectangular_blocks_and_determinism(n_rows, n_cols, long_from):
+    """skr_spmm_plan_* on rectangular matrices whose long rows span several 16 384-column blocks (tasks of every length
+    1..256, rows of exactly the threshold, empty rows, a row touching only the last block), with the long-row threshold
+    lowered so that small cases exercise the task path; repeated runs are BIT-identical (partial rows are added in a
+    fixed order -- no float atomics), epilogues included; argument checks"""
+    import ctypes as C
+    import torch
+    from gpu_utils import dev, to_dev
+    from skrec import _hip
+    L = _hip.lib()
+    rng = np.random.default_rng(n_rows * 7 + long_from)
+    lens = np.minimum(rng.integers(0, 40, n_rows) ** 2 // 3, n_cols)
+    lens[rng.integers(0, n_rows, max(1, n_rows // 50))] = min(n_cols, 3000)          # long rows across many blocks
+    lens[0] = 0
+    if long_from >= 2 and n_rows > 3:
+        lens[1], lens[2] = min(long_from, n_cols), min(long_from, n_cols) - 1          # exactly at / just under the threshold
+    rowptr = np.zeros(n_rows + 1, np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    col = np.concatenate([np.sort(rng.choice(n_cols, l, replace=False)) for l in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    if n_rows > 5 and lens[5] > 0:
+        b, e = rowptr[5], rowptr[6]
+        col[b:e] = np.arange(n_cols - (e - b), n_cols)                                 # only the last columns
+    val = rng.standard_normal(len(col)).astype(np.float32)
+    nnz = len(col)
+    A = sp.csr_matrix((val, col, rowptr), shape=(n_rows, n_cols))
+    X = rng.standard_normal((n_cols, 64)).astype(np.float32)
+    add = rng.standard_normal((n_rows, 64)).astype(np.float32)
+    acc0 = rng.standard_normal((n_rows, 64)).astype(np.float32)
+    d_rp, d_col, d_val = to_dev(rowptr), to_dev(col if nnz else np.zeros(1, np.int32)), to_dev(val if nnz else np.zeros(1, np.float32))
+    dX, dadd = to_dev(X), to_dev(add)
+    h = C.c_void_p()
+    _hip.check(L.skr_spmm_plan_create(n_rows, n_cols, _hip.ptr(d_rp), _hip.ptr(d_col), _hip.ptr(d_val), nnz, long_from, C.byref(h), _hip.stream()))
+    info = (C.c_int64 * 4)()
+    _hip.check(L.skr_spmm_plan_info(h, info))
+    thr = long_from or 512
+    assert info[0] == int((lens >= thr).sum()) and info[2] == -(-n_cols // 16384) and info[3] == thr
+    # tasks: one per 256 entries of every (long row, column block) segment
+    want_tasks = 0
+    for r in np.flatnonzero(lens >= thr):
+        blk = col[rowptr[r]:rowptr[r + 1]] // 16384
+        want_tasks += int(sum(-(-c // 256) for c in np.bincount(blk)))
+    assert info[1] == want_tasks
+    outs = []
+    for rep in range(3):
+        Y = torch.full((n_rows, 64), 7.0, device=dev())
+        acc = to_dev(acc0.copy())
+        _hip.check(L.skr_spmm_plan_run(h, _hip.ptr(dX), 64, _hip.ptr(dadd), _hip.ptr(Y), _hip.ptr(acc), 0.5, _hip.stream()))
+        torch.cuda.synchronize()
+        outs.append((Y.cpu().numpy(), acc.cpu().numpy()))
+    for y, a in outs[1:]:
+        assert np.array_equal(y.view(np.int32), outs[0][0].view(np.int32)) and np.array_equal(a.view(np.int32), outs[0][1].view(np.int32))
+    want = A.astype(np.float64) @ X.astype(np.float64) + add
+    mass = abs(A).astype(np.float64) @ np.abs(X).astype(np.float64) + np.abs(add)
+    assert np.all(np.abs(outs[0][0] - want) <= 2e-6 * mass + 1e-6)
+    assert np.all(np.abs(outs[0][1] - (acc0 + 0.5 * want)) <= 2e-6 * (mass + np.abs(acc0)) + 1e-6)
+    Y = torch.empty((n_rows, 64), device=dev())
+    assert L.skr_spmm_plan_run(h, _hip.ptr(dX), 32, None, _hip.ptr(Y), None, 1.0, _hip.stream()) == -1
+    assert L.skr_spmm_plan_run(h, _hip.ptr(dX), 64, None, _hip.ptr(dX), None, 1.0, _hip.stream()) == -1
+    assert L.skr_spmm_plan_run(None, _hip.ptr(dX), 64, None, _hip.ptr(Y), None, 1.0, _hip.stream()) == -1
+    _hip.check(L.skr_spmm_plan_destroy(h))
+    h2 = C.c_void_p()
+    assert L.skr_spmm_plan_create(n_rows, n_cols, _hip.ptr(d_rp), _hip.ptr(d_col), _hip.ptr(d_val), nnz, 1, C.byref(h2), _hip.stream()) == -1
+    assert L.skr_spmm_plan_create(n_rows, n_cols, None, _hip.ptr(d_col), _hip.ptr(d_val), nnz, 0, C.byref(h2), _hip.stream()) == -1
 
 
 def test_layer_refine_fwd_bwd_vs_torch_autograd():
