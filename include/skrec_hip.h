@@ -252,6 +252,16 @@ int skr_spmm_plan_create(int n_rows, int n_cols, const int64_t* d_rowptr, const 
                          int64_t nnz, int long_rows_from, skr_spmm_plan** out, void* stream);
 int skr_spmm_plan_run(const skr_spmm_plan* plan, const float* d_X, int dim, const float* d_addend, float* d_Y,
                       float* d_accum, float accum_scale, void* stream);
+/* The same product where parts of it are known not to be needed (LightGCN's step: only the batch's rows of the LAST
+ * forward layer are read, and the gradient that enters the FIRST backward hop is zero outside the batch's rows):
+ *   d_row_mask  uint8[n_rows] or NULL: rows with a 0 byte are skipped entirely (their Y / accum rows are left as they are)
+ *   d_col_mask  uint8[n_cols] or NULL: entries whose column has a 0 byte are skipped -- the caller guarantees that those
+ *               rows of X are zero, so the result is the full product's (up to the sign of a zero)
+ * skr_mark_ids sets d_mask[offset + ids[k]] = 1 (negative ids skipped); clear the mask first. */
+int skr_spmm_plan_run_masked(const skr_spmm_plan* plan, const float* d_X, int dim, const float* d_addend, float* d_Y,
+                             float* d_accum, float accum_scale, const uint8_t* d_row_mask, const uint8_t* d_col_mask,
+                             void* stream);
+int skr_mark_ids(const int32_t* d_ids, int64_t n, int64_t offset, uint8_t* d_mask, void* stream);
 int skr_spmm_plan_info(const skr_spmm_plan* plan, int64_t* h_info4);
 int skr_spmm_plan_destroy(skr_spmm_plan* plan);
 

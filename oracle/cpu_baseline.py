@@ -95,3 +95,30 @@ def time_eval_batches(user_table, item_table, bias, train_rowptr, train_items, t
         t_tot += time.perf_counter() - t0
         n += len(bu)
     return n / t_tot, ("reference" if O.have_ref() else "port")
+
+
+def time_lightgcn_layer(rowptr, col, val, n_nodes, dim, n_layers=3, budget_s=30.0):
+    """The reference's LightGCN step on the host (LightGCN.py:89-100,180-199): K x torch.sparse.mm on the normalised COO
+    adjacency, the autograd backward of each, dense Adam.  A whole step at BASELINE size takes ~45 s on 128 cores, so
+    ONE layer is timed forward + backward (two sparse products) plus one dense Adam update, and the step is extrapolated
+    as n_layers x that layer + Adam.  -> (seconds per step [extrapolated], cores, description)"""
+    import torch
+    import torch.nn as nn
+    rows = np.repeat(np.arange(n_nodes, dtype=np.int64), np.diff(rowptr))
+    idx = torch.from_numpy(np.stack([rows, col.astype(np.int64)]))
+    A = torch.sparse_coo_tensor(idx, torch.from_numpy(val), (n_nodes, n_nodes), is_coalesced=True)
+    E = nn.Parameter(torch.randn(n_nodes, dim) * 0.01)
+    opt = torch.optim.Adam([E], lr=1e-3)
+    t0 = time.perf_counter()
+    y = torch.sparse.mm(A, E)
+    t_fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    y.sum().backward()
+    t_bwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    opt.step()
+    t_adam = time.perf_counter() - t0
+    t_step = n_layers * (t_fwd + t_bwd) + t_adam
+    return t_step, torch.get_num_threads(), (f"one layer of the reference's torch-CPU sequence on the full graph: sparse.mm forward "
+                                             f"{t_fwd:.2f} s + autograd backward {t_bwd:.2f} s, dense Adam {t_adam:.2f} s; step "
+                                             f"extrapolated as {n_layers} x layer + Adam = {t_step:.1f} s")

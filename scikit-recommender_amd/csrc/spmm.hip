@@ -34,10 +34,11 @@ constexpr int ROW_NF = 4;            // 16-byte gathers in flight per lane
 constexpr int BLK_WGS_PER_XCD = 256;
 
 struct Task {
-    int64_t beg;     // first entry (index into the caller's col / val)
-    int32_t len;     // 1 .. SPMM_TASK
-    int32_t part;    // slot of its partial row (row-major over the long rows)
+    int64_t beg;         // first entry (index into the caller's col / val)
+    uint32_t len_slot;   // (length - 1) in the low 8 bits, the long row's slot (index into long_rows) above them
+    int32_t part;        // slot of its partial row (row-major over the long rows)
 };
+static_assert(SPMM_TASK <= 256, "a task's length - 1 is packed into 8 bits");
 
 // accumulate entries [e, e + m) (m <= 64, held one per lane in cl / vl; lanes >= m hold a valid column and value 0)
 __device__ __forceinline__ void gather_block(const float4* __restrict__ X4, int cl, float vl, int m, int grp, int sub, float4& acc) {
@@ -69,6 +70,20 @@ __device__ __forceinline__ void sum_groups(float4& acc) {
     acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
 }
 
+// keep only the entries whose column is marked in `col_mask` (the others would multiply rows of X that are known to be
+// zero): kept entries move to the front of the block in their order, the others behind them with value 0; returns how
+// many were kept.  Every lane takes part in the two permutes.
+__device__ __forceinline__ int keep_marked(const uint8_t* __restrict__ col_mask, int lane, int m, int& cl, float& vl) {
+    const bool keep = lane < m && col_mask[cl] != 0;
+    const unsigned long long b = __ballot(keep);
+    const int kept = __popcll(b);
+    const int below = __popcll(b & ((1ull << lane) - 1ull));
+    const int dst = keep ? below : kept + (lane - below);
+    cl = __builtin_amdgcn_ds_permute(dst << 2, cl);
+    vl = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(keep ? vl : 0.0f)));
+    return kept;
+}
+
 __device__ __forceinline__ void finish_row(float4 y, int64_t r, int sub, const float* __restrict__ addend, float* __restrict__ Y,
                                            float* __restrict__ accum, float accum_scale) {
     if (addend) {
@@ -84,22 +99,27 @@ __device__ __forceinline__ void finish_row(float4 y, int64_t r, int sub, const f
 }
 
 // rows shorter than `long_thr`: one wavefront per row (empty rows included: Y = addend)
+template <bool COLMASK>
 __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, int long_thr, const int64_t* __restrict__ rowptr,
                                                                    const int32_t* __restrict__ col, const float* __restrict__ val,
                                                                    const float* __restrict__ X, const float* __restrict__ addend,
-                                                                   float* __restrict__ Y, float* __restrict__ accum, float accum_scale) {
+                                                                   float* __restrict__ Y, float* __restrict__ accum, float accum_scale,
+                                                                   const uint8_t* __restrict__ row_mask,
+                                                                   const uint8_t* __restrict__ col_mask) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
     const float4* X4 = reinterpret_cast<const float4*>(X);
     for (int64_t r = blockIdx.x * ROW_WAVES + wv; r < n_rows; r += static_cast<int64_t>(gridDim.x) * ROW_WAVES) {
+        if (row_mask && !row_mask[r]) continue;
         const int64_t rb = rowptr[r], re = rowptr[r + 1];
         if (re - rb >= long_thr) continue;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int64_t e = rb; e < re; e += 64) {
-            const int m = static_cast<int>(re - e < 64 ? re - e : 64);
+            int m = static_cast<int>(re - e < 64 ? re - e : 64);
             int cl = 0;
             float vl = 0.0f;
             if (lane < m) { cl = col[e + lane]; vl = val[e + lane]; }
+            if (COLMASK) m = keep_marked(col_mask, lane, m, cl, vl);
             gather_block(X4, cl, vl, m, grp, sub, acc);
         }
         sum_groups(acc);
@@ -108,10 +128,13 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, i
 }
 
 // long rows: the tasks of column block 8 * group + (blockIdx % 8)
+template <bool COLMASK>
 __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_t* __restrict__ first_task, int n_long, int n_blocks, int group,
                                                                     const Task* __restrict__ tasks, const int32_t* __restrict__ col,
                                                                     const float* __restrict__ val, const float* __restrict__ X,
-                                                                    float* __restrict__ part) {
+                                                                    float* __restrict__ part, const int32_t* __restrict__ long_rows,
+                                                                    const uint8_t* __restrict__ row_mask,
+                                                                    const uint8_t* __restrict__ col_mask) {
     const int b = group * 8 + (blockIdx.x & 7);
     if (b >= n_blocks) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -121,12 +144,15 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
     const int64_t t_end = first_task[static_cast<int64_t>(b + 1) * n_long];
     for (int64_t t = first_task[static_cast<int64_t>(b) * n_long] + (blockIdx.x >> 3) * ROW_WAVES + wv; t < t_end; t += n_w) {
         const Task tk = tasks[t];
+        if (row_mask && !row_mask[long_rows[tk.len_slot >> 8]]) continue;
+        const int len = static_cast<int>(tk.len_slot & 255u) + 1;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e0 = 0; e0 < tk.len; e0 += 64) {
-            const int m = tk.len - e0 < 64 ? tk.len - e0 : 64;
+        for (int e0 = 0; e0 < len; e0 += 64) {
+            int m = len - e0 < 64 ? len - e0 : 64;
             int cl = col[tk.beg];          // padding lanes gather the task's first column: an address inside the block
             float vl = 0.0f;
             if (lane < m) { cl = col[tk.beg + e0 + lane]; vl = val[tk.beg + e0 + lane]; }
+            if (COLMASK) m = keep_marked(col_mask, lane, m, cl, vl);
             gather_block(X4, cl, vl, m, grp, sub, acc);
         }
         sum_groups(acc);
@@ -138,9 +164,11 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
 // quarter of the row's slots (8 loads in flight), the four sums are combined in wave order
 __global__ __launch_bounds__(256) void spmm_reduce_kernel(const int32_t* __restrict__ long_rows, const int64_t* __restrict__ part_ptr,
                                                           const float* __restrict__ part, const float* __restrict__ addend,
-                                                          float* __restrict__ Y, float* __restrict__ accum, float accum_scale) {
+                                                          float* __restrict__ Y, float* __restrict__ accum, float accum_scale,
+                                                          const uint8_t* __restrict__ row_mask) {
     __shared__ float s[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (row_mask && !row_mask[long_rows[blockIdx.x]]) return;      // the whole workgroup leaves together
     const int64_t b = part_ptr[blockIdx.x], n = part_ptr[blockIdx.x + 1] - b;
     const int64_t q0 = b + n * wv / 4, q1 = b + n * (wv + 1) / 4;
     float acc = 0.0f;
@@ -244,7 +272,7 @@ __global__ void fill_tasks_kernel(int n_long, int n_blocks, int cblk, const int3
     for (int64_t e = e0; e < e1; e += SPMM_TASK, ++t, ++p) {
         Task tk;
         tk.beg = e;
-        tk.len = static_cast<int32_t>(e1 - e < SPMM_TASK ? e1 - e : SPMM_TASK);
+        tk.len_slot = static_cast<uint32_t>((e1 - e < SPMM_TASK ? e1 - e : SPMM_TASK) - 1) | (static_cast<uint32_t>(s) << 8);
         tk.part = static_cast<int32_t>(p);
         tasks[t] = tk;
     }
@@ -321,6 +349,11 @@ int skr_spmm_plan_create(int n_rows, int n_cols, const int64_t* d_rowptr, const 
     PLAN_HIP(hipMemcpyAsync(&n_long, slot_of + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PLAN_HIP(hipStreamSynchronize(st));
     p->n_long = static_cast<int>(n_long);
+    if (n_long >= (int64_t{1} << 24)) {
+        (void)hipFree(slot_of);
+        free_plan(p); *out = nullptr;
+        return skr::fail(SKR_EINVAL, "skr_spmm_plan_create: %lld long rows (at most 2^24 - 1)", static_cast<long long>(n_long));
+    }
     if (n_long > 0) {
         PLAN_HIP(hipMalloc(&p->long_rows, sizeof(int32_t) * n_long));
         hipLaunchKernelGGL(compact_long_kernel, dim3(static_cast<unsigned>((n_rows + 255) / 256)), dim3(256), 0, st, n_rows, d_rowptr,
@@ -373,8 +406,8 @@ int skr_spmm_plan_info(const skr_spmm_plan* plan, int64_t* h_info4) {
     return SKR_OK;
 }
 
-int skr_spmm_plan_run(const skr_spmm_plan* plan, const float* d_X, int dim, const float* d_addend, float* d_Y, float* d_accum,
-                      float accum_scale, void* stream) {
+int skr_spmm_plan_run_masked(const skr_spmm_plan* plan, const float* d_X, int dim, const float* d_addend, float* d_Y, float* d_accum,
+                             float accum_scale, const uint8_t* d_row_mask, const uint8_t* d_col_mask, void* stream) {
     SKR_REQUIRE(plan && d_X && d_Y, "skr_spmm_plan_run: NULL argument");
     SKR_REQUIRE(dim == D, "skr_spmm_plan_run: dim must be 64 (got %d)", dim);
     SKR_REQUIRE(d_Y != d_X, "skr_spmm_plan_run: in-place propagation is not supported");
@@ -382,21 +415,52 @@ int skr_spmm_plan_run(const skr_spmm_plan* plan, const float* d_X, int dim, cons
     hipStream_t st = skr::as_stream(stream);
     int64_t wgs = (static_cast<int64_t>(plan->n_rows) + ROW_WAVES - 1) / ROW_WAVES;
     if (wgs > 8192) wgs = 8192;
-    hipLaunchKernelGGL(spmm_rows_kernel, dim3(static_cast<unsigned>(wgs)), dim3(ROW_WAVES * 64), 0, st, plan->n_rows, plan->long_thr,
-                       plan->rowptr, plan->col, plan->val, d_X, d_addend, d_Y, d_accum, accum_scale);
+    const dim3 rgrid(static_cast<unsigned>(wgs)), blk(ROW_WAVES * 64), tgrid(8 * BLK_WGS_PER_XCD);
+    if (d_col_mask)
+        hipLaunchKernelGGL(spmm_rows_kernel<true>, rgrid, blk, 0, st, plan->n_rows, plan->long_thr, plan->rowptr, plan->col, plan->val, d_X,
+                           d_addend, d_Y, d_accum, accum_scale, d_row_mask, d_col_mask);
+    else
+        hipLaunchKernelGGL(spmm_rows_kernel<false>, rgrid, blk, 0, st, plan->n_rows, plan->long_thr, plan->rowptr, plan->col, plan->val, d_X,
+                           d_addend, d_Y, d_accum, accum_scale, d_row_mask, d_col_mask);
     SKR_LAUNCH_CHECK();
     if (plan->n_long > 0) {
         if (plan->n_tasks > 0) {
             const int groups = (plan->n_blocks + 7) / 8;
-            for (int g = 0; g < groups; ++g)
-                hipLaunchKernelGGL(spmm_tasks_kernel, dim3(8 * BLK_WGS_PER_XCD), dim3(ROW_WAVES * 64), 0, st, plan->first_task, plan->n_long,
-                                   plan->n_blocks, g, plan->tasks, plan->col, plan->val, d_X, plan->part);
+            for (int g = 0; g < groups; ++g) {
+                if (d_col_mask)
+                    hipLaunchKernelGGL(spmm_tasks_kernel<true>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
+                                       plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask);
+                else
+                    hipLaunchKernelGGL(spmm_tasks_kernel<false>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
+                                       plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask);
+            }
             SKR_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(spmm_reduce_kernel, dim3(plan->n_long), dim3(256), 0, st, plan->long_rows, plan->part_ptr, plan->part, d_addend,
-                           d_Y, d_accum, accum_scale);
+                           d_Y, d_accum, accum_scale, d_row_mask);
         SKR_LAUNCH_CHECK();
     }
+    return SKR_OK;
+}
+
+int skr_spmm_plan_run(const skr_spmm_plan* plan, const float* d_X, int dim, const float* d_addend, float* d_Y, float* d_accum,
+                      float accum_scale, void* stream) {
+    return skr_spmm_plan_run_masked(plan, d_X, dim, d_addend, d_Y, d_accum, accum_scale, nullptr, nullptr, stream);
+}
+
+// d_mask[ids[k]] = 1 for every k (ids < 0 are skipped); the caller clears the mask (hipMemsetAsync) before
+__global__ void mark_ids_kernel(const int32_t* __restrict__ ids, int64_t n, int64_t offset, uint8_t* __restrict__ mask) {
+    const int64_t k = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (k < n && ids[k] >= 0) mask[offset + ids[k]] = 1;
+}
+
+int skr_mark_ids(const int32_t* d_ids, int64_t n, int64_t offset, uint8_t* d_mask, void* stream) {
+    SKR_REQUIRE(n >= 0 && offset >= 0, "skr_mark_ids: negative size");
+    if (n == 0) return SKR_OK;
+    SKR_REQUIRE(d_ids && d_mask, "skr_mark_ids: NULL argument");
+    hipLaunchKernelGGL(mark_ids_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, skr::as_stream(stream), d_ids, n, offset,
+                       d_mask);
+    SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
 

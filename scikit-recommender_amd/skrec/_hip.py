@@ -61,6 +61,8 @@ SIGNATURES = {
     "skr_csr_spmm": (i32, [i32, vp, vp, vp, vp, i32, i64, vp, vp, vp, f32, vp]),
     "skr_spmm_plan_create": (i32, [i32, i32, vp, vp, vp, i64, i32, C.POINTER(vp), vp]),
     "skr_spmm_plan_run": (i32, [vp, vp, i32, vp, vp, vp, f32, vp]),
+    "skr_spmm_plan_run_masked": (i32, [vp, vp, i32, vp, vp, vp, f32, vp, vp, vp]),
+    "skr_mark_ids": (i32, [vp, i64, i64, vp, vp]),
     "skr_spmm_plan_info": (i32, [vp, C.POINTER(i64)]),
     "skr_spmm_plan_destroy": (i32, [vp]),
     "skr_layer_refine_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp]),

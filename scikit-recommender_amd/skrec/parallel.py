@@ -51,6 +51,19 @@ class DistContext(object):
             dist.all_reduce(t)
         return t
 
+    def all_reduce_begin(self, t):
+        """start summing ``t`` over the ranks on the collective's own stream (RCCL: after everything already queued on
+        the current stream); kernels launched on the current stream until ``all_reduce_end`` run beside it"""
+        if not self.active:
+            return None
+        import torch.distributed as dist
+        return dist.all_reduce(t, async_op=True)
+
+    @staticmethod
+    def all_reduce_end(work):
+        if work is not None:
+            work.wait()          # the current stream waits for the collective; the host does not (RCCL)
+
     def all_gather_rows(self, out, inp):
         """out [world, ...] <- every rank's inp (same shape on every rank)"""
         import torch.distributed as dist
@@ -190,8 +203,10 @@ class ShardedLightGCN(object):
         return self.ego[self.n_local:]
 
     # ---- forward ---------------------------------------------------------------------------------
-    def propagate(self):
-        """final = mean(E0, A E0, ..., A^K E0) for the local user rows and the replicated item rows"""
+    def propagate(self, last_rows=None):
+        """final = mean(E0, A E0, ..., A^K E0) for the local user rows and the replicated item rows.
+        ``last_rows`` = (uint8 [n_local], uint8 [I]) during training: the rows of ``final`` that will be read; the last
+        layer's products are computed for those rows only and ``final`` is valid on those rows only."""
         K, nl = self.n_layers, self.n_local
         scale = 1.0 / (K + 1)
         self.final.zero_()
@@ -200,12 +215,30 @@ class ShardedLightGCN(object):
         xu, xi = self.ego[:nl], self.ego[nl:]
         for k in range(K):
             nu, ni = self._xu[k & 1], self._xi[k & 1]
-            self.a_ui.spmm(xi, nu, accum=fu, accum_scale=scale)          # local users <- replicated items
-            self.a_iu.spmm(xu, ni)                                        # partial items <- local users
-            self.ctx.all_reduce(ni)                                       # the exchange step of this layer
+            mu, mi = last_rows if (last_rows is not None and k == K - 1) else (None, None)
+            if mi is not None:
+                ni.zero_()                                                # rows that are skipped must not carry old sums
+            self.a_iu.spmm(xu, ni, row_mask=mi)                                # partial items <- local users
+            work = self.ctx.all_reduce_begin(ni)                               # the exchange step of this layer ...
+            self.a_ui.spmm(xi, nu, accum=fu, accum_scale=scale, row_mask=mu)   # ... beside: local users <- replicated items
+            self.ctx.all_reduce_end(work)
             self._axpy(scale, ni, fi)
             xu, xi = nu, ni
         return self.final
+
+    def _batch_rows(self, ul, il, jl_all):
+        """(uint8 [n_local], uint8 [I]): the rows a global batch touches -- this rank's users, EVERY rank's items (the
+        item rows are replicated and summed over the ranks, so each rank needs the same set)"""
+        if getattr(self, "_mask_u", None) is None:
+            self._mask_u = torch.zeros(self.n_local, dtype=torch.uint8, device=self.device)
+            self._mask_i = torch.zeros(self.num_items, dtype=torch.uint8, device=self.device)
+        L, st = _hip.lib(), _hip.stream()
+        self._mask_u.zero_()
+        self._mask_i.zero_()
+        _hip.check(L.skr_mark_ids(_hip.ptr(ul), ul.numel(), 0, _hip.ptr(self._mask_u), st))
+        for t in (il, jl_all):
+            _hip.check(L.skr_mark_ids(_hip.ptr(t), t.numel(), 0, _hip.ptr(self._mask_i), st))
+        return self._mask_u, self._mask_i
 
     # ---- one training step on a GLOBAL batch -----------------------------------------------------------
     def train_step(self, users, pos, neg):
@@ -220,7 +253,11 @@ class ShardedLightGCN(object):
             il, jl = pos[sel].contiguous(), neg[sel].contiguous()
         else:
             ul, il, jl = users.contiguous(), pos.contiguous(), neg.contiguous()
-        self.propagate()
+        # skipped: rows of the last forward layer that no rank's batch reads, and -- in the first backward hop -- the
+        # entries that would multiply rows of dL/dfinal that are zero (everything outside the batch).  SKR_LIGHTGCN_DENSE=1
+        # computes everything.
+        masks = None if os.environ.get("SKR_LIGHTGCN_DENSE") == "1" else self._batch_rows(ul, pos.contiguous(), neg.contiguous())
+        self.propagate(last_rows=masks)
         gF, gE = self._g_final, self._g_ego
         gF.zero_()
         self.loss.zero_()
@@ -240,11 +277,13 @@ class ShardedLightGCN(object):
         for k in range(K):
             last = (k == K - 1)
             nu, ni = self._gu[k & 1], self._gi[k & 1]
-            self.a_ui.spmm(gi, nu, addend=hu, accum=gEu if last else None, accum_scale=1.0)
-            self.a_iu.spmm(gu, ni)
+            cu, ci = masks if (masks is not None and k == 0) else (None, None)
+            self.a_iu.spmm(gu, ni, col_mask=cu)
             if last:
                 self._axpy(1.0, gEi, ni)           # this rank's regulariser part of the item gradient
-            self.ctx.all_reduce(ni)
+            work = self.ctx.all_reduce_begin(ni)   # summed over the ranks beside the user-side product of the same hop
+            self.a_ui.spmm(gi, nu, addend=hu, accum=gEu if last else None, accum_scale=1.0, col_mask=ci)
+            self.ctx.all_reduce_end(work)
             self._axpy(1.0, hi, ni)
             gu, gi = nu, ni
         gEi.copy_(gi)                              # identical on every rank -> identical Adam update
@@ -455,12 +494,16 @@ class ShardedBPRMF(object):
             opt.touch[self.n_local:] = 0
             opt.grad[self.n_local * 64:].zero_()
             self._dense_marked = False
-        ids = torch.full((1, max(cap, 1)), -1, dtype=torch.int32, device=self.device)
+        if getattr(self, "_xbuf_cap", 0) != cap:     # exchange buffers: allocated once per batch size, not per step
+            self._xbuf_cap = cap
+            self._xbuf_ids = torch.empty((1, max(cap, 1)), dtype=torch.int32, device=self.device)
+            self._xbuf_pack = torch.empty((cap, 66), dtype=torch.float32, device=self.device)
+            self._xbuf_gathered = torch.empty((world, cap, 66), dtype=torch.float32, device=self.device)
+        ids = self._xbuf_ids.fill_(-1)
         n = il.numel()
         ids[0, :n], ids[0, n:2 * n] = il, jl
         ids = unique_padded_rows(ids)
-        pack = torch.empty((cap, 66), dtype=torch.float32, device=self.device)
-        gathered = torch.empty((world, cap, 66), dtype=torch.float32, device=self.device)
+        pack, gathered = self._xbuf_pack, self._xbuf_gathered
         L, st = _hip.lib(), _hip.stream()
         _hip.check(L.skr_pack_grad_rows(_hip.ptr(ids), cap, _hip.ptr(self._gV), _hip.ptr(self._gb), 64, _hip.ptr(pack), st))
         self.ctx.all_gather_rows(gathered, pack)

@@ -119,12 +119,16 @@ class DeviceCSR(object):
                 pass
             self._plan = None
 
-    def spmm(self, X, Y, addend=None, accum=None, accum_scale=1.0):
-        """Y = A @ X (+ addend); accum += accum_scale * Y"""
+    def spmm(self, X, Y, addend=None, accum=None, accum_scale=1.0, row_mask=None, col_mask=None):
+        """Y = A @ X (+ addend); accum += accum_scale * Y.
+        ``row_mask`` (uint8 [n_rows]): only rows with a non-zero byte are needed (the others may be left untouched);
+        ``col_mask`` (uint8 [n_cols]): rows of X with a zero byte ARE zero, their entries may be skipped.  Both are
+        hints: the plan-free kernel computes the whole product."""
         mode = os.environ.get("SKR_SPMM_PLAN", "auto")
         if mode == "1" or (mode != "0" and self.nnz >= self.PLAN_MIN_NNZ):
-            _hip.check(_hip.lib().skr_spmm_plan_run(self._plan_handle(), _hip.ptr(X), 64, _hip.ptr(addend), _hip.ptr(Y),
-                                                    _hip.ptr(accum), float(accum_scale), _hip.stream()))
+            _hip.check(_hip.lib().skr_spmm_plan_run_masked(self._plan_handle(), _hip.ptr(X), 64, _hip.ptr(addend), _hip.ptr(Y),
+                                                           _hip.ptr(accum), float(accum_scale), _hip.ptr(row_mask),
+                                                           _hip.ptr(col_mask), _hip.stream()))
             return Y
         _hip.check(_hip.lib().skr_csr_spmm(self.shape[0], _hip.ptr(self.rowptr), _hip.ptr(self.col), _hip.ptr(self.val),
                                            _hip.ptr(X), 64, self.nnz, _hip.ptr(addend), _hip.ptr(Y), _hip.ptr(accum),
@@ -238,6 +242,7 @@ class LightGCN(AbstractRecommender):
         self._x = [z(), z()]      # propagation ping-pong
         self._g_final = z()       # dL/dE-bar, then H = dL/dE-bar / (K+1)
         self._g = [z(), z()]      # backward ping-pong
+        self._row_mask = None
         self._final_is_current = False
 
     # views -----------------------------------------------------------------------------------------
@@ -273,8 +278,11 @@ class LightGCN(AbstractRecommender):
         return build_adjacency(pairs[:, 0], pairs[:, 1], self.num_users, self.num_items, adj_type)
 
     # propagation -----------------------------------------------------------------------------------
-    def propagate(self):
-        """E-bar = mean(E0, A E0, ..., A^K E0)  (_forward_gcn, LightGCN.py:89-100)"""
+    def propagate(self, last_rows=None):
+        """E-bar = mean(E0, A E0, ..., A^K E0)  (_forward_gcn, LightGCN.py:89-100).
+        ``last_rows`` (uint8 [N], training only): the rows of E-bar that will be read.  The LAST layer's product is then
+        computed for those rows only -- every earlier layer feeds the next one and stays whole -- and E-bar is valid on
+        those rows only."""
         K = self.config.n_layers
         scale = 1.0 / (K + 1)
         self.final.zero_()
@@ -282,15 +290,31 @@ class LightGCN(AbstractRecommender):
         x = self.ego
         for k in range(K):
             y = self._x[k & 1]
-            self.adj.spmm(x, y, accum=self.final, accum_scale=scale)
+            self.adj.spmm(x, y, accum=self.final, accum_scale=scale, row_mask=last_rows if k == K - 1 else None)
             x = y
         return self.final
+
+    def _batch_rows(self, users, pos, neg):
+        """uint8 [N]: 1 on the rows of [U; V] a batch touches -- the only rows of E-bar its loss reads, and the only
+        non-zero rows of dL/dE-bar (reference: the gathers of _LightGCN.forward, LightGCN.py:82-87)"""
+        if self._row_mask is None:
+            self._row_mask = torch.zeros(self.num_users + self.num_items, dtype=torch.uint8, device=self.device)
+        m, L, st, nu = self._row_mask, _hip.lib(), _hip.stream(), self.num_users
+        m.zero_()
+        _hip.check(L.skr_mark_ids(_hip.ptr(users), users.numel(), 0, _hip.ptr(m), st))
+        _hip.check(L.skr_mark_ids(_hip.ptr(pos), pos.numel(), nu, _hip.ptr(m), st))
+        _hip.check(L.skr_mark_ids(_hip.ptr(neg), neg.numel(), nu, _hip.ptr(m), st))
+        return m
 
     def train_step(self, users, pos, neg, loss_slot):
         cfg, nu = self.config, self.num_users
         K = cfg.n_layers
         n = users.numel()
-        self.propagate()
+        # the product A x dense is the reference's; what is skipped is arithmetic whose result is never read (rows of the
+        # last forward layer outside the batch) or is a sum of zeros (the first backward hop reads dL/dE-bar, which is zero
+        # outside the batch's rows).  SKR_LIGHTGCN_DENSE=1 computes everything.
+        rows = None if os.environ.get("SKR_LIGHTGCN_DENSE") == "1" else self._batch_rows(users, pos, neg)
+        self.propagate(last_rows=rows)
         self._final_is_current = False
         gF, gE = self._g_final, self._g_ego
         gF.zero_()
@@ -305,7 +329,7 @@ class LightGCN(AbstractRecommender):
         for k in range(K):
             y = self._g[k & 1]
             last = (k == K - 1)
-            self.adj_t.spmm(x, y, addend=gF, accum=gE if last else None, accum_scale=1.0)
+            self.adj_t.spmm(x, y, addend=gF, accum=gE if last else None, accum_scale=1.0, col_mask=rows if k == 0 else None)
             x = y
         self.optimizer.step()
 

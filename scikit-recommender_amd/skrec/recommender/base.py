@@ -110,9 +110,16 @@ class DenseAdam(object):
         # k small bpr / hot-step launches
         self._ev_marked.record(cur)
         self._side.wait_event(self._ev_marked)
+        timing = getattr(self, "cold_timing", None)     # measurement hook (bench.py): a list that receives (start, end, k)
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self._side)
         _hip.check(L.skr_adam_block_cold(_hip.ptr(self.flat), _hip.ptr(self.m), _hip.ptr(self.v), self.flat.numel(), self.lr,
                                          self.betas[0], self.betas[1], self.eps, self.t, int(k), _hip.ptr(self._blk_tag),
                                          self._blk_serial, self._side.cuda_stream))
+        if timing is not None:
+            e1.record(self._side)
+            timing.append((e0, e1, int(k)))
         self._ev_cold.record(self._side)
         self._hot = (L.skr_adam_block_hot, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                      self.flat.numel(), block_ids.data_ptr(), block_ids.numel(), self._blk_claim.data_ptr(), st,

@@ -270,3 +270,17 @@ def test_lightgcn_full_size_propagation_and_step(big):
     gg = eng._g_ego[torch.from_numpy(probe).to(dev)].cpu().numpy()
     scale = np.abs(G).max()
     np.testing.assert_allclose(gg, G[probe], rtol=2e-5, atol=2e-6 * scale)
+    # the step above skipped what is never read / sums of zeros (row and column masks); the fully dense step agrees
+    import os
+    g_masked = eng._g_ego.clone()
+    eng._g_ego.zero_()
+    os.environ["SKR_LIGHTGCN_DENSE"] = "1"
+    eng.optimizer.step = lambda: None
+    try:
+        eng.train_step(bu, bi, bj)
+    finally:
+        eng.optimizer.step = step
+        os.environ.pop("SKR_LIGHTGCN_DENSE")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(eng.loss.cpu().numpy(), got, rtol=1e-6)
+    assert float((eng._g_ego - g_masked).abs().max()) <= 2e-6 * scale

@@ -78,10 +78,14 @@ def test_bprmf_replays_reference(golden, tiny_dir, monkeypatch, tmp_path, adam_b
     np.testing.assert_allclose(m.predict(list(g["pred_users"])), g["pred"], rtol=1e-4, atol=1e-6)
 
 
-def test_lightgcn_replays_reference(golden, tiny_dir, monkeypatch, tmp_path):
+@pytest.mark.parametrize("spmm_plan", ["auto", "1"])
+def test_lightgcn_replays_reference(golden, tiny_dir, monkeypatch, tmp_path, spmm_plan):
+    """spmm_plan = "1": the propagation goes through skr_spmm_plan_* even on this small graph, so the training step's
+    row / column masks (last forward layer on the batch's rows, first backward hop on the batch's columns) are live"""
     from skrec.recommender.LightGCN import LightGCN
     from skrec.utils.py.random import reset_global_sampler
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SKR_SPMM_PLAN", spmm_plan)
     g = golden("golden_lightgcn")
     reset_global_sampler(2020)
     _seed()

@@ -208,6 +208,29 @@ def test_spmm_plan_rectangular_blocks_and_determinism(n_rows, n_cols, long_from)
     mass = abs(A).astype(np.float64) @ np.abs(X).astype(np.float64) + np.abs(add)
     assert np.all(np.abs(outs[0][0] - want) <= 2e-6 * mass + 1e-6)
     assert np.all(np.abs(outs[0][1] - (acc0 + 0.5 * want)) <= 2e-6 * (mass + np.abs(acc0)) + 1e-6)
+    # masks: entries of columns whose X rows are zero may be skipped; rows that are not needed may be left untouched
+    cmask = (rng.random(n_cols) < 0.3).astype(np.uint8)
+    rmask = (rng.random(n_rows) < 0.4).astype(np.uint8)
+    X2 = X * cmask[:, None]
+    dX2, d_cm, d_rm = to_dev(X2), to_dev(cmask), to_dev(rmask)
+    Yfull = torch.empty((n_rows, 64), device=dev())
+    _hip.check(L.skr_spmm_plan_run(h, _hip.ptr(dX2), 64, _hip.ptr(dadd), _hip.ptr(Yfull), None, 1.0, _hip.stream()))
+    for use_r, use_c in ((False, True), (True, False), (True, True)):
+        Y = torch.full((n_rows, 64), 7.0, device=dev())
+        acc = to_dev(acc0.copy())
+        _hip.check(L.skr_spmm_plan_run_masked(h, _hip.ptr(dX2), 64, _hip.ptr(dadd), _hip.ptr(Y), _hip.ptr(acc), 0.5,
+                                              _hip.ptr(d_rm) if use_r else None, _hip.ptr(d_cm) if use_c else None, _hip.stream()))
+        torch.cuda.synchronize()
+        y, f, a = Y.cpu().numpy(), Yfull.cpu().numpy(), acc.cpu().numpy()
+        need = rmask.astype(bool) if use_r else np.ones(n_rows, bool)
+        mass2 = abs(A).astype(np.float64) @ np.abs(X2).astype(np.float64) + np.abs(add)
+        assert np.all(np.abs(y[need] - f[need]) <= 1e-6 * mass2[need] + 1e-7)        # same sums, possibly another order
+        assert np.all(y[~need] == 7.0) and np.array_equal(a[~need], acc0[~need])     # skipped rows are untouched
+        assert np.all(np.abs(a[need] - (acc0[need] + 0.5 * f[need])) <= 1e-6 * (mass2[need] + np.abs(acc0[need])) + 1e-7)
+    mk = torch.zeros(n_cols + 3, dtype=torch.uint8, device=dev())
+    ids = to_dev(np.array([0, -1, n_cols - 1, 0], np.int32))
+    _hip.check(L.skr_mark_ids(_hip.ptr(ids), 4, 3, _hip.ptr(mk), _hip.stream()))
+    assert mk.nonzero().flatten().tolist() == sorted({3, n_cols + 2})
     Y = torch.empty((n_rows, 64), device=dev())
     assert L.skr_spmm_plan_run(h, _hip.ptr(dX), 32, None, _hip.ptr(Y), None, 1.0, _hip.stream()) == -1
     assert L.skr_spmm_plan_run(h, _hip.ptr(dX), 64, None, _hip.ptr(dX), None, 1.0, _hip.stream()) == -1
