@@ -6,7 +6,8 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+COMMAND = "python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-epoch"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
@@ -19,9 +20,9 @@ def short(n):
 # 1. --kernel-trace --stats summary (top kernels)
 rows = list(csv.DictReader(open(f"{src}/stats_kernel_stats.csv")))
 with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 192 --warmup 32 --no-cpu-baseline --no-epoch (MI355X)\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- {COMMAND} (MI355X)\n")
     f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
-    for r in rows[:25]:
+    for r in rows[:40]:
         f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
 stats = {short(r["Name"]): r for r in rows}
 
@@ -33,10 +34,18 @@ for name in ("fetch", "write"):
     for r in csv.DictReader(open(f"{src}/{name}_counter_collection.csv")):
         agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     pmc[name] = agg
-summary = {"tag": tag, "command": "python3 bench.py --steps 192 --warmup 32 --no-cpu-baseline --no-epoch", "kernels": {}}
+summary = {"tag": tag, "command": COMMAND, "kernels": {}}
+# L2 hit rate and vector-cache -> L2 read requests of the propagation kernels (own --pmc passes)
+extra = {}
+for fname, counters in (("l2", ("TCC_HIT_sum", "TCC_MISS_sum")), ("tcp", ("TCP_TCC_READ_REQ_sum",))):
+    pth = f"{src}/{fname}_counter_collection.csv"
+    if not os.path.exists(pth):
+        continue
+    for r in csv.DictReader(open(pth)):
+        extra.setdefault(short(r["Kernel_Name"]), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in ("adam_cold_rows_kernel<4>", "adam_cold_kernel<2>", "adam_hot_kernel", "adam_kernel<true, 4, true>", "fused_topk_kernel_v4<true>", "fused_topk_kernel_v3<true>", "split_items_kernel",
-          "bpr_step_kernel", "exact_assign_kernel<false>",
-          "mt_generate_kernel"):
+          "bpr_step_kernel", "exact_assign_kernel<false>", "mt_generate_kernel", "shuffle_gather_kernel<false>",
+          "spmm_rows_kernel<false>", "spmm_rows_kernel<true>", "spmm_tasks_kernel<false>", "spmm_tasks_kernel<true>", "spmm_reduce_kernel"):
     if k not in stats:
         continue
     fe, wr = pmc["fetch"].get(k, []), pmc["write"].get(k, [])
@@ -47,6 +56,11 @@ for k in ("adam_cold_rows_kernel<4>", "adam_cold_kernel<2>", "adam_hot_kernel", 
         ent.update(FETCH_SIZE_KB=fkb, WRITE_SIZE_KB=wkb, hbm_read_bytes=fkb * 1024 * 2, hbm_write_bytes=wkb * 1024,
                    hbm_bytes_per_launch=fkb * 1024 * 2 + wkb * 1024,
                    note="FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read stream)")
+    for cname, vals in extra.get(k, {}).items():
+        ent[cname + "_per_launch"] = sum(vals) / len(vals)
+    if "TCC_HIT_sum_per_launch" in ent:
+        h, m_ = ent["TCC_HIT_sum_per_launch"], ent["TCC_MISS_sum_per_launch"]
+        ent["l2_hit_rate"] = h / max(h + m_, 1.0)
     summary["kernels"][k] = ent
 
 # 3. eval kernel PMC (MFMA utilisation, clock): the largest launch of each fused kernel (v4 = bf16x3, the default;
