@@ -154,6 +154,7 @@ class _EpochAhead(object):
             if self._err is not None:
                 raise self._err
             neg, perm = self._out
+            torch.cuda.current_stream().wait_stream(self._side)   # the fast sampler only ENQUEUES on the side stream
             neg.record_stream(torch.cuda.current_stream())     # allocated under the side stream, consumed here
         else:
             neg, perm = self._produce()

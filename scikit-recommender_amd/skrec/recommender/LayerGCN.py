@@ -208,14 +208,17 @@ class LayerGCN(AbstractRecommender):
         cols = torch.cat([i + self.num_users, u])
         self.train_adj = DeviceCSR.from_device_coo(rows, cols, torch.cat([vals, vals]), n)
 
-    def forward(self, adj=None):
+    def forward(self, adj=None, last_rows=None):
+        """``last_rows`` (uint8 [N], training only): the rows of ``out`` that will be read -- the LAST layer's product is
+        computed for those rows only (every earlier layer feeds the next one and stays whole)"""
         L, st = _hip.lib(), _hip.stream()
         N = self.ego.shape[0]
         adj = adj if adj is not None else self.adj
         self.out.zero_()
         x = self.ego
-        for k in range(self.config.n_layers):
-            adj.spmm(x, self._y[k])
+        K = self.config.n_layers
+        for k in range(K):
+            adj.spmm(x, self._y[k], row_mask=last_rows if k == K - 1 else None)
             zk = self._z[k & 1]
             _hip.check(L.skr_layer_refine_fwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), N, 64, _hip.ptr(zk),
                                               _hip.ptr(self._w[k]), _hip.ptr(self.out), st))
@@ -227,7 +230,11 @@ class LayerGCN(AbstractRecommender):
         L, st = _hip.lib(), _hip.stream()
         N = self.ego.shape[0]
         adj = self.train_adj
-        self.forward(adj)
+        # not computed: rows of the last layer's product that the batch does not read, and -- in the first backward hop --
+        # the products with rows of dY_K that are zero (dL/d out is zero outside the batch's rows, and the refinement's
+        # backward is row-local).  SKR_LIGHTGCN_DENSE=1 computes everything.
+        rows = None if os.environ.get("SKR_LIGHTGCN_DENSE") == "1" else self._batch_rows(users, pos, neg)
+        self.forward(adj, last_rows=rows)
         gO, gE = self._g_out, self._g_ego
         gO.zero_()
         _hip.check(L.skr_bpr_step(
@@ -241,12 +248,24 @@ class LayerGCN(AbstractRecommender):
         for k in range(cfg.n_layers - 1, -1, -1):
             _hip.check(L.skr_layer_refine_bwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), _hip.ptr(self._w[k]),
                                               _hip.ptr(dz), N, 64, _hip.ptr(dy), _hip.ptr(gE), st))
+            cm = rows if k == cfg.n_layers - 1 else None
             if k > 0:
-                adj.spmm(dy, tmp, addend=gO)
+                adj.spmm(dy, tmp, addend=gO, col_mask=cm)
                 dz = tmp
             else:
-                adj.spmm(dy, tmp, accum=gE, accum_scale=1.0)
+                adj.spmm(dy, tmp, accum=gE, accum_scale=1.0, col_mask=cm)
         self.optimizer.step()
+
+    def _batch_rows(self, users, pos, neg):
+        """uint8 [N]: 1 on the rows of [U; V] a batch touches (the gathers of calculate_loss, LayerGCN.py:245-253)"""
+        if getattr(self, "_row_mask", None) is None:
+            self._row_mask = torch.zeros(self.num_users + self.num_items, dtype=torch.uint8, device=self.device)
+        m, L, st, nu = self._row_mask, _hip.lib(), _hip.stream(), self.num_users
+        m.zero_()
+        _hip.check(L.skr_mark_ids(_hip.ptr(users), users.numel(), 0, _hip.ptr(m), st))
+        _hip.check(L.skr_mark_ids(_hip.ptr(pos), pos.numel(), nu, _hip.ptr(m), st))
+        _hip.check(L.skr_mark_ids(_hip.ptr(neg), neg.numel(), nu, _hip.ptr(m), st))
+        return m
 
     def train_epoch(self, data_iter):
         self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)

@@ -221,21 +221,25 @@ class RankingEvaluator(object):
             n_items = int(it.shape[0])
             fused_ok = (it.shape[1] == 64 and ut.shape[1] == 64 and n_items - st["max_train"] >= K)
         if factors is not None and fused_ok:
-            # pass 1: top-K lists of every user, chunk after chunk without touching the host
+            # pass 1: top-K lists of every user, chunk after chunk without touching the host.  One more entry than needed
+            # is asked for where possible (Kq = K + 1): with the (K+1)-th score in hand, a tie that exists ONLY between the
+            # last kept and the first dropped item is seen too, and such a user is re-ranked like any other tied one
             d_users = torch.from_numpy(users).to(dev)
-            work = torch.empty(int(_hip.lib().skr_eval_fused_workspace(min(n, _FUSED_CHUNK), K)), dtype=torch.uint8,
+            Kq = K + 1 if (K + 1 <= _hip.SKR_MAX_TOPK and n_items - st["max_train"] >= K + 1) else K
+            work = torch.empty(int(_hip.lib().skr_eval_fused_workspace(min(n, _FUSED_CHUNK), Kq)), dtype=torch.uint8,
                                device=dev)
-            ids = torch.empty((n, K), dtype=torch.int32, device=dev)
-            top_sc = torch.empty((n, K), dtype=torch.float32, device=dev)
+            ids_q = torch.empty((n, Kq), dtype=torch.int32, device=dev)
+            top_sc = torch.empty((n, Kq), dtype=torch.float32, device=dev)
             for s in range(0, n, _FUSED_CHUNK):
                 b = min(_FUSED_CHUNK, n - s)
                 _hip.check(_hip.lib().skr_eval_fused_topk(
                     _hip.ptr(ut), _hip.ptr(d_users[s:s + b]), b, _hip.ptr(it), _hip.ptr(bias), n_items, 64,
-                    _hip.ptr(st["tr_ptr"]), _hip.ptr(st["tr_items"]), K, _hip.ptr(ids[s:s + b]), _hip.ptr(top_sc[s:s + b]),
+                    _hip.ptr(st["tr_ptr"]), _hip.ptr(st["tr_items"]), Kq, _hip.ptr(ids_q[s:s + b]), _hip.ptr(top_sc[s:s + b]),
                     _hip.ptr(work), work.numel(), _hip.stream()))
+            ids = ids_q if Kq == K else ids_q[:, :K].contiguous()
             # one look at the scores (the only host synchronisation): users with equal scores are re-ranked
             self._rerank_tied_rows(st, ut, it, bias, d_users, ids, top_sc)
-            del top_sc, work
+            del top_sc, work, ids_q
             # pass 2: the metrics
             rows = None
             for s in range(0, n, _FUSED_CHUNK):

@@ -140,10 +140,11 @@ def test_lightgcn_fit_under_torchrun_contract(tiny_dir, tmp_path):
     assert np.array_equal(res[0]["reports"], res[1]["reports"])
 
 
-def _bprmf_worker(rank, world, port, data_dir, workdir, exchange, ret):
+def _bprmf_worker(rank, world, port, data_dir, workdir, exchange, ret, backend="gloo"):
     exchange, _, adam_block = exchange.partition("/")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
-                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo", SKR_EXCHANGE=exchange, SKR_ADAM_BLOCK=adam_block or "8")
+                      WORLD_SIZE=str(world), SKR_DIST_BACKEND=backend, SKR_EXCHANGE=exchange, SKR_ADAM_BLOCK=adam_block or "8",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     os.chdir(workdir)
     import random
     from skrec import RunConfig
@@ -195,6 +196,23 @@ def test_bprmf_fit_under_torchrun_contract(world, exchange, tiny_dir, tmp_path):
         np.testing.assert_allclose(r["b1"], g["b1"].reshape(-1), rtol=0, atol=2e-6)
         np.testing.assert_allclose(r["pred"], g["pred"], rtol=1e-4, atol=1e-6)
     assert np.array_equal(res[0]["V1"], res[1]["V1"]) and np.array_equal(res[0]["reports"], res[world - 1]["reports"])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL branch needs two GPUs (one process per GPU); the test boxes of this "
+                    "environment have one -- it runs as soon as a multi-GPU box executes the suite")
+@pytest.mark.parametrize("exchange", ["sparse/32", "dense/1"])
+def test_bprmf_fit_on_rccl(exchange, tiny_dir, tmp_path):
+    """the same two-rank fit() with backend "nccl" (= RCCL): init_process_group(device_id=...), all_gather_into_tensor,
+    the collectives beside the side-stream cold pass"""
+    g = np.load(os.path.join(GOLDEN, "golden_bprmf.npz"))
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_bprmf_worker, args=(2, _free_port(), tiny_dir, str(tmp_path), exchange, ret, "nccl"), nprocs=2, join=True)
+        res = {k: ret[k] for k in range(2)}
+    for r in res.values():
+        np.testing.assert_allclose(r["losses"][:, 0], g["bpr_sum"], rtol=1e-5)
+        np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=2e-6)
+    assert np.array_equal(res[0]["V1"], res[1]["V1"])
 
 
 def _layergcn_worker(rank, world, port, data_dir, workdir, dropout, ret):

@@ -231,6 +231,42 @@ def test_fused_evaluator_reranks_structural_ties_in_reference_order(fused_mode):
     np.testing.assert_allclose(np.array(list(got.values()), np.float32), want, rtol=1e-6, atol=0)   # fp32 mean order
 
 
+def test_fused_evaluator_sees_a_tie_at_the_k_boundary(fused_mode):
+    """a tie that exists ONLY between the K-th and the (K+1)-th score (evaluate.h:39-45 keeps the one the heap order
+    prefers, not the lower id): the fused path asks for K + 1 entries, sees the tie and re-ranks the user from the dense
+    row -- per-user metric rows equal the oracle's for every user, bit for bit"""
+    import torch
+    from skrec.utils.py import RankingEvaluator
+    rng = np.random.default_rng(12)
+    nU, nI, K = 96, 300, 10
+    # scores are exact integers on every path: one-hot user rows select a column of small-integer item factors
+    It = np.zeros((nI, 64), np.float32)
+    Ut = np.zeros((nU, 64), np.float32)
+    for u in range(nU):
+        Ut[u, u % 64] = 1.0
+    for d in range(64):
+        col = rng.permutation(nI).astype(np.float32)             # all distinct: no tie anywhere ...
+        srt = np.argsort(-col)
+        if d % 2 == 0:
+            col[srt[K]] = col[srt[K - 1]]                         # ... except exactly at the K / K+1 boundary
+        It[:, d] = col
+    train = {u: np.sort(rng.choice(nI, 3, replace=False)) for u in range(nU)}
+    test = {u: rng.choice(nI, 4, replace=False) for u in range(nU)}
+    dU, dI = torch.from_numpy(Ut).cuda(), torch.from_numpy(It).cuda()
+
+    class M(object):
+        def predict_factors(self):
+            return dU, dI, None
+
+        def predict(self, users):
+            return Ut[np.asarray(users)] @ It.T
+    ev = RankingEvaluator(train, test, metric=["Precision", "Recall", "MAP", "NDCG", "MRR"], top_k=K, batch_size=32)
+    rows, _, _ = ev.per_user_rows(M(), list(test.keys()))
+    _, _, want_rows = O.ranking_evaluate(M().predict, train, test, metric=["Precision", "Recall", "MAP", "NDCG", "MRR"], top_k=K,
+                                         batch_size=32)
+    assert np.array_equal(rows.view(np.uint32), want_rows.view(np.uint32))
+
+
 def test_eval_scores_is_deterministic_on_long_rows():
     """Regression: the decision to compact the LDS candidate buffer used to be taken from a counter that other
     threads were already incrementing, so threads could disagree and a candidate was lost in about one of 1e5

@@ -114,10 +114,13 @@ def test_lightgcn_replays_reference(golden, tiny_dir, monkeypatch, tmp_path, spm
     np.testing.assert_allclose(m.predict(list(g["pred_users"])), g["pred"], rtol=1e-4, atol=2e-6)
 
 
-def test_layergcn_replays_reference(golden, tiny_dir, monkeypatch, tmp_path):
+@pytest.mark.parametrize("spmm_plan", ["auto", "1"])
+def test_layergcn_replays_reference(golden, tiny_dir, monkeypatch, tmp_path, spmm_plan):
+    """spmm_plan = "1": products through skr_spmm_plan_*, so the step's row / column masks are live on this small graph"""
     from skrec.recommender.LayerGCN import LayerGCN
     from skrec.utils.py.random import reset_global_sampler
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SKR_SPMM_PLAN", spmm_plan)
     g = golden("golden_layergcn")
     reset_global_sampler(2020)
     _seed()
