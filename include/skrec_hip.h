@@ -64,6 +64,12 @@ int skr_sampler_get_state(skr_sampler* s, uint32_t* words624, int* pos);
 int skr_sampler_set_state(skr_sampler* s, const uint32_t* words624, int pos);
 /* Total raw 32-bit words consumed since creation / set_state (synchronises). */
 int skr_sampler_draws(skr_sampler* s, uint64_t* n);
+/* How the last exact epoch ran (test / measurement hook; synchronises the device): h_info4 = {status, handed_over,
+ * slots filled, words consumed}.  status 0 = the one-workgroup path (dense data, small calls, SKR_EXACT_PATH=serial),
+ * 1 = the slab path (sampler.hip 2d) and every slot was filled, 2 = slab path, the generated words ran out (the next
+ * exact-epoch call reports it as an error).  handed_over 1 = the slab path met a case it leaves to the serial kernel and
+ * that kernel finished the stream. */
+int skr_sampler_last_epoch(skr_sampler* s, int64_t* h_info4);
 
 /* One call of c_randint_choice (randint.h:75): `size` draws from [0, high), written to d_result.
  *   replace      as the reference's bool;

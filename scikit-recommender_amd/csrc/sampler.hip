@@ -16,6 +16,7 @@
 //                              LDS-staged CSR positives; HBM-bound (8 B per sampled negative).
 #include "skr_common.h"
 
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -133,14 +134,37 @@ __global__ void randint_serial_kernel(uint32_t* state, int* pos, unsigned long l
 // ------------------------------------------------------------------------------------------------
 constexpr int GEN_T = 256;
 
+// n >= 0: generate exactly n words.  n < 0: generate at least -n words and stop on a block boundary of the generator
+// (the host does not know the stream position without a read-back); the count goes to *n_out.
+// `piece` / `piece_words`: the stretch may be produced in pieces (piece p = words [p * piece_words, (p + 1) * piece_words) of
+// it, on a stream of their own beside the kernels that consume them): piece 0 starts from the sampler's state and fixes
+// the stretch's length, every piece leaves the generator's state in `carry` (624 words + position) for the next one.
 __global__ __launch_bounds__(GEN_T) void mt_generate_kernel(const uint32_t* __restrict__ state,
                                                             const int* __restrict__ pos_p,
-                                                            uint32_t* __restrict__ raw, int64_t n) {
+                                                            uint32_t* __restrict__ raw, int64_t n, int64_t* __restrict__ n_out,
+                                                            uint32_t* __restrict__ carry = nullptr, int piece = 0,
+                                                            int64_t piece_words = 0) {
     __shared__ uint32_t mt[MT_N];
     const int tid = threadIdx.x;
-    for (int i = tid; i < MT_N; i += GEN_T) mt[i] = state[i];
+    const bool resume = carry && piece > 0;
+    for (int i = tid; i < MT_N; i += GEN_T) mt[i] = resume ? carry[i] : state[i];
     __syncthreads();
-    int p = *pos_p;
+    int p = resume ? static_cast<int>(carry[MT_N]) : *pos_p;
+    if (n < 0) {
+        if (resume) {
+            n = *n_out;                    // fixed by piece 0
+        } else {
+            const int64_t want = -n, r0 = MT_N - p;
+            n = want <= r0 ? r0 : r0 + ((want - r0 + MT_N - 1) / MT_N) * MT_N;
+            if (tid == 0 && n_out) *n_out = n;
+        }
+    }
+    if (carry) {                           // this piece's share of the stretch
+        const int64_t beg = static_cast<int64_t>(piece) * piece_words;
+        raw += beg;
+        n = n - beg < piece_words ? n - beg : piece_words;
+        if (n < 0) n = 0;
+    }
     int64_t k = 0;
     while (k < n) {
         if (p >= MT_N) {
@@ -172,12 +196,18 @@ __global__ __launch_bounds__(GEN_T) void mt_generate_kernel(const uint32_t* __re
         p += m;
         __syncthreads();
     }
+    if (carry) {
+        for (int i = tid; i < MT_N; i += GEN_T) carry[i] = mt[i];
+        if (tid == 0) carry[MT_N] = static_cast<uint32_t>(p);
+    }
 }
 
 // 2c. advance the stored state by `consumed` words of the buffer generated above.
 // The tempered words of a whole block ARE that block's state (tempering is a bijection).
 __global__ void mt_commit_kernel(uint32_t* state, int* pos_p, unsigned long long* draws,
-                                 const uint32_t* __restrict__ raw, int64_t n_raw, const int64_t* ctl) {
+                                 const uint32_t* __restrict__ raw, int64_t n_raw, const int64_t* ctl,
+                                 const int64_t* __restrict__ n_raw_dev) {
+    if (n_raw_dev) n_raw = *n_raw_dev;
     const int64_t consumed = ctl[1];
     const int p0 = *pos_p;
     const int64_t r0 = MT_N - p0;  // words of the current block that were still unread
@@ -212,6 +242,17 @@ __global__ void mt_commit_kernel(uint32_t* state, int* pos_p, unsigned long long
 // ------------------------------------------------------------------------------------------------
 // 2b. exact assignment: which draw fills which slot
 // ------------------------------------------------------------------------------------------------
+// words of the control block d_ctl (int64 each)
+constexpr int SL_S = 0;         // slots filled so far
+constexpr int SL_D = 1;         // words of the generated stretch consumed so far
+constexpr int SL_SCRATCH = 2;   // max_row_len scratch (two ints)
+constexpr int SL_SUMSQ = 3;     // sum of squared row lengths (dataset statistic)
+constexpr int SL_FALLBACK = 4;  // the slab path met a case it leaves to the serial kernel
+constexpr int SL_NRAW = 5;      // words generated
+constexpr int SL_SLAB_S = 6;    // S at the start of the slab being scattered
+constexpr int SL_SLAB_N = 7;    // draws of that slab that were consumed (0: nothing to scatter)
+constexpr int SL_STATUS = 8;    // 1 = the last exact epoch ended with every slot filled
+
 constexpr int AS_T = 1024;
 constexpr int AS_PER = 16;
 constexpr int AS_C = AS_T * AS_PER;
@@ -266,6 +307,15 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
     const int lane = tid & 63, wv = tid >> 6;
     const uint32_t lemire_thr = (0u - high) % high;
 
+    int64_t draw_origin = 0;
+    if (slot_start < 0) {
+        // FALLBACK of the slab path (run_exact_epoch_slabs): continue from the point it gave up at, if it did
+        if (ctl[SL_FALLBACK] == 0 || ctl[SL_S] >= n_slots) return;
+        slot_start = ctl[SL_S];
+        draw_origin = ctl[SL_D];
+        n_raw = ctl[SL_NRAW] - draw_origin;
+        raw += draw_origin;
+    }
     int64_t slot_base = slot_start;
     int64_t draw_base = 0;
     int w0 = 0;  // first user of the staged window; the owner of slot_base never moves backwards
@@ -486,13 +536,290 @@ __global__ __launch_bounds__(AS_T) void exact_assign_kernel(
     }
     if (tid == 0) {
         ctl[0] = slot_base;
-        ctl[1] = draw_base;
+        ctl[1] = draw_origin + draw_base;
 #ifdef SKR_SAMPLER_STAMPS
         for (int k = 0; k < 6; ++k) ctl[4 + k] = tph[k];
 #endif
     }
 #undef STAMP
 }
+
+// ------------------------------------------------------------------------------------------------
+// 2d. the same assignment on the whole chip, for sparse data: SLABS of draws, three parallel-friendly kernels per slab
+// ------------------------------------------------------------------------------------------------
+// Which slot a draw fills depends on every rejection before it, so the stream is a serial chain -- but rejections are
+// RARE on recommendation data (a draw is rejected when it hits one of its user's positives: ~0.05 % at 48 positives
+// per user and 100 k items).  Per slab of SLAB_B draws, with the exact number S of slots filled before the slab known:
+//   detect   (every CU)  draw j can only land in slots S + j - W(j) .. S + j, where W(j) bounds the rejections inside the
+//            slab before it.  Those slots belong to a handful of users; the draw's value is searched in the positives of
+//            each of them.  A hit anywhere, or a Lemire rejection, makes the draw an EVENT (one bit per draw + a mask of
+//            the users it would be rejected for).  Everything here is independent of the rejections inside the slab.
+//   resolve  (one workgroup) walks the slab's few hundred events in order with the running rejection count r: the
+//            event's slot S + j - r names its owner among the candidate users, the mask says whether the draw is
+//            rejected there.  This is the serial chain, shrunk from every draw to the events.
+//   scatter  (every CU)  out[S + j - (rejections before j)] = value for the accepted draws.
+// Anything outside the assumptions -- more rejections than W(j), more events or candidate users than the tables hold, a
+// window of row offsets that does not fit -- raises SL_FALLBACK: the remaining stream is then assigned by
+// exact_assign_kernel (the serial kernel above) from the point the slabs stopped at.  Same stream, same slots, bit for bit.
+constexpr int SLAB_B = 1 << 17;        // draws per slab at most (sparse data); denser data gets shorter slabs, see run_exact_epoch_slabs
+constexpr int SLAB_T = 256;            // threads per workgroup (detect / scatter)
+constexpr int SLAB_ROWS = 1024;        // row offsets staged per detect workgroup
+constexpr int SLAB_EV = 1024;          // events per slab the resolver holds
+constexpr int SLAB_BND = 8;            // candidate owners per event the resolver looks at
+constexpr int32_t EV_LEMIRE = -2, EV_UNKNOWN = -1;
+
+struct SlabArgs {
+    const uint32_t* raw;
+    uint32_t high;
+    const int64_t* rowptr;       // membership rows (CSR of the exclusion sets)
+    const int64_t* optr;         // ownership: cumulative q-units per user (rowptr itself, or drawptr)
+    int n_users;
+    const int32_t* pos_sorted;
+    int num_neg;
+    int64_t n_slots;
+    int64_t* ctl;
+    int64_t slab_off;            // first draw of this slab in raw
+    int slab_b;                  // draws per slab in this call (a multiple of 256, <= SLAB_B)
+    int win0;                    // W(j) = win0 + (j * win_rate) >> 16
+    uint32_t win_rate;
+    unsigned long long* ev_bits; // [SLAB_B / 64]
+    uint32_t* ev_mask;           // [SLAB_B]
+    int32_t* ev_uhi;             // [SLAB_B]
+    unsigned long long* rej_bits;// [SLAB_B / 64]
+    int32_t* out;
+};
+
+__device__ __forceinline__ int slab_window(const SlabArgs& a, int j) {
+    const int w = a.win0 + static_cast<int>((static_cast<uint64_t>(j) * a.win_rate) >> 16);
+    return w < j ? w : j;    // there cannot be more rejections before draw j than draws
+}
+
+// draws of this slab that exist (the generated stretch may end inside it); 0 when the slab has nothing to do
+__device__ __forceinline__ int slab_len(const SlabArgs& a) {
+    if (a.ctl[SL_FALLBACK] != 0 || a.ctl[SL_D] != a.slab_off || a.ctl[SL_S] >= a.n_slots) return 0;
+    const int64_t left = a.ctl[SL_NRAW] - a.slab_off;
+    return left <= 0 ? 0 : static_cast<int>(left < a.slab_b ? left : a.slab_b);
+}
+
+__global__ __launch_bounds__(SLAB_T) void slab_detect_kernel(SlabArgs a) {
+    __shared__ int64_t l_own[SLAB_ROWS + 1];
+    __shared__ int s_ubase, s_cover;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int len = slab_len(a);
+    const int j0 = blockIdx.x * SLAB_T;
+    if (j0 >= len) return;
+    const int64_t S = a.ctl[SL_S];
+    const int j = j0 + tid;
+    const int jl = (j0 + SLAB_T - 1 < len ? j0 + SLAB_T - 1 : len - 1);      // last draw of this workgroup
+    // slots this workgroup's draws can land in
+    int64_t slot_lo = S + j0 - slab_window(a, jl);
+    if (slot_lo < S) slot_lo = S;
+    int64_t slot_hi = S + jl;
+    if (slot_hi > a.n_slots - 1) slot_hi = a.n_slots - 1;
+    const bool beyond = slot_lo > a.n_slots - 1;        // every draw here comes after the last slot is filled
+    const int64_t q_lo = slot_lo / a.num_neg, q_hi = slot_hi / a.num_neg;
+    if (tid == 0) s_ubase = beyond ? 0 : owner_of(a.optr, 0, a.n_users - 1, q_lo);
+    __syncthreads();
+    const int ubase = s_ubase;
+    const int nrow = a.n_users - ubase < SLAB_ROWS ? a.n_users - ubase : SLAB_ROWS;   // users ubase .. ubase + nrow - 1
+    for (int i = tid; i <= nrow; i += SLAB_T) l_own[i] = a.optr[ubase + i];
+    __syncthreads();
+    if (tid == 0) s_cover = (l_own[nrow] > q_hi) ? 1 : 0;      // the owner of q_hi is inside the staged window
+    __syncthreads();
+    const bool covered = s_cover != 0;
+    bool is_ev = false;
+    uint32_t mask = 0;
+    int32_t uhi = EV_UNKNOWN;
+    if (j < len && !beyond) {
+        const uint64_t prod = static_cast<uint64_t>(a.raw[a.slab_off + j]) * a.high;
+        const int val = static_cast<int>(prod >> 32);
+        const uint32_t thr = (0u - a.high) % a.high;
+        int64_t smin = S + j - slab_window(a, j);
+        if (smin < S) smin = S;
+        if (static_cast<uint32_t>(prod) < thr) {
+            is_ev = true;
+            uhi = EV_LEMIRE;
+        } else if (smin <= a.n_slots - 1) {
+            if (!covered) {
+                is_ev = true;                      // the resolver hands the slab to the serial kernel
+            } else {
+                int64_t smax = S + j;
+                if (smax > a.n_slots - 1) smax = a.n_slots - 1;
+                const int64_t qmin = smin / a.num_neg, qmax = smax / a.num_neg;
+                // largest index with l_own[idx] <= q
+                int lo = 0, hi = nrow - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (l_own[mid] <= qmax) lo = mid; else hi = mid - 1; }
+                const int ihi = lo;
+                lo = 0; hi = ihi;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (l_own[mid] <= qmin) lo = mid; else hi = mid - 1; }
+                const int ilo = lo;
+                if (ihi - ilo >= 32) {
+                    is_ev = true;                  // more candidate users than a mask holds
+                } else {
+                    for (int i = ihi; i >= ilo; --i) {
+                        if (l_own[i + 1] == l_own[i]) continue;           // owns no slot: can never be the owner
+                        const int u = ubase + i;
+                        if (skr::contains_sorted(a.pos_sorted, a.rowptr[u], a.rowptr[u + 1], val)) mask |= 1u << (ihi - i);
+                    }
+                    if (mask) {
+                        is_ev = true;
+                        uhi = ubase + ihi;
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long b = __ballot(is_ev);
+    if (lane == 0) a.ev_bits[j >> 6] = b;          // (j is a multiple of 64 on lane 0)
+    if (is_ev) {
+        a.ev_mask[j] = mask;
+        a.ev_uhi[j] = uhi;
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_resolve_kernel(SlabArgs a) {
+    __shared__ int32_t l_j[SLAB_EV], l_uhi[SLAB_EV];      // l_uhi[e] becomes EV_REJECTED once event e is known to be rejected
+    __shared__ uint32_t l_mask[SLAB_EV];
+    __shared__ int64_t l_q0[SLAB_EV];                     // optr[uhi]
+    __shared__ int32_t l_bnd[SLAB_EV][SLAB_BND];          // optr[uhi] - optr[uhi - i]  (>= 0; INT32_MAX: no such user)
+    __shared__ int l_cnt[256];
+    __shared__ int s_total;
+    constexpr int32_t EV_REJECTED = -3;
+    const int tid = threadIdx.x;
+    const int len = slab_len(a);
+    if (tid == 0) a.ctl[SL_SLAB_N] = 0;
+    if (len == 0) return;
+    const int n_words = (len + 63) >> 6;
+    const int WPT = ((a.slab_b >> 6) + 255) / 256;      // bitmap words per thread
+    // events, in draw order
+    int cnt = 0;
+    for (int w = tid * WPT; w < (tid + 1) * WPT && w < n_words; ++w) {
+        a.rej_bits[w] = 0ull;
+        cnt += __popcll(a.ev_bits[w]);
+    }
+    l_cnt[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < 256; ++t) { const int c = l_cnt[t]; l_cnt[t] = run; run += c; }
+        s_total = run;
+    }
+    __syncthreads();
+    const int E = s_total;
+    const bool too_many = E > SLAB_EV;
+    if (!too_many) {
+        int e = l_cnt[tid];
+        for (int w = tid * WPT; w < (tid + 1) * WPT && w < n_words; ++w) {
+            unsigned long long bits = a.ev_bits[w];
+            while (bits) {
+                const int bpos = __ffsll(static_cast<long long>(bits)) - 1;
+                bits &= bits - 1;
+                l_j[e++] = (w << 6) + bpos;
+            }
+        }
+    }
+    __syncthreads();
+    if (!too_many) {
+        for (int e = tid; e < E; e += 256) {
+            const int j = l_j[e];
+            const int32_t uhi = a.ev_uhi[j];
+            l_uhi[e] = uhi;
+            l_mask[e] = a.ev_mask[j];
+            if (uhi >= 0) {
+                const int64_t q0 = a.optr[uhi];
+                l_q0[e] = q0;
+#pragma unroll
+                for (int i = 0; i < SLAB_BND; ++i) {
+                    int64_t d = (uhi - i >= 0) ? q0 - a.optr[uhi - i] : 0x7fffffff;
+                    l_bnd[e][i] = d > 0x7fffffff ? 0x7fffffff : static_cast<int32_t>(d);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // the serial chain: one lane, everything it reads is in LDS
+    if (tid == 0) {
+        const int64_t S = a.ctl[SL_S];
+        const int64_t remaining = a.n_slots - S;
+        int r = 0;
+        bool give_up = too_many;
+        for (int e = 0; e < E && !give_up; ++e) {
+            const int j = l_j[e];
+            if (j - r >= remaining) break;                       // every slot is filled before this draw is reached
+            if (r > slab_window(a, j)) { give_up = true; break; }  // more rejections than the detector allowed for
+            const int32_t uhi = l_uhi[e];
+            bool rejected;
+            if (uhi == EV_LEMIRE) {
+                rejected = true;
+            } else if (uhi < 0) {
+                give_up = true;
+                break;
+            } else {
+                // owner = the largest user u <= uhi with optr[u] <= q, i.e. the smallest i with optr[uhi] - optr[uhi - i] >= optr[uhi] - q
+                const int64_t need = l_q0[e] - (S + j - r) / a.num_neg;
+                int i = 0;
+                while (i < SLAB_BND && static_cast<int64_t>(l_bnd[e][i]) < need) ++i;
+                if (i == SLAB_BND) { give_up = true; break; }
+                rejected = (l_mask[e] >> i) & 1u;
+            }
+            if (rejected) {
+                ++r;
+                l_uhi[e] = EV_REJECTED;
+            }
+        }
+        if (give_up) {
+            a.ctl[SL_FALLBACK] = 1;                              // S and D stay at the slab's start
+            s_total = 0;
+        } else {
+            // r counts the rejections among the CONSUMED draws: the walk stops at the first event that is not reached
+            int64_t consumed = remaining + r;
+            if (consumed > len) consumed = len;
+            a.ctl[SL_SLAB_S] = S;
+            a.ctl[SL_SLAB_N] = consumed;
+            a.ctl[SL_S] = S + (consumed - r);
+            a.ctl[SL_D] = a.slab_off + consumed;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < s_total; e += 256)
+        if (l_uhi[e] == EV_REJECTED) atomicOr(&a.rej_bits[l_j[e] >> 6], 1ull << (l_j[e] & 63));
+}
+
+__global__ __launch_bounds__(SLAB_T) void slab_scatter_kernel(SlabArgs a) {
+    __shared__ int l_part[SLAB_T];
+    const int tid = threadIdx.x;
+    const int64_t consumed = a.ctl[SL_SLAB_N];
+    // the resolver has moved SL_D past this slab (or left it, or given up): SL_SLAB_N > 0 only for the slab just resolved
+    if (consumed <= 0 || a.ctl[SL_D] != a.slab_off + consumed) return;
+    const int j0 = blockIdx.x * SLAB_T;
+    if (j0 >= consumed) return;
+    const int64_t S = a.ctl[SL_SLAB_S];
+    // rejections before this workgroup's first draw: the bitmap words below j0 / 64
+    const int w0 = j0 >> 6;
+    int part = 0;
+    for (int w = tid; w < w0; w += SLAB_T) part += __popcll(a.rej_bits[w]);
+    l_part[tid] = part;
+    __syncthreads();
+    for (int o = SLAB_T / 2; o > 0; o >>= 1) {
+        if (tid < o) l_part[tid] += l_part[tid + o];
+        __syncthreads();
+    }
+    const int before_wg = l_part[0];
+    const int j = j0 + tid;
+    if (j >= consumed) return;
+    int before = before_wg;
+    for (int w = w0; w < (j >> 6); ++w) before += __popcll(a.rej_bits[w]);
+    const unsigned long long word = a.rej_bits[j >> 6];
+    if ((word >> (j & 63)) & 1ull) return;                       // rejected
+    before += __popcll(word & ((1ull << (j & 63)) - 1ull));
+    const uint64_t prod = static_cast<uint64_t>(a.raw[a.slab_off + j]) * a.high;
+    a.out[S + j - before] = static_cast<int>(prod >> 32);
+}
+
+__global__ void slab_begin_kernel(int64_t* ctl) {
+    ctl[SL_S] = 0; ctl[SL_D] = 0; ctl[SL_FALLBACK] = 0; ctl[SL_NRAW] = 0; ctl[SL_SLAB_S] = 0; ctl[SL_SLAB_N] = 0; ctl[SL_STATUS] = 0;
+}
+__global__ void slab_end_kernel(int64_t* ctl, int64_t n_slots) { ctl[SL_STATUS] = (ctl[SL_S] >= n_slots) ? 1 : 2; }
 
 // ------------------------------------------------------------------------------------------------
 // 3. fast path: slot-keyed xoshiro128++ with rejection against LDS-staged positives
@@ -599,18 +926,25 @@ __global__ __launch_bounds__(FS_T) void sample_fast_kernel(uint64_t seed, uint64
     }
 }
 
-__global__ void max_row_len_kernel(const int64_t* __restrict__ rowptr, int n_rows, int* __restrict__ out_max) {
+__global__ void max_row_len_kernel(const int64_t* __restrict__ rowptr, int n_rows, int* __restrict__ out_max,
+                                   unsigned long long* __restrict__ out_sumsq) {
     int m = 0;
+    unsigned long long sq = 0;
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n_rows;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int len = static_cast<int>(rowptr[i + 1] - rowptr[i]);
         m = len > m ? len : m;
+        sq += static_cast<unsigned long long>(len) * static_cast<unsigned long long>(len);
     }
     for (int o = 32; o > 0; o >>= 1) {
         int t = __shfl_xor(m, o, 64);
         m = t > m ? t : m;
+        sq += __shfl_xor(sq, o, 64);
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(out_max, m);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(out_max, m);
+        if (out_sumsq) atomicAdd(out_sumsq, sq);
+    }
 }
 
 }  // namespace
@@ -625,6 +959,15 @@ struct skr_sampler {
     int64_t* d_ctl = nullptr;               // [0] slots filled, [1] words consumed, [2] scratch (max row len)
     uint32_t* d_raw = nullptr;
     size_t raw_cap = 0;  // in words
+    // scratch of the slab path (one slab's worth)
+    uint32_t* d_carry = nullptr;            // generator state between the pieces of a stretch (624 words + position)
+    hipStream_t gen_stream = nullptr;       // the pieces are generated here, beside the slabs that consume them
+    std::vector<hipEvent_t> gen_events;
+    hipEvent_t start_event = nullptr;
+    unsigned long long* d_ev_bits = nullptr;
+    unsigned long long* d_rej_bits = nullptr;
+    uint32_t* d_ev_mask = nullptr;
+    int32_t* d_ev_uhi = nullptr;
 };
 
 namespace skr {
@@ -633,7 +976,8 @@ int max_row_len(const int64_t* d_rowptr, int n_rows, int* d_scratch, hipStream_t
     int blocks = (n_rows + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(max_row_len_kernel, dim3(blocks), dim3(256), 0, st, d_rowptr, n_rows, d_scratch);
+    hipLaunchKernelGGL(max_row_len_kernel, dim3(blocks), dim3(256), 0, st, d_rowptr, n_rows, d_scratch,
+                       static_cast<unsigned long long*>(nullptr));
     SKR_LAUNCH_CHECK();
     SKR_HIP(hipMemcpyAsync(out, d_scratch, sizeof(int), hipMemcpyDeviceToHost, st));
     SKR_HIP(hipStreamSynchronize(st));
@@ -651,7 +995,8 @@ int skr_sampler_create(uint32_t seed, skr_sampler** out) {
     SKR_HIP(hipMalloc(&s->d_state, MT_N * sizeof(uint32_t)));
     SKR_HIP(hipMalloc(&s->d_pos, sizeof(int)));
     SKR_HIP(hipMalloc(&s->d_draws, sizeof(unsigned long long)));
-    SKR_HIP(hipMalloc(&s->d_ctl, 16 * sizeof(int64_t)));
+    SKR_HIP(hipMalloc(&s->d_ctl, 32 * sizeof(int64_t)));
+    SKR_HIP(hipMemset(s->d_ctl, 0, 32 * sizeof(int64_t)));
     std::vector<uint32_t> mt(MT_N);
     mt[0] = seed;  // std::mt19937::seed(value)
     for (int i = 1; i < MT_N; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + static_cast<uint32_t>(i);
@@ -666,6 +1011,14 @@ int skr_sampler_destroy(skr_sampler* s) {
     (void)hipFree(s->d_draws);
     (void)hipFree(s->d_ctl);
     (void)hipFree(s->d_raw);
+    (void)hipFree(s->d_carry);
+    if (s->gen_stream) (void)hipStreamDestroy(s->gen_stream);
+    for (hipEvent_t e : s->gen_events) (void)hipEventDestroy(e);
+    if (s->start_event) (void)hipEventDestroy(s->start_event);
+    (void)hipFree(s->d_ev_bits);
+    (void)hipFree(s->d_rej_bits);
+    (void)hipFree(s->d_ev_mask);
+    (void)hipFree(s->d_ev_uhi);
     delete s;
     return SKR_OK;
 }
@@ -697,6 +1050,18 @@ int skr_sampler_draws(skr_sampler* s, uint64_t* n) {
     return SKR_OK;
 }
 
+int skr_sampler_last_epoch(skr_sampler* s, int64_t* h_info4) {
+    SKR_REQUIRE(s && h_info4, "skr_sampler_last_epoch: NULL argument");
+    SKR_HIP(hipDeviceSynchronize());
+    int64_t ctl[SL_STATUS + 1];
+    SKR_HIP(hipMemcpy(ctl, s->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+    h_info4[0] = ctl[SL_STATUS];      // 0: serial path (or no epoch yet), 1: slab path, every slot filled, 2: slab path, incomplete
+    h_info4[1] = ctl[SL_FALLBACK];    // 1: the slab path handed the rest of the stream to the serial kernel
+    h_info4[2] = ctl[SL_S];           // slots filled
+    h_info4[3] = ctl[SL_D];           // words of the generated stretch consumed
+    return SKR_OK;
+}
+
 int skr_randint_choice(skr_sampler* s, int high, int size, int replace, const float* d_prob,
                        const int32_t* d_exclusion, int n_exclusion, int32_t* d_result, void* stream) {
     SKR_REQUIRE(s && d_result, "skr_randint_choice: NULL argument");
@@ -718,8 +1083,9 @@ int skr_randint_choice(skr_sampler* s, int high, int size, int replace, const fl
     return SKR_OK;
 }
 
-// shared driver of the exact epoch: generate a stretch of the word stream, assign, commit, repeat
-static int run_exact_epoch(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
+// the exact epoch on ONE workgroup: generate a stretch of the word stream, assign, commit, repeat (dense data, tiny calls,
+// SKR_EXACT_PATH=serial)
+static int run_exact_epoch_serial(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
                            const int32_t* d_pos_sorted, const int64_t* d_drawptr, int num_neg, int64_t n_slots,
                            int32_t* d_out, hipStream_t st) {
     int64_t filled = 0;
@@ -739,7 +1105,8 @@ static int run_exact_epoch(skr_sampler* s, int num_items, int n_users, const int
             SKR_HIP(hipMalloc(&s->d_raw, static_cast<size_t>(n_gen) * sizeof(uint32_t)));
             s->raw_cap = static_cast<size_t>(n_gen);
         }
-        hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(GEN_T), 0, st, s->d_state, s->d_pos, s->d_raw, n_gen);
+        hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(GEN_T), 0, st, s->d_state, s->d_pos, s->d_raw, n_gen,
+                           static_cast<int64_t*>(nullptr));
         SKR_LAUNCH_CHECK();
         if (d_drawptr)
             hipLaunchKernelGGL(exact_assign_kernel<true>, dim3(1), dim3(AS_T), 0, st, s->d_raw, n_gen,
@@ -751,7 +1118,7 @@ static int run_exact_epoch(skr_sampler* s, int num_items, int n_users, const int
                                d_out, s->d_ctl, static_cast<const int64_t*>(nullptr));
         SKR_LAUNCH_CHECK();
         hipLaunchKernelGGL(mt_commit_kernel, dim3(1), dim3(256), 0, st, s->d_state, s->d_pos, s->d_draws, s->d_raw,
-                           n_gen, s->d_ctl);
+                           n_gen, s->d_ctl, static_cast<const int64_t*>(nullptr));
         SKR_LAUNCH_CHECK();
         int64_t ctl[2] = {0, 0};
         SKR_HIP(hipMemcpyAsync(ctl, s->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));
@@ -770,6 +1137,135 @@ static int run_exact_epoch(skr_sampler* s, int num_items, int n_users, const int
     return SKR_OK;
 }
 
+// The exact epoch in slabs (kernels 2d): nothing here waits for the device.  The stretch of the word stream is generated
+// with head-room for the rejections (the caller has checked that no row covers more than 1/16 of the catalogue, so the
+// 12.5 % + 4096 words always suffice); how many words were used is committed on the device (mt_commit_kernel), and
+// whether every slot was filled is left in d_ctl[SL_STATUS] for the next call to look at.
+static int run_exact_epoch_slabs(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
+                                 const int32_t* d_pos_sorted, const int64_t* d_drawptr, int num_neg, int64_t n_slots,
+                                 int32_t* d_out, double reject_rate, hipStream_t st) {
+    const int64_t want = n_slots + n_slots / 8 + 4096;
+    const size_t cap = static_cast<size_t>(want) + 2 * MT_N;
+    if (cap > s->raw_cap) {
+        if (s->d_raw) SKR_HIP(hipFree(s->d_raw));
+        s->d_raw = nullptr;
+        s->raw_cap = 0;
+        SKR_HIP(hipMalloc(&s->d_raw, cap * sizeof(uint32_t)));
+        s->raw_cap = cap;
+    }
+    if (!s->d_ev_bits) {
+        SKR_HIP(hipMalloc(&s->d_ev_bits, (SLAB_B / 64) * sizeof(unsigned long long)));
+        SKR_HIP(hipMalloc(&s->d_rej_bits, (SLAB_B / 64) * sizeof(unsigned long long)));
+        SKR_HIP(hipMalloc(&s->d_ev_mask, SLAB_B * sizeof(uint32_t)));
+        SKR_HIP(hipMalloc(&s->d_ev_uhi, SLAB_B * sizeof(int32_t)));
+    }
+    // the word stream is a serial chain on one workgroup (~0.8 G words/s): it is produced in pieces on a stream of the
+    // sampler's own, and the slabs of the caller's stream start as soon as the piece they read is there
+    constexpr int64_t PIECE = int64_t{1} << 21;
+    const int n_pieces = static_cast<int>((want + MT_N + PIECE - 1) / PIECE);
+    if (!s->gen_stream) {
+        SKR_HIP(hipStreamCreateWithFlags(&s->gen_stream, hipStreamNonBlocking));
+        SKR_HIP(hipEventCreateWithFlags(&s->start_event, hipEventDisableTiming));
+        SKR_HIP(hipMalloc(&s->d_carry, (MT_N + 1) * sizeof(uint32_t)));
+    }
+    while (static_cast<int>(s->gen_events.size()) < n_pieces) {
+        hipEvent_t e;
+        SKR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->gen_events.push_back(e);
+    }
+    hipLaunchKernelGGL(slab_begin_kernel, dim3(1), dim3(1), 0, st, s->d_ctl);
+    SKR_HIP(hipEventRecord(s->start_event, st));
+    SKR_HIP(hipStreamWaitEvent(s->gen_stream, s->start_event, 0));
+    for (int pc = 0; pc < n_pieces; ++pc) {
+        hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(GEN_T), 0, s->gen_stream, s->d_state, s->d_pos, s->d_raw, -want,
+                           s->d_ctl + SL_NRAW, s->d_carry, pc, PIECE);
+        SKR_HIP(hipEventRecord(s->gen_events[pc], s->gen_stream));
+    }
+    SKR_LAUNCH_CHECK();
+    int pieces_awaited = 0;
+    SlabArgs a{};
+    a.raw = s->d_raw;
+    a.high = static_cast<uint32_t>(num_items);
+    a.rowptr = d_rowptr;
+    a.optr = d_drawptr ? d_drawptr : d_rowptr;
+    a.n_users = n_users;
+    a.pos_sorted = d_pos_sorted;
+    a.num_neg = num_neg;
+    a.n_slots = n_slots;
+    a.ctl = s->d_ctl;
+    // W(j) = 24 + 2 * (expected rejections among j draws): a slab's rejection count is Poisson-like, so this is many
+    // standard deviations of head-room; if it is ever exceeded the resolver hands over to the serial kernel
+    a.win0 = 24;
+    const double rate = 2.0 * reject_rate * 65536.0 + 1.0;
+    a.win_rate = rate > 4.0e9 ? 4000000000u : static_cast<uint32_t>(rate);
+    a.ev_bits = s->d_ev_bits;
+    a.rej_bits = s->d_rej_bits;
+    a.ev_mask = s->d_ev_mask;
+    a.ev_uhi = s->d_ev_uhi;
+    a.out = d_out;
+    // slab length: about 256 expected rejections per slab (each shows up as a few events, the resolver holds SLAB_EV)
+    int slab_b = SLAB_B;
+    while (slab_b > 4096 && reject_rate * slab_b > 256.0) slab_b >>= 1;
+    a.slab_b = slab_b;
+    const int64_t n_slabs = (want + MT_N + slab_b - 1) / slab_b;      // the generator stops at most MT_N words past `want`
+    for (int64_t k = 0; k < n_slabs; ++k) {
+        a.slab_off = k * slab_b;
+        int last_piece = static_cast<int>((a.slab_off + slab_b - 1) / PIECE);     // the piece holding this slab's last word
+        if (last_piece > n_pieces - 1) last_piece = n_pieces - 1;
+        for (; pieces_awaited <= last_piece; ++pieces_awaited) SKR_HIP(hipStreamWaitEvent(st, s->gen_events[pieces_awaited], 0));
+        hipLaunchKernelGGL(slab_detect_kernel, dim3(slab_b / SLAB_T), dim3(SLAB_T), 0, st, a);
+        hipLaunchKernelGGL(slab_resolve_kernel, dim3(1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(slab_scatter_kernel, dim3(slab_b / SLAB_T), dim3(SLAB_T), 0, st, a);
+    }
+    SKR_LAUNCH_CHECK();
+    for (; pieces_awaited < n_pieces; ++pieces_awaited) SKR_HIP(hipStreamWaitEvent(st, s->gen_events[pieces_awaited], 0));
+    // whatever the slabs left (normally nothing: the kernel returns at once)
+    if (d_drawptr)
+        hipLaunchKernelGGL(exact_assign_kernel<true>, dim3(1), dim3(AS_T), 0, st, s->d_raw, 0, static_cast<uint32_t>(num_items),
+                           d_rowptr, n_users, d_pos_sorted, 1, n_slots, static_cast<int64_t>(-1), d_out, s->d_ctl, d_drawptr);
+    else
+        hipLaunchKernelGGL(exact_assign_kernel<false>, dim3(1), dim3(AS_T), 0, st, s->d_raw, 0, static_cast<uint32_t>(num_items),
+                           d_rowptr, n_users, d_pos_sorted, num_neg, n_slots, static_cast<int64_t>(-1), d_out, s->d_ctl,
+                           static_cast<const int64_t*>(nullptr));
+    hipLaunchKernelGGL(slab_end_kernel, dim3(1), dim3(1), 0, st, s->d_ctl, n_slots);
+    hipLaunchKernelGGL(mt_commit_kernel, dim3(1), dim3(256), 0, st, s->d_state, s->d_pos, s->d_draws, s->d_raw,
+                       static_cast<int64_t>(0), s->d_ctl, s->d_ctl + SL_NRAW);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+// One read-back per call, at its START (the stream is normally idle then): the longest row (the reference's argument check,
+// pyx_random.pyx:49), the sum of squared row lengths (how often a draw hits a positive), and whether the PREVIOUS exact
+// epoch filled every slot.  Then the path: slabs for sparse data, the serial kernel otherwise.
+static int run_exact_epoch(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr, const int32_t* d_pos_sorted,
+                           const int64_t* d_drawptr, int num_neg, int64_t n_slots, int64_t nnz, int32_t* d_out, hipStream_t st,
+                           const char* who) {
+    SKR_HIP(hipMemsetAsync(s->d_ctl + SL_SCRATCH, 0, 2 * sizeof(int64_t), st));
+    int blocks = (n_users + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(max_row_len_kernel, dim3(blocks), dim3(256), 0, st, d_rowptr, n_users, reinterpret_cast<int*>(s->d_ctl + SL_SCRATCH),
+                       reinterpret_cast<unsigned long long*>(s->d_ctl + SL_SUMSQ));
+    SKR_LAUNCH_CHECK();
+    int64_t host[SL_STATUS + 1];
+    SKR_HIP(hipMemcpyAsync(host, s->d_ctl, sizeof(host), hipMemcpyDeviceToHost, st));
+    SKR_HIP(hipStreamSynchronize(st));
+    const int max_len = static_cast<int>(host[SL_SCRATCH] & 0xffffffff);
+    if (host[SL_STATUS] == 2) {
+        SKR_HIP(hipMemsetAsync(s->d_ctl + SL_STATUS, 0, sizeof(int64_t), st));
+        return skr::fail(SKR_EOVERFLOW, "%s: the previous exact epoch ran out of generated words before every slot was filled", who);
+    }
+    SKR_REQUIRE(max_len < num_items, "The length of 'exclusion' must be smaller than 'high'.");  // pyx_random.pyx:49
+    const char* path = getenv("SKR_EXACT_PATH");
+    const bool force_slab = path && !strcmp(path, "slab"), force_serial = path && !strcmp(path, "serial");
+    const bool sparse = static_cast<int64_t>(max_len) * 16 <= num_items;
+    if (!force_serial && sparse && (force_slab || n_slots >= 4096)) {
+        const double lemire = static_cast<double>((0u - static_cast<uint32_t>(num_items)) % static_cast<uint32_t>(num_items)) / 4294967296.0;
+        const double rate = (nnz > 0 ? static_cast<double>(static_cast<unsigned long long>(host[SL_SUMSQ])) / (static_cast<double>(nnz) * num_items) : 0.0) + lemire;
+        return run_exact_epoch_slabs(s, num_items, n_users, d_rowptr, d_pos_sorted, d_drawptr, num_neg, n_slots, d_out, rate, st);
+    }
+    return run_exact_epoch_serial(s, num_items, n_users, d_rowptr, d_pos_sorted, d_drawptr, num_neg, n_slots, d_out, st);
+}
+
 int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
                            const int32_t* d_pos_sorted, int64_t nnz, int num_neg, int32_t* d_out, void* stream) {
     SKR_REQUIRE(s && d_rowptr && d_pos_sorted && d_out, "skr_sample_epoch_exact: NULL argument");
@@ -778,13 +1274,10 @@ int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int
     SKR_REQUIRE(nnz >= 0, "skr_sample_epoch_exact: negative nnz");
     hipStream_t st = skr::as_stream(stream);
     if (nnz == 0) return SKR_OK;
-    int max_len = 0;
-    int rc = skr::max_row_len(d_rowptr, n_users, reinterpret_cast<int*>(s->d_ctl + 2), st, &max_len);
-    if (rc) return rc;
-    SKR_REQUIRE(max_len < num_items, "The length of 'exclusion' must be smaller than 'high'.");  // pyx_random.pyx:49
     const int64_t n_slots = nnz * num_neg;
     SKR_REQUIRE(n_slots < (int64_t(1) << 31), "more than 2^31-1 samples per call (the reference's int limit)");
-    return run_exact_epoch(s, num_items, n_users, d_rowptr, d_pos_sorted, nullptr, num_neg, n_slots, d_out, st);
+    return run_exact_epoch(s, num_items, n_users, d_rowptr, d_pos_sorted, nullptr, num_neg, n_slots, nnz, d_out, st,
+                           "skr_sample_epoch_exact");
 }
 
 int skr_sample_epoch_exact_counts(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
@@ -798,11 +1291,8 @@ int skr_sample_epoch_exact_counts(skr_sampler* s, int num_items, int n_users, co
     SKR_REQUIRE(n_draws >= 0 && n_draws < (int64_t(1) << 31), "more than 2^31-1 samples per call (the reference's int limit)");
     hipStream_t st = skr::as_stream(stream);
     if (n_draws == 0) return SKR_OK;
-    int max_len = 0;
-    int rc = skr::max_row_len(d_rowptr, n_users, reinterpret_cast<int*>(s->d_ctl + 2), st, &max_len);
-    if (rc) return rc;
-    SKR_REQUIRE(max_len < num_items, "The length of 'exclusion' must be smaller than 'high'.");  // pyx_random.pyx:49
-    return run_exact_epoch(s, num_items, n_users, d_rowptr, d_excl_sorted, d_drawptr, 1, n_draws, d_out, st);
+    return run_exact_epoch(s, num_items, n_users, d_rowptr, d_excl_sorted, d_drawptr, 1, n_draws, nnz, d_out, st,
+                           "skr_sample_epoch_exact_counts");
 }
 
 int skr_sample_epoch_fast(uint64_t seed, uint64_t epoch, int64_t slot_offset, int num_items, int n_users,

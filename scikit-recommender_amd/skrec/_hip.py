@@ -28,6 +28,7 @@ SIGNATURES = {
     "skr_sampler_get_state": (i32, [vp, vp, C.POINTER(i32)]),
     "skr_sampler_set_state": (i32, [vp, vp, i32]),
     "skr_sampler_draws": (i32, [vp, C.POINTER(u64)]),
+    "skr_sampler_last_epoch": (i32, [vp, C.POINTER(i64)]),
     "skr_randint_choice": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp]),
     "skr_sample_epoch_exact": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, vp]),
     "skr_sample_epoch_exact_counts": (i32, [vp, i32, i32, vp, vp, i64, vp, i64, vp, vp]),

@@ -73,6 +73,12 @@ class DeviceSampler(object):
                                                      _hip.ptr(d_pos_sorted), int(nnz), int(num_neg), _hip.ptr(d_out),
                                                      _hip.stream()))
 
+    def last_epoch(self):
+        """how the last exact epoch ran: dict(status, handed_over, filled, consumed) -- see skr_sampler_last_epoch"""
+        info = (C.c_int64 * 4)()
+        _hip.check(_hip.lib().skr_sampler_last_epoch(self._h, info))
+        return dict(status=int(info[0]), handed_over=int(info[1]), filled=int(info[2]), consumed=int(info[3]))
+
     def sample_epoch_exact_counts(self, num_items, n_users, d_rowptr, d_excl_sorted, nnz, d_drawptr, n_draws, d_out):
         """exclusion CSR and per-user draw counts given separately (sequential / knowledge-graph iterators)"""
         _hip.check(_hip.lib().skr_sample_epoch_exact_counts(self._h, int(num_items), int(n_users), _hip.ptr(d_rowptr),

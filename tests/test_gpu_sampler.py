@@ -106,6 +106,73 @@ def test_exact_epoch_matches_oracle(U, I, lo, hi, nn):
     assert (p_ref % 624) == (p_gpu % 624) or {p_ref, p_gpu} <= {0, 624}
 
 
+def _csr_from_lens(rng, lens, num_items):
+    rowptr = np.zeros(len(lens) + 1, np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    pos = np.concatenate([np.sort(rng.choice(num_items, l, replace=False)) for l in lens if l > 0] + [np.zeros(0, np.int64)]).astype(np.int32)
+    return rowptr, pos
+
+
+@pytest.mark.parametrize("case", ["uniform", "empties", "burst", "edges", "nn2"])
+@pytest.mark.parametrize("path", ["slab", "serial"])
+def test_exact_epoch_slab_path_matches_oracle(case, path, monkeypatch):
+    """The whole-chip form of the exact epoch (slabs of 131 072 draws: detect -> resolve -> scatter, sampler.hip 2d) and
+    the one-workgroup form give the oracle's negatives and stream position, bit for bit, on sparse data of every kind the
+    slab path has a special answer for:
+      uniform  several slabs, a few hundred events each
+      empties  most users own no slot: the owner of a slot lies more than 8 users below the highest candidate -> the
+               resolver hands the rest of the stream to the serial kernel
+      burst    a block of users 30x denser than the data set's average: more rejections inside a slab than the window
+               the detector allowed for -> hand-over in the middle of the stream
+      edges    slot counts within a few draws of a slab boundary, one-slot rows, a single user
+      nn2      two negatives per positive (a slot's owner is slot // 2)"""
+    from gpu_utils import ExactSampler
+    monkeypatch.setenv("SKR_EXACT_PATH", path)
+    rng = np.random.default_rng({"uniform": 1, "empties": 2, "burst": 3, "edges": 4, "nn2": 5}[case])
+    nn = 1
+    if case == "uniform":
+        I = 4000
+        rowptr, pos = _csr_from_lens(rng, rng.integers(20, 120, 6000), I)
+    elif case == "empties":
+        I = 50_000
+        lens = np.where(rng.random(400_000) < 0.1, rng.integers(1, 6, 400_000), 0)
+        rowptr, pos = _csr_from_lens(rng, lens, I)
+    elif case == "burst":
+        I = 3200
+        lens = np.concatenate([np.full(45_000, 2), np.full(100, 200), np.full(45_000, 2)])
+        rowptr, pos = _csr_from_lens(rng, lens, I)
+    elif case == "edges":
+        I = 100_000
+        rowptr, pos = None, None
+    else:
+        I, nn = 2000, 2
+        rowptr, pos = _csr_from_lens(rng, rng.integers(0, 90, 3000), I)
+    if case == "edges":
+        for n_slots in (131072 - 2, 131072, 131072 + 1, 2 * 131072 - 40, 4096, 5000):
+            lens = np.ones(n_slots, np.int64) if n_slots % 2 else np.array([n_slots])
+            if len(lens) == 1:
+                lens = np.array([min(n_slots, 6000)] * (n_slots // 6000) + ([n_slots % 6000] if n_slots % 6000 else []))
+            rp, ps = _csr_from_lens(rng, lens, I)
+            ref, gpu = O.Sampler(2020), ExactSampler(2020)
+            for _ in range(2):
+                assert np.array_equal(gpu.epoch(I, rp, ps, 1), ref.sample_epoch(I, rp, ps, 1)), n_slots
+                assert gpu.s.draws == ref.draws
+        return
+    ref, gpu = O.Sampler(2020), ExactSampler(2020)
+    for epoch in range(2):
+        want = ref.sample_epoch(I, rowptr, pos, nn).reshape(-1)
+        got = gpu.epoch(I, rowptr, pos, nn)
+        assert np.array_equal(got, want), (epoch, np.flatnonzero(got != want)[:5], len(want))
+        assert gpu.s.draws == ref.draws
+        how = gpu.s.last_epoch()
+        if path == "serial":
+            assert how["status"] == 0
+        else:   # the slab path ran, filled every slot, and handed over exactly where it is designed to
+            assert how["status"] == 1 and how["filled"] == len(want)
+            assert how["handed_over"] == (1 if case in ("empties", "burst") else 0), how
+    assert ref.next_u32() == _next_from_state(*gpu.s.get_state())
+
+
 def _next_from_state(words, pos):
     s = O.Sampler(1)
     s.set_state(words, pos)
