@@ -620,6 +620,8 @@ def main():
     def sample_slice(sl):
         neg = torch.empty(sl["nnz"], dtype=torch.int32, device=dev)
         sampler.sample_epoch_exact(nI, sl["n_users"], sl["rowptr"], sl["items"], sl["nnz"], 1, neg)
+        if os.environ.get("SKR_BENCH_SYNC_AFTER_SAMPLER") == "1":     # diagnosis of shared-GPU rehearsals only
+            torch.cuda.synchronize()
         return neg
 
     def run_slice(sl, n_steps, phase=None, neg=None):

@@ -1174,15 +1174,21 @@ static int run_exact_epoch_slabs(skr_sampler* s, int num_items, int n_users, con
         s->gen_events.push_back(e);
     }
     hipLaunchKernelGGL(slab_begin_kernel, dim3(1), dim3(1), 0, st, s->d_ctl);
-    SKR_HIP(hipEventRecord(s->start_event, st));
-    SKR_HIP(hipStreamWaitEvent(s->gen_stream, s->start_event, 0));
+    // SKR_SAMPLER_ONE_STREAM=1: everything on the caller's stream (several processes sharing ONE GPU -- rehearsals of the
+    // multi-rank paths -- oversubscribe the hardware queues, and cross-queue waits then cost milliseconds)
+    static const bool one_stream = getenv("SKR_SAMPLER_ONE_STREAM") && !strcmp(getenv("SKR_SAMPLER_ONE_STREAM"), "1");
+    hipStream_t gst = one_stream ? st : s->gen_stream;
+    if (!one_stream) {
+        SKR_HIP(hipEventRecord(s->start_event, st));
+        SKR_HIP(hipStreamWaitEvent(gst, s->start_event, 0));
+    }
     for (int pc = 0; pc < n_pieces; ++pc) {
-        hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(GEN_T), 0, s->gen_stream, s->d_state, s->d_pos, s->d_raw, -want,
+        hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(GEN_T), 0, gst, s->d_state, s->d_pos, s->d_raw, -want,
                            s->d_ctl + SL_NRAW, s->d_carry, pc, PIECE);
-        SKR_HIP(hipEventRecord(s->gen_events[pc], s->gen_stream));
+        if (!one_stream) SKR_HIP(hipEventRecord(s->gen_events[pc], gst));
     }
     SKR_LAUNCH_CHECK();
-    int pieces_awaited = 0;
+    int pieces_awaited = one_stream ? n_pieces : 0;
     SlabArgs a{};
     a.raw = s->d_raw;
     a.high = static_cast<uint32_t>(num_items);
