@@ -31,7 +31,7 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
     const int32_t* __restrict__ i_ids, const int32_t* __restrict__ j_ids, int n, float loss_scale, float reg,
     float reg_scale, float* __restrict__ gP, float* __restrict__ gQ, float* __restrict__ gb, float* __restrict__ gRP,
     float* __restrict__ gRQ, float* __restrict__ loss, uint8_t* __restrict__ touch, const float* touch_base,
-    int loss_slots) {
+    int loss_slots, int shard_world, int shard_rank) {
     __shared__ float s_loss[BPR_WAVES], s_l2[BPR_WAVES];
     // mark the 64-float gradient block that starts at `a` as touched (one lane per row is enough)
     // (a byte that is already non-zero -- 1, or the sticky 2 -- is left alone)
@@ -44,7 +44,12 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
     const float rs = reg * reg_scale;
     const bool same_tables = RP == P && RQ == Q && gRP == gP && gRQ == gQ;
     for (int b = blockIdx.x * BPR_WAVES + wv; b < n; b += gridDim.x * BPR_WAVES) {
-        const int64_t u = u_ids[b], i = i_ids[b], j = j_ids[b];
+        int64_t u = u_ids[b];
+        const int64_t i = i_ids[b], j = j_ids[b];
+        if (shard_world > 1) {      // a GLOBAL batch on a user-sharded rank: only the triples of the users this rank owns
+            if (u % shard_world != shard_rank) continue;
+            u /= shard_world;       // row of the local user table
+        }
         const float pu = P[u * D + lane], qi = Q[i * D + lane], qj = Q[j * D + lane];
         // x_ui - x_uj; the two inner products are reduced separately like inner_product() does
         float xi = skr::wave_sum(pu * qi), xj = skr::wave_sum(pu * qj);
@@ -363,6 +368,25 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, const int32_
     const int64_t k = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
     if (k >= n) return;
     out[k * D + lane] = table[static_cast<int64_t>(idx[k]) * D + lane];
+}
+
+// table[idx[k]] = src[k]; negative ids are skipped; duplicate ids must carry identical rows
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int64_t n,
+                                    float* __restrict__ table) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
+    if (k >= n || idx[k] < 0) return;
+    table[static_cast<int64_t>(idx[k]) * D + lane] = src[k * D + lane];
+}
+
+// out[i] = ((in[0][i] + in[1][i]) + in[2][i]) + ...   -- the ranks' blocks added in rank order, the same bits on every rank
+__global__ void sum_blocks_kernel(const float* __restrict__ in, int n_blocks, int64_t n, float* __restrict__ out) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
+        float acc = in[i];
+        for (int b = 1; b < n_blocks; ++b) acc += in[b * n + i];
+        out[i] = acc;
+    }
 }
 
 __global__ void axpy_kernel(float a, const float* __restrict__ x, float* __restrict__ y, int64_t n) {
@@ -907,9 +931,12 @@ extern "C" {
 static int bpr_step_launch(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
                  const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n, float loss_scale, float reg,
                  float reg_scale, float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ, float* d_loss,
-                 uint8_t* d_touch, const float* d_touch_base, int loss_slots, void* stream) {
+                 uint8_t* d_touch, const float* d_touch_base, int loss_slots, void* stream, int shard_world = 1,
+                 int shard_rank = 0) {
     SKR_REQUIRE(d_P && d_Q && d_RP && d_RQ && d_u && d_i && d_j && d_gP && d_gQ && d_gRP && d_gRQ && d_loss,
                 "skr_bpr_step: NULL argument");
+    SKR_REQUIRE(shard_world >= 1 && shard_rank >= 0 && shard_rank < shard_world, "skr_bpr_step_sharded: rank %d of %d", shard_rank,
+                shard_world);
     SKR_REQUIRE(n >= 0, "skr_bpr_step: negative batch size");
     SKR_REQUIRE(!d_touch || d_touch_base, "skr_bpr_step: d_touch needs d_touch_base");
     if (n == 0) return SKR_OK;
@@ -917,7 +944,7 @@ static int bpr_step_launch(const float* d_P, const float* d_Q, const float* d_bi
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bpr_step_kernel, dim3(blocks), dim3(BPR_WAVES * 64), 0, skr::as_stream(stream), d_P, d_Q, d_bias,
                        d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP, d_gRQ, d_loss,
-                       d_touch, d_touch_base, loss_slots);
+                       d_touch, d_touch_base, loss_slots, shard_world, shard_rank);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
@@ -928,6 +955,14 @@ int skr_bpr_step(const float* d_P, const float* d_Q, const float* d_bias, const 
                  uint8_t* d_touch, const float* d_touch_base, void* stream) {
     return bpr_step_launch(d_P, d_Q, d_bias, d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP,
                            d_gRQ, d_loss, d_touch, d_touch_base, 1, stream);
+}
+
+int skr_bpr_step_sharded(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
+                         const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n, float loss_scale, float reg,
+                         float reg_scale, float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ, float* d_loss,
+                         uint8_t* d_touch, const float* d_touch_base, int shard_world, int shard_rank, void* stream) {
+    return bpr_step_launch(d_P, d_Q, d_bias, d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP,
+                           d_gRQ, d_loss, d_touch, d_touch_base, 1, stream, shard_world, shard_rank);
 }
 
 int skr_bpr_step_spread(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
@@ -1042,6 +1077,27 @@ int skr_gather_rows(const float* d_table, const int32_t* d_idx, int64_t n, int d
     if (n <= 0) return SKR_OK;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(rows_to_blocks(n)), dim3(256), 0, skr::as_stream(stream), d_table, d_idx,
                        n, d_out);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_scatter_rows(const float* d_src, const int32_t* d_idx, int64_t n, int dim, float* d_table, void* stream) {
+    SKR_REQUIRE(d_table && d_idx && d_src, "skr_scatter_rows: NULL argument");
+    SKR_REQUIRE(dim == D, "skr_scatter_rows: dim must be 64 (got %d)", dim);
+    if (n <= 0) return SKR_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(rows_to_blocks(n)), dim3(256), 0, skr::as_stream(stream), d_src, d_idx, n,
+                       d_table);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_sum_blocks(const float* d_in, int n_blocks, int64_t n, float* d_out, void* stream) {
+    SKR_REQUIRE(d_in && d_out && n_blocks >= 1 && n >= 0, "skr_sum_blocks: bad argument");
+    if (n == 0) return SKR_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sum_blocks_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream), d_in, n_blocks, n,
+                       d_out);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

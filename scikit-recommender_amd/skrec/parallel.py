@@ -219,26 +219,61 @@ class ShardedLightGCN(object):
             if mi is not None:
                 ni.zero_()                                                # rows that are skipped must not carry old sums
             self.a_iu.spmm(xu, ni, row_mask=mi)                                # partial items <- local users
-            work = self.ctx.all_reduce_begin(ni)                               # the exchange step of this layer ...
-            self.a_ui.spmm(xi, nu, accum=fu, accum_scale=scale, row_mask=mu)   # ... beside: local users <- replicated items
-            self.ctx.all_reduce_end(work)
+            # the exchange step of this layer, beside the user-side product.  In the masked last layer only the GLOBAL
+            # batch's item rows carry anything: they travel as a compact [2 * batch, 64] block instead of the [I, 64] one
+            compact = self._batch_item_ids if (mi is not None and self.ctx.active) else None
+            if compact is not None:
+                work = self._rows_exchange_begin(ni, compact)
+            else:
+                work = self.ctx.all_reduce_begin(ni)
+            self.a_ui.spmm(xi, nu, accum=fu, accum_scale=scale, row_mask=mu)   # local users <- replicated items
+            if compact is not None:
+                self._rows_exchange_end(work, compact, ni)
+            else:
+                self.ctx.all_reduce_end(work)
             self._axpy(scale, ni, fi)
             xu, xi = nu, ni
         return self.final
 
-    def _batch_rows(self, ul, il, jl_all):
-        """(uint8 [n_local], uint8 [I]): the rows a global batch touches -- this rank's users, EVERY rank's items (the
-        item rows are replicated and summed over the ranks, so each rank needs the same set)"""
+    def _batch_rows(self, users, pos, neg):
+        """(uint8 [n_local], uint8 [I]) for a GLOBAL batch (global user ids): the rows it touches -- this rank's users,
+        EVERY rank's items (the item rows are replicated and summed over the ranks, so each rank needs the same set).
+        Also keeps the batch's item ids (pos ++ neg, identical on every rank) for the compact exchanges."""
         if getattr(self, "_mask_u", None) is None:
             self._mask_u = torch.zeros(self.n_local, dtype=torch.uint8, device=self.device)
             self._mask_i = torch.zeros(self.num_items, dtype=torch.uint8, device=self.device)
-        L, st = _hip.lib(), _hip.stream()
+        L, st, world, rank = _hip.lib(), _hip.stream(), self.ctx.world, self.ctx.rank
         self._mask_u.zero_()
         self._mask_i.zero_()
-        _hip.check(L.skr_mark_ids(_hip.ptr(ul), ul.numel(), 0, _hip.ptr(self._mask_u), st))
-        for t in (il, jl_all):
-            _hip.check(L.skr_mark_ids(_hip.ptr(t), t.numel(), 0, _hip.ptr(self._mask_i), st))
+        if world > 1:   # local rows of the users this rank owns; the others become -1 (skipped)
+            ul = torch.where((users % world) == rank, torch.div(users, world, rounding_mode="floor"), torch.full_like(users, -1))
+        else:
+            ul = users
+        _hip.check(L.skr_mark_ids(_hip.ptr(ul.contiguous()), ul.numel(), 0, _hip.ptr(self._mask_u), st))
+        self._batch_item_ids = torch.cat([pos, neg]).contiguous()
+        _hip.check(L.skr_mark_ids(_hip.ptr(self._batch_item_ids), self._batch_item_ids.numel(), 0, _hip.ptr(self._mask_i), st))
         return self._mask_u, self._mask_i
+
+    def _rows_exchange_begin(self, block, ids):
+        """Sum the rows `ids` of a replicated [I, 64] block over the ranks, compactly: the rows are gathered into a
+        [len(ids), 64] buffer, the ranks' buffers all-gathered (started here, on the collective's stream) ..."""
+        import torch.distributed as dist
+        n, world = ids.numel(), self.ctx.world
+        if getattr(self, "_xrows", None) is None or self._xrows.shape[0] != n:
+            self._xrows = torch.empty((n, 64), dtype=torch.float32, device=self.device)
+            self._xall = torch.empty((world, n, 64), dtype=torch.float32, device=self.device)
+        _hip.check(_hip.lib().skr_gather_rows(_hip.ptr(block), _hip.ptr(ids), n, 64, _hip.ptr(self._xrows), _hip.stream()))
+        if dist.get_backend() == "nccl":
+            return dist.all_gather_into_tensor(self._xall, self._xrows, async_op=True)
+        return dist.all_gather([self._xall[r] for r in range(world)], self._xrows, async_op=True)
+
+    def _rows_exchange_end(self, work, ids, block):
+        """... and added up in RANK ORDER by every rank itself (skr_sum_blocks): the replicas end with identical bits
+        whatever order the collective library reduces in; the sums go back into the block's rows."""
+        work.wait()
+        L, st, n = _hip.lib(), _hip.stream(), ids.numel()
+        _hip.check(L.skr_sum_blocks(_hip.ptr(self._xall), self.ctx.world, n * 64, _hip.ptr(self._xrows), st))
+        _hip.check(L.skr_scatter_rows(_hip.ptr(self._xrows), _hip.ptr(ids), n, 64, _hip.ptr(block), st))
 
     # ---- one training step on a GLOBAL batch -----------------------------------------------------------
     def train_step(self, users, pos, neg):
@@ -247,31 +282,30 @@ class ShardedLightGCN(object):
         global (bpr mean, l2) of this step."""
         K, nl, world, rank = self.n_layers, self.n_local, self.ctx.world, self.ctx.rank
         n_global = users.numel()
-        if world > 1:
-            sel = (users % world) == rank
-            ul = torch.div(users[sel], world, rounding_mode="floor").int().contiguous()
-            il, jl = pos[sel].contiguous(), neg[sel].contiguous()
-        else:
-            ul, il, jl = users.contiguous(), pos.contiguous(), neg.contiguous()
+        users, pos, neg = users.contiguous(), pos.contiguous(), neg.contiguous()
         # skipped: rows of the last forward layer that no rank's batch reads, and -- in the first backward hop -- the
         # entries that would multiply rows of dL/dfinal that are zero (everything outside the batch).  SKR_LIGHTGCN_DENSE=1
         # computes everything.
-        masks = None if os.environ.get("SKR_LIGHTGCN_DENSE") == "1" else self._batch_rows(ul, pos.contiguous(), neg.contiguous())
+        masks = None if os.environ.get("SKR_LIGHTGCN_DENSE") == "1" else self._batch_rows(users, pos, neg)
         self.propagate(last_rows=masks)
         gF, gE = self._g_final, self._g_ego
         gF.zero_()
         self.loss.zero_()
-        if ul.numel() > 0:
-            _hip.check(_hip.lib().skr_bpr_step(
-                _hip.ptr(self.final[:nl]), _hip.ptr(self.final[nl:]), None, _hip.ptr(self.ego[:nl]), _hip.ptr(self.ego[nl:]),
-                _hip.ptr(ul), _hip.ptr(il), _hip.ptr(jl), ul.numel(), 1.0 / n_global, self.reg, 1.0 / self.batch_size_cfg,
-                _hip.ptr(gF[:nl]), _hip.ptr(gF[nl:]), None, _hip.ptr(gE[:nl]), _hip.ptr(gE[nl:]), _hip.ptr(self.loss),
-                None, None, _hip.stream()))
+        # the whole GLOBAL batch goes to the kernel, which keeps the triples of the users this rank owns: no selection on
+        # the host, no count to read back
+        _hip.check(_hip.lib().skr_bpr_step_sharded(
+            _hip.ptr(self.final[:nl]), _hip.ptr(self.final[nl:]), None, _hip.ptr(self.ego[:nl]), _hip.ptr(self.ego[nl:]),
+            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), n_global, 1.0 / n_global, self.reg, 1.0 / self.batch_size_cfg,
+            _hip.ptr(gF[:nl]), _hip.ptr(gF[nl:]), None, _hip.ptr(gE[:nl]), _hip.ptr(gE[nl:]), _hip.ptr(self.loss),
+            None, None, world, rank, _hip.stream()))
         self.ctx.all_reduce(self.loss)
         # H = dL/dfinal / (K+1); the item half is a partial sum over ranks
         _hip.check(_hip.lib().skr_scale(1.0 / (K + 1), _hip.ptr(gF), gF.numel(), _hip.stream()))
         hu, hi = gF[:nl], gF[nl:]
-        self.ctx.all_reduce(hi)
+        if masks is not None and self.ctx.active:      # hi is zero outside the global batch's item rows: compact exchange
+            self._rows_exchange_end(self._rows_exchange_begin(hi, self._batch_item_ids), self._batch_item_ids, hi)
+        else:
+            self.ctx.all_reduce(hi)
         gu, gi = hu, hi
         gEu, gEi = gE[:nl], gE[nl:]
         for k in range(K):
