@@ -216,6 +216,117 @@ def lightgcn_leg(args, world, rank, dev, dist, full, K, W, cpu_baseline):
     return leg
 
 
+def gru_leg(args, world, rank, dev, dist, K, W, cpu_baseline):
+    """BASELINE configs[4]: GRU4RecPlus d=128, histories of 50 events, the reference's session-parallel loop
+    (GRU4RecPlus.py:202-254: 128 sessions advance together, logits against the batch's own next items + 2048
+    popularity^0.75 negatives, bpr_max, TF-style dense Adam over both item tables); at N > 1 the 128 parallel sessions are
+    split over the ranks (skrec.recommender.GRU4RecPlus.ShardedSessionGRU: ONE compact exchange per step).  The data set
+    is `--sessions` synthetic sessions (10 M in configs[4]); only the sessions the W + K steps advance are materialised
+    (128 at a time, in order), the rest of an epoch repeats the same step.  PARITY UNPINNED (TensorFlow absent)."""
+    from skrec import _hip
+    from skrec.parallel import DistContext
+    from skrec.recommender.GRU4RecPlus import SessionGRU, ShardedSessionGRU
+    L_, st = _hip.lib(), _hip.stream
+    nI, d, b, n_s, T = args.items, 128, 128, 2048, 50
+    assert b % world == 0
+    g = torch.Generator().manual_seed(5)
+    E_in = torch.nn.init.trunc_normal_(torch.empty(nI, d), std=0.01, a=-0.02, b=0.02, generator=g)
+    E_out = torch.nn.init.trunc_normal_(torch.empty(nI, d), std=0.01, a=-0.02, b=0.02, generator=g)
+    lim_g, lim_c = (6.0 / (d + 3 * d)) ** 0.5, (6.0 / (d + 2 * d)) ** 0.5
+    cells = [((torch.rand(2 * d, 2 * d, generator=g) * 2 - 1) * lim_g, torch.ones(2 * d), (torch.rand(2 * d, d, generator=g) * 2 - 1) * lim_c,
+              torch.zeros(d))]
+    net_args = (E_in, cells, E_out, torch.zeros(nI), "tanh", "linear", "bpr_max", 1.0, 0.0, 1e-3, dev)
+    net = ShardedSessionGRU(DistContext(rank, world), *net_args) if world > 1 else SessionGRU(*net_args)
+    lo, hi = net.slots(b) if world > 1 else (0, b)
+    # item popularity Zipf(0.9); a session = T items drawn from it; negatives from popularity^0.75 (numpy uniforms, as the
+    # reference draws them; the search runs on the device: skr_pop_sample)
+    pop = 1.0 / np.arange(1, nI + 1) ** 0.9
+    pop = pop[np.random.default_rng(3).permutation(nI)]
+    cs_items = torch.from_numpy(np.cumsum(pop) / pop.sum()).to(dev)
+    p75 = np.cumsum(pop ** 0.75)
+    cs_neg = torch.from_numpy(p75 / p75[-1]).to(dev)
+    n_blocks = (W + K + 8 + T - 2) // (T - 1) + 1                 # groups of b sessions the steps walk through
+    items = torch.empty(n_blocks * b * T, dtype=torch.int32, device=dev)
+    _hip.check(L_.skr_pop_sample(_hip.ptr(cs_items), nI, None, 1234, items.numel(), _hip.ptr(items), st()))
+    items = items.view(n_blocks, b, T)
+    np.random.seed(77)                                             # the same negatives on every rank
+    state = {"s": net.zero_states(hi - lo), "step": 0}
+
+    def run(n_steps):
+        for _ in range(n_steps):
+            s_ = state["step"]
+            blk, t = divmod(s_, T - 1)
+            if t == 0 and s_ > 0:                                  # the b sessions ended together: fresh states
+                state["s"] = net.zero_states(hi - lo)
+            x = items[blk, :, t].contiguous()
+            u = torch.from_numpy(np.random.rand(n_s)).to(dev)
+            neg = torch.empty(n_s, dtype=torch.int32, device=dev)
+            _hip.check(L_.skr_pop_sample(_hip.ptr(cs_neg), nI, _hip.ptr(u), 0, n_s, _hip.ptr(neg), st()))
+            y = torch.cat([items[blk, :, t + 1], neg]).contiguous()
+            state["s"] = net.train_step(x, y, state["s"])
+            state["step"] += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    run(W)
+    barrier()
+    t0 = time.perf_counter()
+    run(K)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    loss = float(net.loss.cpu())
+    # dominant kernel of a step: the dense TF-semantics Adam over every parameter (both item tables) -- 28 B per parameter
+    opt = net.opt
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+    for a_, z_ in ev:
+        a_.record()
+        _hip.check(L_.skr_adam_step(_hip.ptr(opt.flat), _hip.ptr(opt.grad), _hip.ptr(opt.m), _hip.ptr(opt.v), opt.flat.numel(), 0.0, 0.9,
+                                    0.999, 1e-8, opt.t + 1, 1, _hip.ptr(opt.touch), st()))
+        z_.record()
+    torch.cuda.synchronize()
+    adam_ms = float(np.mean([a_.elapsed_time(z_) for a_, z_ in ev]))
+    adam_bytes = opt.flat.numel() * 28.0
+    leg = {"value": K * b / dt, "unit": "train events/s (one event = one session advancing one item)", "n_gpus": world, "steps": K, "warmup": W,
+           "ms_per_step": dt / K * 1e3, "scaling": "strong", "dtype": "f32", "parity": "unpinned (TensorFlow 1.14 absent; DESIGN.md 7)",
+           "last_loss": loss,
+           "config": {"workload": f"BASELINE configs[4]: GRU4RecPlus d={d}, {args.sessions} synthetic sessions of {T} events over {nI} items, "
+                                  f"session-parallel loop, {b} parallel sessions + {n_s} popularity^0.75 negatives, bpr_max, dense Adam",
+                      "parallel_sessions": b, "sessions_per_rank": hi - lo, "steps_per_epoch": args.sessions * (T - 1) // b,
+                      "sharding": f"the {b} parallel sessions split over {world} ranks; one compact all-gather per step "
+                                  f"({(b + n_s) * (d + 1) + b * d + 3 * 2 * d * d + 3 * d + 1} floats per rank), summed in rank order"},
+           "roofline": {"kernel": "adam_kernel (dense TF-semantics Adam over [E_in | E_out | b_out | GRU kernels], one launch per step)",
+                        "bound": "hbm", "achieved": adam_bytes / (adam_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": adam_bytes / (adam_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": adam_ms,
+                        "launches_averaged": len(ev), "algorithmic_bytes_per_launch": adam_bytes,
+                        "share_of_step": adam_ms / (dt / K * 1e3)}}
+    if cpu_baseline and world == 1:
+        from oracle import gru4rec as G
+        o = G.GRU4RecOracle(E_in.numpy(), [tuple(w.numpy() for w in cells[0])], E_out.numpy(), np.zeros(nI, np.float32), loss="bpr_max",
+                            bpr_reg=1.0, reg=0.0, lr=1e-3)
+        st_o = [torch.zeros(b, d)]
+        rng = np.random.default_rng(1)
+        ts = []
+        for s_ in range(4):
+            X = rng.integers(0, nI, b).astype(np.int32)
+            Y = rng.integers(0, nI, b + n_s).astype(np.int32)
+            t1 = time.perf_counter()
+            _, st_o = o.train_step(X, Y, st_o)
+            ts.append(time.perf_counter() - t1)
+        t_step = float(np.mean(ts[1:]))
+        leg["cpu_baseline"] = {"value": b / t_step, "unit": "train events/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"3 steps of the torch-CPU restatement of the graph (oracle/gru4rec.py: autograd + dense "
+                                         f"TF-style Adam) at the same sizes: {t_step * 1e3:.1f} ms per step"}
+    del net
+    torch.cuda.empty_cache()
+    return leg
+
+
 def pmc_lookup():
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE / WRITE_SIZE passes of
     bench.py: tools/profile_bench.sh -> tools/summarize_profiles.py -> profiles/<round>_pmc_summary.json).  Counters cannot
@@ -402,6 +513,8 @@ def finish(args, world, rank, dev, dist, full, V, bias, out):
     if not args.no_lightgcn:
         out["lightgcn"] = lightgcn_leg(args, world, rank, dev, dist, full, args.lightgcn_steps, args.lightgcn_warmup,
                                        not args.no_cpu_baseline)
+    if not args.no_gru and 128 % world == 0:
+        out["gru4rec"] = gru_leg(args, world, rank, dev, dist, args.gru_steps, 10, not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -506,7 +619,10 @@ def bprmf_strong(args, world, rank, dev, dist, full, ds):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["bprmf", "lightgcn"], default="bprmf")
+    ap.add_argument("--workload", choices=["bprmf", "lightgcn", "gru4rec"], default="bprmf")
+    ap.add_argument("--sessions", type=int, default=10_000_000, help="gru4rec leg: sessions of the synthetic data set")
+    ap.add_argument("--no-gru", action="store_true", help="skip the GRU4RecPlus leg (BASELINE configs[4])")
+    ap.add_argument("--gru-steps", type=int, default=100)
     ap.add_argument("--start-step", type=int, default=0, help="optimiser step count the run starts from (0 = a fresh model; "
                     "past ~16 600 steps Adam's second bias correction is exactly 1 and its division is skipped)")
     ap.add_argument("--gpus", type=int, default=1)
@@ -551,6 +667,16 @@ def main():
     L = _hip.lib()
     st = _hip.stream
 
+    if args.workload == "gru4rec":       # the GRU4RecPlus leg as the headline
+        leg = gru_leg(args, world, rank, dev, dist, args.steps, args.warmup, not args.no_cpu_baseline)
+        out = {"metric": "train interactions/sec + eval users/sec (HR@10/NDCG@10) at 1/2/4/8 MI355X", "higher_is_better": True,
+               "vs_baseline": None, "data": "synthetic"}
+        out.update(leg)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     full = same_on_every_rank(synth_dataset(args.users, args.items, args.interactions, 20260101, dev), rank, world, dev, dist)
     if args.workload == "lightgcn":      # the LightGCN leg as the headline
         leg = lightgcn_leg(args, world, rank, dev, dist, full, args.steps, args.warmup, not args.no_cpu_baseline)

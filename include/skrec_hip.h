@@ -286,8 +286,8 @@ int skr_layer_refine_fwd(const float* d_Y, const float* d_E, int64_t n_rows, int
 int skr_layer_refine_bwd(const float* d_Y, const float* d_E, const float* d_w, const float* d_dZ,
                          int64_t n_rows, int dim, float* d_dY, float* d_dE, void* stream);
 
-/* Row gather out[k] = table[idx[k]] (F.embedding) and  y = a*x + y  helpers used by the host
- * mirror so that no torch kernel sits on the hot path. */
+/* Row gather out[k] = table[idx[k]] (F.embedding; any row width `dim`, 64 has its own kernel) and  y = a*x + y  helpers
+ * used by the host mirror so that no torch kernel sits on the hot path. */
 int skr_gather_rows(const float* d_table, const int32_t* d_idx, int64_t n, int dim, float* d_out, void* stream);
 /* table[idx[k]] = src[k] (negative ids skipped; rows of duplicate ids must be identical): with skr_gather_rows, the
  * compact form in which the user-sharded engines exchange the FEW rows of a replicated block a step touches */
@@ -411,12 +411,26 @@ int skr_session_loss(const float* d_out, int B, int hid, const float* d_item_tab
                      const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
                      float* d_dout, float* d_loss, void* stream);
 
+/* One rank's share of a SESSION-SHARDED step (BASELINE configs[4]): the B_local sessions of this call are the
+ * slots slot_offset .. slot_offset + B_local - 1 of a batch of B_global sessions whose next items are the first B_global
+ * entries of d_y on every rank (row r's positive is column slot_offset + r); the loss is the mean over B_global. */
+int skr_session_loss_sharded(const float* d_out, int B_local, int hid, const float* d_item_table, const float* d_item_bias,
+                             const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
+                             float* d_dout, float* d_loss, int slot_offset, int B_global, void* stream);
+
 /* Output-side gradients of the same step, accumulated into dense gradient tables:
  *   d_g_table[Y[y]] += sum_b dlogits[b,y] out[b] + reg * E[Y[y]],  d_g_bias[Y[y]] += sum_b dlogits[b,y] + reg * bias[Y[y]]
  * (reg: the l2_loss term of :189-191; repeated targets count each time).  d_touch / d_touch_base as in skr_bpr_step. */
 int skr_session_out_grads(const float* d_dlogits, const float* d_out, int B, int hid, const int32_t* d_y, int n_y,
                           const float* d_item_table, const float* d_item_bias, float reg, float* d_g_table,
                           float* d_g_bias, uint8_t* d_touch, const float* d_touch_base, void* stream);
+
+/* The popularity^alpha negatives of the session-parallel loop (`_sample_neg_items`, GRU4RecPlus.py:198-200:
+ * np.searchsorted(pop_cumsum, np.random.rand(size))) on the device: d_out[k] = first index with d_cumsum[idx] >= u_k.
+ * d_uniform float64[n]: the uniforms drawn on the host from numpy's global generator (the reference's stream), or NULL:
+ * a counter-keyed device generator (seed, k) -- equal to the reference in law only.  d_cumsum float64[n_items], ascending. */
+int skr_pop_sample(const double* d_cumsum, int n_items, const double* d_uniform, uint64_t seed, int64_t n, int32_t* d_out,
+                   void* stream);
 
 /* d_g_table[index[n]] += src[n] + reg * table[index[n]]: gradient of an embedding lookup (+ l2_loss of the looked-up rows) */
 int skr_scatter_add_rows(const float* d_src, const int32_t* d_index, int n, int dim, const float* d_table, float reg,

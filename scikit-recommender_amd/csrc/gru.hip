@@ -326,12 +326,16 @@ __global__ __launch_bounds__(G_T) void session_logits_kernel(const float* __rest
 }
 
 // (b) per session: softmax over the other targets, loss, gradient w.r.t. the pre-activation logits (in place)
+// pos_off / B_mean: session row r of this launch is slot pos_off + r of a batch of B_mean sessions (its positive is
+// column pos_off + r, the loss is the mean over B_mean) -- one rank's share of a session-sharded step; 0 / B otherwise
 __global__ __launch_bounds__(G_T) void session_rowloss_kernel(int B, int n_y, int fact, int loss_kind, float bpr_reg,
-                                                              float* __restrict__ dlogits, float* __restrict__ loss) {
+                                                              float* __restrict__ dlogits, float* __restrict__ loss,
+                                                              int pos_off, int B_mean) {
     __shared__ float lg[L_NY_MAX];
     __shared__ float red[G_T / 64];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    float* row = dlogits + static_cast<int64_t>(b) * n_y;
+    const int tid = threadIdx.x;
+    float* row = dlogits + static_cast<int64_t>(blockIdx.x) * n_y;
+    const int b = pos_off + static_cast<int>(blockIdx.x);       // column of this session's positive
     float mx = 0.0f;   // the masked column contributes a 0 to the max
     for (int y = tid; y < n_y; y += G_T) {
         const float l = row[y];
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(G_T) void session_rowloss_kernel(int B, int n_y, in
     a0 = block_reduce(a0, red, false);
     a1 = block_reduce(a1, red, false);
     a2 = block_reduce(a2, red, false);
-    const float invB = 1.0f / static_cast<float>(B);
+    const float invB = 1.0f / static_cast<float>(B_mean);
     float lb, gpos;
     if (loss_kind == 0) {
         lb = -logf(a0 + 1e-24f) + bpr_reg * a1;
@@ -554,12 +558,13 @@ int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_
     return SKR_OK;
 }
 
-int skr_session_loss(const float* d_out, int B, int hid, const float* d_item_table, const float* d_item_bias,
-                     const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
-                     float* d_dout, float* d_loss, void* stream) {
+static int session_loss_launch(const float* d_out, int B, int hid, const float* d_item_table, const float* d_item_bias,
+                               const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
+                               float* d_dout, float* d_loss, int pos_off, int B_mean, void* stream) {
     SKR_REQUIRE(d_out && d_item_table && d_item_bias && d_y && d_dlogits && d_dout && d_loss, "skr_session_loss: NULL argument");
     SKR_REQUIRE(hid == 32 || hid == 64 || hid == 128, "skr_session_loss: hid must be 32, 64 or 128 (got %d)", hid);
-    SKR_REQUIRE(B >= 1 && n_y >= B && n_y <= L_NY_MAX, "skr_session_loss: need B <= n_y <= %d (got %d, %d)", L_NY_MAX, B, n_y);
+    SKR_REQUIRE(B >= 1 && pos_off >= 0 && pos_off + B <= B_mean && n_y >= B_mean && n_y <= L_NY_MAX,
+                "skr_session_loss: need slots [%d, %d) inside a batch of %d <= n_y = %d <= %d", pos_off, pos_off + B, B_mean, n_y, L_NY_MAX);
     SKR_REQUIRE(final_act_kind >= 0 && final_act_kind <= 2, "There is not final_act named '%d'.", final_act_kind);
     SKR_REQUIRE(loss_kind == 0 || loss_kind == 1, "There is not loss named '%d'.", loss_kind);
     hipStream_t st = skr::as_stream(stream);
@@ -567,13 +572,27 @@ int skr_session_loss(const float* d_out, int B, int hid, const float* d_item_tab
                        d_item_bias, d_y, n_y, final_act_kind, d_dlogits);
     SKR_LAUNCH_CHECK();
     hipLaunchKernelGGL(session_rowloss_kernel, dim3(B), dim3(G_T), 0, st, B, n_y, final_act_kind, loss_kind, bpr_reg,
-                       d_dlogits, d_loss);
+                       d_dlogits, d_loss, pos_off, B_mean);
     SKR_LAUNCH_CHECK();
     SKR_HIP(hipMemsetAsync(d_dout, 0, static_cast<size_t>(B) * hid * sizeof(float), st));
     hipLaunchKernelGGL(session_dout_kernel, dim3((n_y + L_CY - 1) / L_CY, (B + L_CB - 1) / L_CB), dim3(G_T), 0, st, d_dlogits,
                        B, hid, d_item_table, d_y, n_y, d_dout);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
+}
+
+int skr_session_loss(const float* d_out, int B, int hid, const float* d_item_table, const float* d_item_bias,
+                     const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
+                     float* d_dout, float* d_loss, void* stream) {
+    return session_loss_launch(d_out, B, hid, d_item_table, d_item_bias, d_y, n_y, final_act_kind, loss_kind, bpr_reg, d_dlogits,
+                               d_dout, d_loss, 0, B, stream);
+}
+
+int skr_session_loss_sharded(const float* d_out, int B_local, int hid, const float* d_item_table, const float* d_item_bias,
+                             const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
+                             float* d_dout, float* d_loss, int slot_offset, int B_global, void* stream) {
+    return session_loss_launch(d_out, B_local, hid, d_item_table, d_item_bias, d_y, n_y, final_act_kind, loss_kind, bpr_reg,
+                               d_dlogits, d_dout, d_loss, slot_offset, B_global, stream);
 }
 
 int skr_session_out_grads(const float* d_dlogits, const float* d_out, int B, int hid, const int32_t* d_y, int n_y,
@@ -587,6 +606,41 @@ int skr_session_out_grads(const float* d_dlogits, const float* d_out, int B, int
     hipLaunchKernelGGL(session_out_grads_kernel, dim3((n_y + G_T / 64 - 1) / (G_T / 64)), dim3(G_T), 0,
                        skr::as_stream(stream), d_dlogits, d_out, B, hid, d_y, n_y, d_item_table, d_item_bias, reg, d_g_table,
                        d_g_bias, d_touch, d_touch_base);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+// popularity^alpha negatives (GRU4RecPlus.py:198-200): np.searchsorted(pop_cumsum, u) -- the first index whose cumulative
+// weight is >= u -- for n uniforms.  u comes from the host (numpy's global stream, as the reference draws it) or, with
+// d_uniform == NULL, from a counter-keyed generator on the device (splitmix64 of (seed, k): equal to the reference in law only)
+__global__ void pop_sample_kernel(const double* __restrict__ cumsum, int n_items, const double* __restrict__ uniform,
+                                  unsigned long long seed, int64_t n, int32_t* __restrict__ out) {
+    const int64_t k = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    double u;
+    if (uniform) {
+        u = uniform[k];
+    } else {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * static_cast<unsigned long long>(k + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        u = static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0);     // 53 random bits -> [0, 1)
+    }
+    int lo = 0, hi = n_items;      // lower_bound
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cumsum[mid] < u) lo = mid + 1; else hi = mid;
+    }
+    out[k] = lo;
+}
+
+int skr_pop_sample(const double* d_cumsum, int n_items, const double* d_uniform, uint64_t seed, int64_t n, int32_t* d_out,
+                   void* stream) {
+    SKR_REQUIRE(d_cumsum && d_out && n_items >= 1 && n >= 0, "skr_pop_sample: bad argument");
+    if (n == 0) return SKR_OK;
+    hipLaunchKernelGGL(pop_sample_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, skr::as_stream(stream), d_cumsum,
+                       n_items, d_uniform, static_cast<unsigned long long>(seed), n, d_out);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

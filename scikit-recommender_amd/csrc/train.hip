@@ -369,6 +369,22 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, const int32_
     if (k >= n) return;
     out[k * D + lane] = table[static_cast<int64_t>(idx[k]) * D + lane];
 }
+// any row width (the GRU4RecPlus tables: 32 / 64 / 128 floats, biases: 1): one thread per element
+__global__ void gather_rows_any_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx, int64_t n, int dim,
+                                       float* __restrict__ out) {
+    const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (e >= n * dim) return;
+    const int64_t k = e / dim;
+    out[e] = table[static_cast<int64_t>(idx[k]) * dim + (e - k * dim)];
+}
+__global__ void scatter_rows_any_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int64_t n, int dim,
+                                        float* __restrict__ table) {
+    const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (e >= n * dim) return;
+    const int64_t k = e / dim;
+    if (idx[k] < 0) return;
+    table[static_cast<int64_t>(idx[k]) * dim + (e - k * dim)] = src[e];
+}
 
 // table[idx[k]] = src[k]; negative ids are skipped; duplicate ids must carry identical rows
 __global__ void scatter_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int64_t n,
@@ -1073,20 +1089,28 @@ int skr_layer_refine_bwd(const float* d_Y, const float* d_E, const float* d_w, c
 
 int skr_gather_rows(const float* d_table, const int32_t* d_idx, int64_t n, int dim, float* d_out, void* stream) {
     SKR_REQUIRE(d_table && d_idx && d_out, "skr_gather_rows: NULL argument");
-    SKR_REQUIRE(dim == D, "skr_gather_rows: dim must be 64 (got %d)", dim);
+    SKR_REQUIRE(dim >= 1, "skr_gather_rows: dim must be positive (got %d)", dim);
     if (n <= 0) return SKR_OK;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows_to_blocks(n)), dim3(256), 0, skr::as_stream(stream), d_table, d_idx,
-                       n, d_out);
+    if (dim == D)
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(rows_to_blocks(n)), dim3(256), 0, skr::as_stream(stream), d_table, d_idx,
+                           n, d_out);
+    else
+        hipLaunchKernelGGL(gather_rows_any_kernel, dim3(static_cast<unsigned>((n * dim + 255) / 256)), dim3(256), 0,
+                           skr::as_stream(stream), d_table, d_idx, n, dim, d_out);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
 
 int skr_scatter_rows(const float* d_src, const int32_t* d_idx, int64_t n, int dim, float* d_table, void* stream) {
     SKR_REQUIRE(d_table && d_idx && d_src, "skr_scatter_rows: NULL argument");
-    SKR_REQUIRE(dim == D, "skr_scatter_rows: dim must be 64 (got %d)", dim);
+    SKR_REQUIRE(dim >= 1, "skr_scatter_rows: dim must be positive (got %d)", dim);
     if (n <= 0) return SKR_OK;
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(rows_to_blocks(n)), dim3(256), 0, skr::as_stream(stream), d_src, d_idx, n,
-                       d_table);
+    if (dim == D)
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3(rows_to_blocks(n)), dim3(256), 0, skr::as_stream(stream), d_src, d_idx, n,
+                           d_table);
+    else
+        hipLaunchKernelGGL(scatter_rows_any_kernel, dim3(static_cast<unsigned>((n * dim + 255) / 256)), dim3(256), 0,
+                           skr::as_stream(stream), d_src, d_idx, n, dim, d_table);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

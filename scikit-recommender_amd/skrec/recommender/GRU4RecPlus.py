@@ -30,7 +30,7 @@ from ..run_config import RunConfig
 from ..utils.py import EarlyStopping, ModelConfig
 from .base import AbstractRecommender, DenseAdam
 
-__all__ = ["GRU4RecPlus", "GRU4RecPlusConfig"]
+__all__ = ["GRU4RecPlus", "GRU4RecPlusConfig", "SessionGRU", "ShardedSessionGRU"]
 
 _HIDDEN = {"tanh": 0, "relu": 1}
 _FINAL = {"linear": 0, "relu": 1, "leaky_relu": 2}
@@ -194,6 +194,93 @@ class SessionGRU(object):
         return states[-1]
 
 
+class ShardedSessionGRU(SessionGRU):
+    """SessionGRU for one rank of a SESSION-SHARDED job (BASELINE configs[4]; the reference is single-process).
+
+    The b sessions that advance together (GRU4RecPlus.py:210-247) are split into world contiguous groups of b / world
+    slots; a rank runs the GRU stack, the logits and their gradients for its own slots only.  Every parameter is
+    replicated -- both item tables, the output bias, the GRU kernels -- and kept identical: a step's targets (the batch's
+    next items + the shared negatives) and inputs are the same lists on every rank (same data, same numpy stream), so the
+    ranks exchange ONE compact block per step -- the rows of dE_out / db_out for the targets, the rows of dE_in for the
+    inputs, the dense GRU gradients -- all-gather it and add the ranks' blocks in rank order (``skr_sum_blocks``), then
+    run the same dense Adam.  The l2 term of the shared target rows is added by rank 0 only."""
+
+    def __init__(self, ctx, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.ctx = ctx
+        self.opt.touch[:] = 2                 # exchanged rows arrive without touch marks: always read every gradient
+        self._cells_lo = int(self.gcells[0][0].data_ptr() - self.opt.grad.data_ptr()) // 4
+        self._xbuf = None
+
+    def slots(self, b):
+        assert b % self.ctx.world == 0, "batch_size must be a multiple of the number of ranks"
+        per = b // self.ctx.world
+        return self.ctx.rank * per, (self.ctx.rank + 1) * per
+
+    def train_step(self, x_index, y_index, states):
+        """x_index int32 [b], y_index int32 [b + n_sample]: the GLOBAL step (identical on every rank); states: this rank's
+        [b / world, h_l].  ``self.loss`` = the global mean loss afterwards."""
+        import torch.distributed as dist
+        L, st = _hip.lib(), _hip.stream()
+        b, n_y, hn = x_index.numel(), y_index.numel(), self.hids[-1]
+        lo, hi = self.slots(b)
+        bl = hi - lo
+        x_local = x_index[lo:hi].contiguous()
+        self._parity = 1 - getattr(self, "_parity", 0)
+        new_states, saved = self.forward(x_local, states, save=True, tag=f"t{self._parity}")
+        out = new_states[-1]
+        dlog, dout = self._buf("dlogits", (bl, n_y)), self._buf("dout", (bl, hn))
+        self.loss.zero_()
+        g = self.opt
+        _hip.check(L.skr_session_loss_sharded(_hip.ptr(out), bl, hn, _hip.ptr(self.E_out), _hip.ptr(self.b_out), _hip.ptr(y_index),
+                                              n_y, self.final_act, self.loss_kind, self.bpr_reg, _hip.ptr(dlog), _hip.ptr(dout),
+                                              _hip.ptr(self.loss), lo, b, st))
+        reg_y = self.reg if self.ctx.rank == 0 else 0.0
+        _hip.check(L.skr_session_out_grads(_hip.ptr(dlog), _hip.ptr(out), bl, hn, _hip.ptr(y_index), n_y,
+                                           _hip.ptr(self.E_out), _hip.ptr(self.b_out), reg_y, _hip.ptr(self.gE_out),
+                                           _hip.ptr(self.gb_out), _hip.ptr(g.touch), _hip.ptr(g.grad), st))
+        dh = dout
+        for l in range(len(self.cells) - 1, -1, -1):
+            (Wg, bg, Wc, bc), (gWg, gbg, gWc, gbc) = self.cells[l], self.gcells[l]
+            src, idx, r, u, c = saved[l]
+            i_d, h = self.dims_in[l], self.hids[l]
+            dx, work = self._buf(f"dx{l}", (bl, i_d)), self._buf(f"work{l}", (3 * bl * h,))
+            _hip.check(L.skr_gru_cell_bwd(_hip.ptr(src), _hip.ptr(idx), _hip.ptr(states[l]), bl, i_d, h, _hip.ptr(Wg),
+                                          _hip.ptr(Wc), self.hidden_act, _hip.ptr(r), _hip.ptr(u), _hip.ptr(c), _hip.ptr(dh),
+                                          _hip.ptr(gWg), _hip.ptr(gbg), _hip.ptr(gWc), _hip.ptr(gbc), _hip.ptr(dx),
+                                          _hip.ptr(work), st))
+            dh = dx
+        _hip.check(L.skr_scatter_add_rows(_hip.ptr(dh), _hip.ptr(x_local), bl, self.in_dim, _hip.ptr(self.E_in), self.reg,
+                                          _hip.ptr(self.gE_in), _hip.ptr(g.touch), _hip.ptr(g.grad), st))
+        # ---- the step's one exchange: [dE_out rows of y | db_out of y | dE_in rows of x | GRU gradients | loss]
+        world = self.ctx.world
+        n_cells = g.grad.numel() - self._cells_lo
+        sizes = (n_y * hn, n_y, b * self.in_dim, n_cells, 1)
+        total = sum(sizes)
+        if self._xbuf is None or self._xbuf.numel() != total:
+            self._xbuf = torch.empty(total, dtype=torch.float32, device=self.device)
+            self._xall = torch.empty((world, total), dtype=torch.float32, device=self.device)
+        o0, o1, o2, o3 = sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2], total - 1
+        buf = self._xbuf
+        _hip.check(L.skr_gather_rows(_hip.ptr(self.gE_out), _hip.ptr(y_index), n_y, hn, _hip.ptr(buf[:o0]), st))
+        _hip.check(L.skr_gather_rows(_hip.ptr(self.gb_out), _hip.ptr(y_index), n_y, 1, _hip.ptr(buf[o0:o1]), st))
+        _hip.check(L.skr_gather_rows(_hip.ptr(self.gE_in), _hip.ptr(x_index), b, self.in_dim, _hip.ptr(buf[o1:o2]), st))
+        buf[o2:o3].copy_(g.grad[self._cells_lo:])
+        buf[o3:].copy_(self.loss)
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(self._xall, buf)
+        else:
+            dist.all_gather([self._xall[r] for r in range(world)], buf)
+        _hip.check(L.skr_sum_blocks(_hip.ptr(self._xall), world, total, _hip.ptr(buf), st))
+        _hip.check(L.skr_scatter_rows(_hip.ptr(buf[:o0]), _hip.ptr(y_index), n_y, hn, _hip.ptr(self.gE_out), st))
+        _hip.check(L.skr_scatter_rows(_hip.ptr(buf[o0:o1]), _hip.ptr(y_index), n_y, 1, _hip.ptr(self.gb_out), st))
+        _hip.check(L.skr_scatter_rows(_hip.ptr(buf[o1:o2]), _hip.ptr(x_index), b, self.in_dim, _hip.ptr(self.gE_in), st))
+        g.grad[self._cells_lo:].copy_(buf[o2:o3])
+        self.loss.copy_(buf[o3:])
+        g.step()
+        return new_states
+
+
 class GRU4RecPlus(AbstractRecommender):
     def __init__(self, run_config: RunConfig, model_config: Dict):
         self.config = GRU4RecPlusConfig(**model_config)
@@ -217,8 +304,12 @@ class GRU4RecPlus(AbstractRecommender):
             cells.append((nn.init.xavier_uniform_(torch.empty(i_d + h, 2 * h)), torch.ones(2 * h),
                           nn.init.xavier_uniform_(torch.empty(i_d + h, h)), torch.zeros(h)))
             i_d = h
-        self.net = SessionGRU(E_in, cells, E_out, torch.zeros(self.items_num), config.hidden_act, config.final_act,
-                              config.loss, config.bpr_reg, config.reg, config.lr, self.device)
+        from ..parallel import init_from_env
+        self.dist = init_from_env()      # one process per GPU under torchrun: the b parallel sessions are split over the ranks
+        net_args = (E_in, cells, E_out, torch.zeros(self.items_num), config.hidden_act, config.final_act, config.loss,
+                    config.bpr_reg, config.reg, config.lr, self.device)
+        self.net = ShardedSessionGRU(self.dist, *net_args) if self.dist.active else SessionGRU(*net_args)
+        self._d_pop_cumsum = torch.from_numpy(np.ascontiguousarray(self.pop_cumsum, dtype=np.float64)).to(self.device)
         # histories by time as a CSR over ALL users for the inference sweep
         rowptr = np.zeros(self.users_num + 1, np.int64)
         for u, items in self.user_pos_train.items():
@@ -240,14 +331,21 @@ class GRU4RecPlus(AbstractRecommender):
         return data_ui, offset_idx
 
     def _sample_neg_items(self, size):
-        return np.searchsorted(self.pop_cumsum, np.random.rand(size))
+        """device int32 [size]: np.searchsorted(pop_cumsum, np.random.rand(size)) (GRU4RecPlus.py:198-200) -- the uniforms
+        come from numpy's global generator like the reference's, the search runs on the device (skr_pop_sample)"""
+        u = torch.from_numpy(np.random.rand(size)).to(self.device)
+        out = torch.empty(size, dtype=torch.int32, device=self.device)
+        _hip.check(_hip.lib().skr_pop_sample(_hip.ptr(self._d_pop_cumsum), self._d_pop_cumsum.numel(), _hip.ptr(u), 0, size,
+                                             _hip.ptr(out), _hip.stream()))
+        return out
 
     def train_epoch(self):
         """the session-parallel loop of GRU4RecPlus.fit (:210-247), control flow on the host as there"""
         cfg, net, dev = self.config, self.net, self.device
         offset_idx, d_items = self.offset_idx, self._d_items
         b = cfg.batch_size
-        state = net.zero_states(b)
+        lo, hi = net.slots(b) if self.dist.active else (0, b)     # this rank's share of the b parallel sessions
+        state = net.zero_states(hi - lo)
         user_idx = np.random.permutation(len(offset_idx) - 1)
         iters = np.arange(b, dtype=np.int32)
         maxiter = iters.max()
@@ -264,8 +362,7 @@ class GRU4RecPlus(AbstractRecommender):
                 out_idx = d_items[d_start + (i + 1)]
                 out_items = out_idx
                 if cfg.n_sample:
-                    neg = torch.from_numpy(self._sample_neg_items(cfg.n_sample).astype(np.int32)).to(dev)
-                    out_items = torch.cat([out_idx, neg])
+                    out_items = torch.cat([out_idx, self._sample_neg_items(cfg.n_sample)])
                 state = net.train_step(in_idx.contiguous(), out_items.contiguous(), state)
                 losses.append(net.loss.clone())
             start = start + min_len - 1
@@ -278,6 +375,7 @@ class GRU4RecPlus(AbstractRecommender):
                 iters[idx] = maxiter
                 start[idx] = offset_idx[user_idx[maxiter]]
                 end[idx] = offset_idx[user_idx[maxiter] + 1]
+            mask = mask[(mask >= lo) & (mask < hi)] - lo           # the finished sessions among this rank's slots
             if len(mask):
                 d_mask = torch.from_numpy(mask).to(dev)
                 state = [s.index_fill(0, d_mask, 0.0) for s in state]

@@ -200,3 +200,86 @@ def test_gru4recplus_fit_through_the_api(tiny_dir, monkeypatch, tmp_path):
     ue = m.cur_user_embeddings.cpu().numpy()
     want = ue[[0, 5, 9]] @ m.net.E_out.cpu().numpy().T + m.net.b_out.cpu().numpy()
     np.testing.assert_allclose(p, want, rtol=1e-4, atol=1e-5)
+
+
+def test_pop_sampler_is_numpys_searchsorted():
+    """skr_pop_sample (GRU4RecPlus.py:198-200): with the host's uniforms == np.searchsorted(pop_cumsum, u), including
+    u exactly on a boundary and u = 0; with the device generator: in range and following the popularity law"""
+    from skrec import _hip
+    L = _hip.lib()
+    rng = np.random.default_rng(3)
+    n_items = 5000
+    pop = np.power(rng.integers(1, 1000, n_items).astype(np.float64), 0.75)
+    cs = np.cumsum(pop)
+    cs = cs / cs[-1]
+    u = rng.random(4096)
+    u[:5] = [0.0, cs[0], cs[17], cs[-2], np.nextafter(1.0, 0.0)]
+    d_cs, d_u = to_dev(cs), to_dev(u)
+    out = torch.empty(len(u), dtype=torch.int32, device="cuda")
+    _hip.check(L.skr_pop_sample(_hip.ptr(d_cs), n_items, _hip.ptr(d_u), 0, len(u), _hip.ptr(out), _hip.stream()))
+    assert np.array_equal(out.cpu().numpy(), np.searchsorted(cs, u))
+    big = torch.empty(400_000, dtype=torch.int32, device="cuda")
+    _hip.check(L.skr_pop_sample(_hip.ptr(d_cs), n_items, None, 99, big.numel(), _hip.ptr(big), _hip.stream()))
+    got = big.cpu().numpy()
+    assert got.min() >= 0 and got.max() < n_items
+    freq = np.bincount(got, minlength=n_items) / len(got)
+    want = np.diff(np.concatenate([[0.0], cs]))
+    assert np.abs(freq - want).max() < 5 * np.sqrt(want.max() / len(got)) + 1e-4
+
+
+def _sharded_gru_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from skrec.parallel import DistContext
+    from skrec.recommender.GRU4RecPlus import SessionGRU, ShardedSessionGRU
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(21)
+    n_items, b, n_s, steps = 400, 24, 40, 12
+    E_in = rng.normal(0, 0.1, (n_items, 64)).astype(np.float32)
+    E_out = rng.normal(0, 0.1, (n_items, 128)).astype(np.float32)
+    cells = [_cell(rng, 64, 64), _cell(rng, 64, 128)]
+    args = (E_in, cells, E_out, np.zeros(n_items, np.float32), "tanh", "linear", "bpr_max", 1.0, 1e-3, 1e-2)
+    net = ShardedSessionGRU(DistContext(rank, world), *args) if world > 1 else SessionGRU(*args)
+    lo, hi = net.slots(b) if world > 1 else (0, b)
+    states = net.zero_states(hi - lo)
+    losses = []
+    for s in range(steps):
+        x = rng.integers(0, n_items, b).astype(np.int32)
+        y = np.concatenate([rng.integers(0, n_items, b), rng.integers(0, n_items, n_s)]).astype(np.int32)
+        y[3] = y[b + 1]                                   # a sampled negative equal to a positive
+        if s == 5:                                        # sessions 2 and 20 end: their states are reset
+            for g_ in (2, 20):
+                if lo <= g_ < hi:
+                    states = [st.index_fill(0, torch.tensor([g_ - lo], device="cuda"), 0.0) for st in states]
+        states = net.train_step(to_dev(x), to_dev(y), states)
+        losses.append(float(net.loss.cpu()))
+    torch.cuda.synchronize()
+    ret[rank] = dict(losses=np.array(losses), flat=net.flat.cpu().numpy(), lo=lo, hi=hi, state=states[-1].cpu().numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_session_sharded_steps_equal_the_single_process_steps(world):
+    """ShardedSessionGRU (row f-4, BASELINE configs[4]): the b parallel sessions split over the ranks, ONE compact exchange
+    per step (target rows of both output tables' gradients, input rows, GRU gradients, loss; all-gathered and added in rank
+    order) == the single-process steps: per-step losses, every parameter, the recurrent states; replicas bit-identical"""
+    import torch.multiprocessing as mp
+    from test_gpu_dist import _free_port
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_sharded_gru_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+        one = ret[0]
+        ret2 = mgr.dict()
+        mp.spawn(_sharded_gru_worker, args=(world, _free_port(), ret2), nprocs=world, join=True)
+        many = {k: ret2[k] for k in range(world)}
+    for r in range(world):
+        np.testing.assert_allclose(many[r]["losses"], one["losses"], rtol=2e-5)
+        # (the ranks' gradient blocks are added in another order than one process adds them, and Adam at lr = 1e-2 turns a
+        #  last-bit difference of a tiny gradient into up to ~1e-5 of a parameter)
+        np.testing.assert_allclose(many[r]["flat"], one["flat"], rtol=0, atol=3e-5)
+        np.testing.assert_allclose(many[r]["state"], one["state"][many[r]["lo"]:many[r]["hi"]], rtol=0, atol=3e-5)
+        assert np.array_equal(many[r]["flat"], many[0]["flat"])          # replicas: the same bits

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 GPU check: touched tests, the driver's default bench command, 2-rank rehearsals (gloo, one GPU) of both scaling modes
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_train.py tests/test_gpu_models.py tests/test_gpu_dist.py tests/test_gpu_fullsize.py -x -q -k "spmm or lightgcn or layergcn or dist" > gpurun_out/r2_tests4.log 2>&1; echo "tests rc=$?"
+python -m pytest tests/test_gpu_gru.py tests/test_gpu_train.py tests/test_gpu_models.py tests/test_gpu_dist.py tests/test_gpu_fullsize.py -x -q -k "gru or session or pop or spmm or lightgcn or layergcn or dist" > gpurun_out/r2_tests4.log 2>&1; echo "tests rc=$?"
 timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r2_bench_n1.json 2> gpurun_out/r2_bench_n1.err; echo "bench rc=$?"
 # (two processes time-slicing ONE GPU: side streams only add cross-queue waits there, so the rehearsal keeps everything on
 #  one stream per process; on a real node every rank has its GPU to itself)
