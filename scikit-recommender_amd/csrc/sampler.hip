@@ -964,6 +964,7 @@ struct skr_sampler {
     hipStream_t gen_stream = nullptr;       // the pieces are generated here, beside the slabs that consume them
     std::vector<hipEvent_t> gen_events;
     hipEvent_t start_event = nullptr;
+    int64_t* h_ctl = nullptr;               // pinned: the one read-back per exact-epoch call lands here
     unsigned long long* d_ev_bits = nullptr;
     unsigned long long* d_rej_bits = nullptr;
     uint32_t* d_ev_mask = nullptr;
@@ -1015,6 +1016,7 @@ int skr_sampler_destroy(skr_sampler* s) {
     if (s->gen_stream) (void)hipStreamDestroy(s->gen_stream);
     for (hipEvent_t e : s->gen_events) (void)hipEventDestroy(e);
     if (s->start_event) (void)hipEventDestroy(s->start_event);
+    if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     (void)hipFree(s->d_ev_bits);
     (void)hipFree(s->d_rej_bits);
     (void)hipFree(s->d_ev_mask);
@@ -1252,8 +1254,9 @@ static int run_exact_epoch(skr_sampler* s, int num_items, int n_users, const int
     hipLaunchKernelGGL(max_row_len_kernel, dim3(blocks), dim3(256), 0, st, d_rowptr, n_users, reinterpret_cast<int*>(s->d_ctl + SL_SCRATCH),
                        reinterpret_cast<unsigned long long*>(s->d_ctl + SL_SUMSQ));
     SKR_LAUNCH_CHECK();
-    int64_t host[SL_STATUS + 1];
-    SKR_HIP(hipMemcpyAsync(host, s->d_ctl, sizeof(host), hipMemcpyDeviceToHost, st));
+    if (!s->h_ctl) SKR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctl), (SL_STATUS + 1) * sizeof(int64_t), hipHostMallocDefault));
+    int64_t* host = s->h_ctl;
+    SKR_HIP(hipMemcpyAsync(host, s->d_ctl, (SL_STATUS + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     SKR_HIP(hipStreamSynchronize(st));
     const int max_len = static_cast<int>(host[SL_SCRATCH] & 0xffffffff);
     if (host[SL_STATUS] == 2) {
