@@ -258,7 +258,9 @@ int skr_csr_spmm(int n_rows, const int64_t* d_rowptr, const int32_t* d_col, cons
  *                         CSR pointers -- the arrays must outlive it and keep their contents -- plus a task list and a
  *                         scratch buffer of its own.  Columns must ascend within a row and be < n_cols.
  *                         long_rows_from: 0 = default (512), otherwise >= 2.
- *   skr_spmm_plan_info    h_info4 = {long rows, tasks, column blocks, long_rows_from}
+ *   skr_spmm_plan_info    h_info4 = {long rows, tasks, column blocks, long_rows_from + (column windows << 32)};
+ *                         SKR_SPMM_WINDOWS=n (default 1) makes the short-row kernel gather from X in n column windows, one
+ *                         launch each (an experiment switch: no gain measured at X = 256 MB)
  * A plan may be run any number of times, by one stream at a time (the scratch buffer is shared between runs). */
 typedef struct skr_spmm_plan skr_spmm_plan;
 int skr_spmm_plan_create(int n_rows, int n_cols, const int64_t* d_rowptr, const int32_t* d_col, const float* d_val,

@@ -283,3 +283,47 @@ def test_session_sharded_steps_equal_the_single_process_steps(world):
         np.testing.assert_allclose(many[r]["flat"], one["flat"], rtol=0, atol=3e-5)
         np.testing.assert_allclose(many[r]["state"], one["state"][many[r]["lo"]:many[r]["hi"]], rtol=0, atol=3e-5)
         assert np.array_equal(many[r]["flat"], many[0]["flat"])          # replicas: the same bits
+
+
+def test_config4_shape_steps_match_oracle():
+    """BASELINE configs[4]'s shape -- d = 128, 100 000 items, 128 parallel sessions walking 50-event histories, 2 048
+    popularity^0.75 negatives per step (skr_pop_sample on numpy's uniforms), bpr_max -- for the steps around a session
+    boundary (positions 47, 48 of one group of sessions, then 0, 1 of the next with fresh states): per-step loss, the
+    recurrent state and every touched parameter row against the torch-CPU restatement (parity unpinned, see the header)"""
+    from skrec.recommender.GRU4RecPlus import SessionGRU
+    L = _hip.lib()
+    rng = np.random.default_rng(4)
+    n_items, d, b, n_s, T = 100_000, 128, 128, 2048, 50
+    E_in = np.clip(rng.normal(0, 0.01, (n_items, d)), -0.02, 0.02).astype(np.float32)
+    E_out = np.clip(rng.normal(0, 0.01, (n_items, d)), -0.02, 0.02).astype(np.float32)
+    cells = [_cell(rng, d, d)]
+    o = G.GRU4RecOracle(E_in, cells, E_out, np.zeros(n_items, np.float32), loss="bpr_max", bpr_reg=1.0, reg=1e-5, lr=1e-3)
+    net = SessionGRU(E_in, cells, E_out, np.zeros(n_items, np.float32), loss="bpr_max", bpr_reg=1.0, reg=1e-5, lr=1e-3)
+    pop = 1.0 / np.arange(1, n_items + 1) ** 0.9
+    cs = np.cumsum(pop ** 0.75)
+    cs /= cs[-1]
+    d_cs = to_dev(cs)
+    sessions = rng.choice(n_items, (2, b, T), p=pop / pop.sum()).astype(np.int32)
+    st_o, st_d = [torch.zeros(b, d)], net.zero_states(b)
+    touched = set()
+    for blk, t in ((0, 46), (0, 47), (0, 48), (1, 0), (1, 1)):
+        if t == 0:
+            st_o, st_d = [torch.zeros(b, d)], net.zero_states(b)
+        u = rng.random(n_s)
+        neg = torch.empty(n_s, dtype=torch.int32, device="cuda")
+        _hip.check(L.skr_pop_sample(_hip.ptr(d_cs), n_items, _hip.ptr(to_dev(u)), 0, n_s, _hip.ptr(neg), _hip.stream()))
+        neg_h = neg.cpu().numpy()
+        assert np.array_equal(neg_h, np.searchsorted(cs, u))
+        X, Y = sessions[blk, :, t], np.concatenate([sessions[blk, :, t + 1], neg_h]).astype(np.int32)
+        lo, st_o = o.train_step(X, Y, st_o)
+        st_d = net.train_step(to_dev(X), to_dev(Y), st_d)
+        assert abs(float(net.loss) - lo) <= 5e-5 * abs(lo) + 1e-6, (blk, t, float(net.loss), lo)
+        _close(st_d[0].cpu().numpy(), st_o[0].numpy(), 1e-4, 1e-6)
+        touched.update(X.tolist())
+        touched.update(Y.tolist())
+    rows = np.array(sorted(touched))
+    _close(net.E_in.cpu().numpy()[rows], o.E_in.detach().numpy()[rows], 2e-4, 2e-6)
+    _close(net.E_out.cpu().numpy()[rows], o.E_out.detach().numpy()[rows], 2e-4, 2e-6)
+    _close(net.b_out.cpu().numpy()[rows], o.b_out.detach().numpy()[rows], 2e-4, 2e-6)
+    for a, w in zip(net.cells[0], o.cells[0]):
+        _close(a.cpu().numpy(), w.detach().numpy(), 2e-4, 2e-6)

@@ -152,13 +152,19 @@ def test_csr_spmm_vs_scipy(n_rows, density, heavy, plan, monkeypatch):
         assert info["long_rows"] == heavy and (info["tasks"] > 0) == (heavy > 0), info
 
 
+@pytest.mark.parametrize("windows", [None, "3"])
 @pytest.mark.parametrize("n_rows,n_cols,long_from", [(300, 40_000, 2), (1000, 70_000, 8), (64, 200_000, 100), (5000, 33_000, 0), (7, 5, 2)])
-def test_spmm_plan_rectangular_blocks_and_determinism(n_rows, n_cols, long_from):
+def test_spmm_plan_rectangular_blocks_and_determinism(n_rows, n_cols, long_from, windows, monkeypatch):
     """skr_spmm_plan_* on rectangular matrices whose long rows span several 16 384-column blocks (tasks of every length
     1..256, rows of exactly the threshold, empty rows, a row touching only the last block), with the long-row threshold
     lowered so that small cases exercise the task path; repeated runs are BIT-identical (partial rows are added in a
-    fixed order -- no float atomics), epilogues included; argument checks"""
+    fixed order -- no float atomics), epilogues included; argument checks.  windows = "3": the short rows gather from X in
+    three column windows, one launch each (what the plan does by itself when X exceeds the Infinity Cache)"""
     import ctypes as C
+    if windows:
+        monkeypatch.setenv("SKR_SPMM_WINDOWS", windows)
+    else:
+        monkeypatch.delenv("SKR_SPMM_WINDOWS", raising=False)
     import torch
     from gpu_utils import dev, to_dev
     from skrec import _hip
@@ -188,7 +194,8 @@ def test_spmm_plan_rectangular_blocks_and_determinism(n_rows, n_cols, long_from)
     info = (C.c_int64 * 4)()
     _hip.check(L.skr_spmm_plan_info(h, info))
     thr = long_from or 512
-    assert info[0] == int((lens >= thr).sum()) and info[2] == -(-n_cols // 16384) and info[3] == thr
+    assert info[0] == int((lens >= thr).sum()) and info[2] == -(-n_cols // 16384) and (info[3] & 0xffffffff) == thr
+    assert (info[3] >> 32) == (int(windows) if windows else 1)
     # tasks: one per 256 entries of every (long row, column block) segment
     want_tasks = 0
     for r in np.flatnonzero(lens >= thr):
