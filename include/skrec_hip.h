@@ -215,11 +215,15 @@ int skr_bpr_step(const float* d_P, const float* d_Q, const float* d_bias,
                  float* d_loss, uint8_t* d_touch, const float* d_touch_base, void* stream);
 /* skr_bpr_step on one rank of a user-sharded job: d_u / d_i / d_j hold a GLOBAL batch of n triples with
  * GLOBAL user ids; only the triples whose user this rank owns (u % shard_world == shard_rank) are processed, against row
- * u / shard_world of the rank's local user tables.  No selection on the host, no read-back of a count. */
+ * u / shard_world of the rank's local user tables.  No selection on the host, no read-back of a count.
+ * grad_scale multiplies the score part of the gradient only (d_gP / d_gQ / d_gb), not the loss sums nor the regulariser's
+ * gradient: LightGCN passes 1 / (n_layers + 1), the factor of the layer mean (LightGCN.py:97-99), instead of scaling the
+ * [N, 64] gradient buffer in a pass of its own. */
 int skr_bpr_step_sharded(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
                          const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n, float loss_scale, float reg,
                          float reg_scale, float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ, float* d_loss,
-                         uint8_t* d_touch, const float* d_touch_base, int shard_world, int shard_rank, void* stream);
+                         uint8_t* d_touch, const float* d_touch_base, int shard_world, int shard_rank, float grad_scale,
+                         void* stream);
 /* skr_bpr_step with the two loss sums spread over SKR_LOSS_SLOTS pairs: d_loss64 is float[2 * SKR_LOSS_SLOTS], pair q
  * receives the sums of the workgroups q, q + SKR_LOSS_SLOTS, ...; the batch's sums are the sums over the pairs.  (One
  * pair of words for all workgroups makes their atomics serialise: 4.5 us of a 10.9 us launch at batch 1024.) */
@@ -298,6 +302,7 @@ int skr_scatter_rows(const float* d_src, const int32_t* d_idx, int64_t n, int di
  * blocks added in rank order, so that every replica ends with the same bits whatever the collective library does */
 int skr_sum_blocks(const float* d_in, int n_blocks, int64_t n, float* d_out, void* stream);
 int skr_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
+int skr_scale_copy(float a, const float* d_x, float* d_y, int64_t n, void* stream);    /* y = a * x */
 int skr_scale(float a, float* d_x, int64_t n, void* stream);                 /* x *= a */
 
 /* ---------------------------------------------------------------------------------------------

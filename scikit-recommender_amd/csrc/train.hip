@@ -31,7 +31,7 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
     const int32_t* __restrict__ i_ids, const int32_t* __restrict__ j_ids, int n, float loss_scale, float reg,
     float reg_scale, float* __restrict__ gP, float* __restrict__ gQ, float* __restrict__ gb, float* __restrict__ gRP,
     float* __restrict__ gRQ, float* __restrict__ loss, uint8_t* __restrict__ touch, const float* touch_base,
-    int loss_slots, int shard_world, int shard_rank) {
+    int loss_slots, int shard_world, int shard_rank, float grad_scale) {
     __shared__ float s_loss[BPR_WAVES], s_l2[BPR_WAVES];
     // mark the 64-float gradient block that starts at `a` as touched (one lane per row is enough)
     // (a byte that is already non-zero -- 1, or the sticky 2 -- is left alone)
@@ -66,7 +66,9 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
         const float l = -(fminf(0.0f, x) - log1pf(z));
         // d/dx = -sigmoid(-x)
         const float sig_neg = (x >= 0.0f) ? z / (1.0f + z) : 1.0f / (1.0f + z);
-        const float c = -sig_neg * loss_scale;
+        // grad_scale: an extra factor on the SCORE part of the gradient only (LightGCN: dL/dE-bar enters the backward
+        // propagation as H = dL/dE-bar / (K + 1); scaling here saves a pass over the [N, 64] buffer)
+        const float c = -sig_neg * loss_scale * grad_scale;
         float sq;
         if (same_tables) {
             // BPRMF: the regulariser rows ARE the score rows -- no second read, one atomic per row for both gradient parts
@@ -409,6 +411,11 @@ __global__ void axpy_kernel(float a, const float* __restrict__ x, float* __restr
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride)
         y[i] = fmaf(a, x[i], y[i]);
+}
+
+__global__ void scale_copy_kernel(float a, const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) y[i] = a * x[i];
 }
 
 __global__ void scale_kernel(float a, float* __restrict__ x, int64_t n) {
@@ -948,7 +955,7 @@ static int bpr_step_launch(const float* d_P, const float* d_Q, const float* d_bi
                  const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n, float loss_scale, float reg,
                  float reg_scale, float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ, float* d_loss,
                  uint8_t* d_touch, const float* d_touch_base, int loss_slots, void* stream, int shard_world = 1,
-                 int shard_rank = 0) {
+                 int shard_rank = 0, float grad_scale = 1.0f) {
     SKR_REQUIRE(d_P && d_Q && d_RP && d_RQ && d_u && d_i && d_j && d_gP && d_gQ && d_gRP && d_gRQ && d_loss,
                 "skr_bpr_step: NULL argument");
     SKR_REQUIRE(shard_world >= 1 && shard_rank >= 0 && shard_rank < shard_world, "skr_bpr_step_sharded: rank %d of %d", shard_rank,
@@ -960,7 +967,7 @@ static int bpr_step_launch(const float* d_P, const float* d_Q, const float* d_bi
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bpr_step_kernel, dim3(blocks), dim3(BPR_WAVES * 64), 0, skr::as_stream(stream), d_P, d_Q, d_bias,
                        d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP, d_gRQ, d_loss,
-                       d_touch, d_touch_base, loss_slots, shard_world, shard_rank);
+                       d_touch, d_touch_base, loss_slots, shard_world, shard_rank, grad_scale);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
@@ -976,9 +983,10 @@ int skr_bpr_step(const float* d_P, const float* d_Q, const float* d_bias, const 
 int skr_bpr_step_sharded(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
                          const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n, float loss_scale, float reg,
                          float reg_scale, float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ, float* d_loss,
-                         uint8_t* d_touch, const float* d_touch_base, int shard_world, int shard_rank, void* stream) {
+                         uint8_t* d_touch, const float* d_touch_base, int shard_world, int shard_rank, float grad_scale,
+                         void* stream) {
     return bpr_step_launch(d_P, d_Q, d_bias, d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP,
-                           d_gRQ, d_loss, d_touch, d_touch_base, 1, stream, shard_world, shard_rank);
+                           d_gRQ, d_loss, d_touch, d_touch_base, 1, stream, shard_world, shard_rank, grad_scale);
 }
 
 int skr_bpr_step_spread(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
@@ -1111,6 +1119,16 @@ int skr_scatter_rows(const float* d_src, const int32_t* d_idx, int64_t n, int di
     else
         hipLaunchKernelGGL(scatter_rows_any_kernel, dim3(static_cast<unsigned>((n * dim + 255) / 256)), dim3(256), 0,
                            skr::as_stream(stream), d_src, d_idx, n, dim, d_table);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_scale_copy(float a, const float* d_x, float* d_y, int64_t n, void* stream) {
+    SKR_REQUIRE(d_x && d_y, "skr_scale_copy: NULL argument");
+    if (n <= 0) return SKR_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream), a, d_x, d_y, n);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

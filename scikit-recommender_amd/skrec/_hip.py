@@ -59,7 +59,7 @@ SIGNATURES = {
     "skr_score_matrix": (i32, [vp, vp, i32, vp, vp, i32, i32, vp, i64, vp]),
     "skr_rank_metrics": (i32, [vp, i32, i32, vp, vp, vp, C.POINTER(i32), i32, vp, vp, vp]),
     "skr_bpr_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "skr_bpr_step_sharded": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "skr_bpr_step_sharded": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "skr_bpr_step_spread": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "skr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, vp]),
     "skr_csr_spmm": (i32, [i32, vp, vp, vp, vp, i32, i64, vp, vp, vp, f32, vp]),
@@ -75,6 +75,7 @@ SIGNATURES = {
     "skr_scatter_rows": (i32, [vp, vp, i64, i32, vp, vp]),
     "skr_sum_blocks": (i32, [vp, i32, i64, vp, vp]),
     "skr_axpy": (i32, [f32, vp, vp, i64, vp]),
+    "skr_scale_copy": (i32, [f32, vp, vp, i64, vp]),
     "skr_scale": (i32, [f32, vp, i64, vp]),
 }
 

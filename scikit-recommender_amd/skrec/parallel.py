@@ -209,8 +209,7 @@ class ShardedLightGCN(object):
         layer's products are computed for those rows only and ``final`` is valid on those rows only."""
         K, nl = self.n_layers, self.n_local
         scale = 1.0 / (K + 1)
-        self.final.zero_()
-        self._axpy(scale, self.ego, self.final)
+        _hip.check(_hip.lib().skr_scale_copy(scale, _hip.ptr(self.ego), _hip.ptr(self.final), self.ego.numel(), _hip.stream()))
         fu, fi = self.final[:nl], self.final[nl:]
         xu, xi = self.ego[:nl], self.ego[nl:]
         for k in range(K):
@@ -297,10 +296,9 @@ class ShardedLightGCN(object):
             _hip.ptr(self.final[:nl]), _hip.ptr(self.final[nl:]), None, _hip.ptr(self.ego[:nl]), _hip.ptr(self.ego[nl:]),
             _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), n_global, 1.0 / n_global, self.reg, 1.0 / self.batch_size_cfg,
             _hip.ptr(gF[:nl]), _hip.ptr(gF[nl:]), None, _hip.ptr(gE[:nl]), _hip.ptr(gE[nl:]), _hip.ptr(self.loss),
-            None, None, world, rank, _hip.stream()))
+            None, None, world, rank, 1.0 / (K + 1), _hip.stream()))
         self.ctx.all_reduce(self.loss)
-        # H = dL/dfinal / (K+1); the item half is a partial sum over ranks
-        _hip.check(_hip.lib().skr_scale(1.0 / (K + 1), _hip.ptr(gF), gF.numel(), _hip.stream()))
+        # gF holds H = dL/dfinal / (K+1) (the kernel applied the factor); the item half is a partial sum over ranks
         hu, hi = gF[:nl], gF[nl:]
         if masks is not None and self.ctx.active:      # hi is zero outside the global batch's item rows: compact exchange
             self._rows_exchange_end(self._rows_exchange_begin(hi, self._batch_item_ids), self._batch_item_ids, hi)

@@ -286,8 +286,7 @@ class LightGCN(AbstractRecommender):
         those rows only."""
         K = self.config.n_layers
         scale = 1.0 / (K + 1)
-        self.final.zero_()
-        _hip.check(_hip.lib().skr_axpy(scale, _hip.ptr(self.ego), _hip.ptr(self.final), self.ego.numel(), _hip.stream()))
+        _hip.check(_hip.lib().skr_scale_copy(scale, _hip.ptr(self.ego), _hip.ptr(self.final), self.ego.numel(), _hip.stream()))
         x = self.ego
         for k in range(K):
             y = self._x[k & 1]
@@ -319,13 +318,13 @@ class LightGCN(AbstractRecommender):
         self._final_is_current = False
         gF, gE = self._g_final, self._g_ego
         gF.zero_()
-        _hip.check(_hip.lib().skr_bpr_step(
+        # the score part of the gradient is written already divided by K + 1: gF holds H = dL/dE-bar / (K + 1)
+        _hip.check(_hip.lib().skr_bpr_step_sharded(
             _hip.ptr(self.final[:nu]), _hip.ptr(self.final[nu:]), None, _hip.ptr(self.ego[:nu]), _hip.ptr(self.ego[nu:]),
             _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), n, 1.0 / n, cfg.reg, 1.0 / cfg.batch_size,
             _hip.ptr(gF[:nu]), _hip.ptr(gF[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot),
-            None, None, _hip.stream()))
-        # backward through the mean and the K propagations: dL/dE0 += sum_k (A^T)^k H, H = gF/(K+1)
-        _hip.check(_hip.lib().skr_scale(1.0 / (K + 1), _hip.ptr(gF), gF.numel(), _hip.stream()))
+            None, None, 1, 0, 1.0 / (K + 1), _hip.stream()))
+        # backward through the mean and the K propagations: dL/dE0 += sum_k (A^T)^k H
         x = gF
         for k in range(K):
             y = self._g[k & 1]
