@@ -358,6 +358,10 @@ int skr_spmm_plan_create(int n_rows, int n_cols, const int64_t* d_rowptr, const 
     p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = nnz;
     p->rowptr = d_rowptr; p->col = d_col; p->val = d_val;
     if (long_rows_from) p->long_thr = long_rows_from;
+    if (const char* e = getenv("SKR_SPMM_CBLK")) {       // tuning switch: columns per block (default 16 384 = 4 MB of X)
+        const int v = atoi(e);
+        if (v >= 256) p->cblk = v;
+    }
     p->n_blocks = (n_cols + p->cblk - 1) / p->cblk;
     *out = p;
     if (n_rows == 0 || nnz == 0 || p->n_blocks == 0) return SKR_OK;
@@ -479,6 +483,8 @@ int skr_spmm_plan_run_masked(const skr_spmm_plan* plan, const float* d_X, int di
     if (plan->n_long > 0) {
         if (plan->n_tasks > 0) {
             const int groups = (plan->n_blocks + 7) / 8;
+            // (tried: the next task's descriptor and entries requested before this task's gathers -- 1.389 vs 1.394 ms on the
+            //  item side: the gather path, not the task's fixed cost, is the limit.  profiles/r02_spmm_lab.txt, run 7)
             for (int g = 0; g < groups; ++g) {
                 if (d_col_mask)
                     hipLaunchKernelGGL(spmm_tasks_kernel<true>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
