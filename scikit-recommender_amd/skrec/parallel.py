@@ -510,8 +510,10 @@ class ShardedBPRMF(object):
         self._dense_marked = False
         self.loss = torch.zeros(2, dtype=torch.float32, device=self.device)
 
-    def _exchange_item_grads(self, n_global, il, jl):
-        """sum the [V | b] gradient over the ranks; every replica ends with bit-identical values"""
+    def _exchange_item_grads(self, n_global, il, jl, ids=None):
+        """sum the [V | b] gradient over the ranks; every replica ends with bit-identical values.  ``ids`` (int32 [1, 2 *
+        n_global], ascending then -1): the rows to exchange, if the caller has them already (train_block: the GLOBAL batch's
+        items, the same list on every rank -- rows a rank did not touch travel as zeros)"""
         world, ni = self.ctx.world, self.num_items
         opt = self.optimizer
         cap = 2 * int(n_global)          # slots per rank: a rank holds at most the whole global batch (no device read-back)
@@ -531,10 +533,11 @@ class ShardedBPRMF(object):
             self._xbuf_ids = torch.empty((1, max(cap, 1)), dtype=torch.int32, device=self.device)
             self._xbuf_pack = torch.empty((cap, 66), dtype=torch.float32, device=self.device)
             self._xbuf_gathered = torch.empty((world, cap, 66), dtype=torch.float32, device=self.device)
-        ids = self._xbuf_ids.fill_(-1)
-        n = il.numel()
-        ids[0, :n], ids[0, n:2 * n] = il, jl
-        ids = unique_padded_rows(ids)
+        if ids is None:
+            ids = self._xbuf_ids.fill_(-1)
+            n = il.numel()
+            ids[0, :n], ids[0, n:2 * n] = il, jl
+            ids = unique_padded_rows(ids)
         pack, gathered = self._xbuf_pack, self._xbuf_gathered
         L, st = _hip.lib(), _hip.stream()
         _hip.check(L.skr_pack_grad_rows(_hip.ptr(ids), cap, _hip.ptr(self._gV), _hip.ptr(self._gb), 64, _hip.ptr(pack), st))
@@ -565,17 +568,22 @@ class ShardedBPRMF(object):
             local = torch.div(mine, world, rounding_mode="floor").int() if world > 1 else mine
             self.optimizer.begin_block(torch.cat([local, ib + nl, jb + nl, (ib >> 6) + (nl + ni), (jb >> 6) + (nl + ni)]), kk)
         if world > 1 and all(b - a == bsz for a, b in bounds):
-            # this rank's triples of every batch of the block, compacted to the front of each row in ONE pass: one
-            # read-back of the k counts per block instead of a boolean-mask selection (a host synchronisation) per step
+            # the whole GLOBAL batch goes to the kernel, which keeps the triples of the users this rank owns
+            # (skr_bpr_step_sharded): no selection, no compaction, no count read back.  The rows to exchange are the global
+            # batch's items -- the same list on every rank, made unique for all k steps of the block in one call
             U, I, J = ub.view(kk, bsz), ib.view(kk, bsz), jb.view(kk, bsz)
-            mine = (U % world) == rank
-            order = torch.argsort((~mine).to(torch.uint8), dim=1, stable=True)
-            Ul = torch.gather(torch.div(U, world, rounding_mode="floor").int(), 1, order).contiguous()
-            Il, Jl = torch.gather(I, 1, order).contiguous(), torch.gather(J, 1, order).contiguous()
-            counts = mine.sum(1).tolist()
+            step_ids = unique_padded_rows(torch.cat([I, J], dim=1))
+            opt = self.optimizer
             for k in range(kk):
-                c = counts[k]
-                self._step_local(Ul[k, :c], Il[k, :c], Jl[k, :c], bsz)
+                self.loss.zero_()
+                _hip.check(_hip.lib().skr_bpr_step_sharded(
+                    _hip.ptr(self.user_rows), _hip.ptr(self.item_rows), _hip.ptr(self.item_bias), _hip.ptr(self.user_rows),
+                    _hip.ptr(self.item_rows), _hip.ptr(U[k]), _hip.ptr(I[k]), _hip.ptr(J[k]), bsz, 1.0, self.reg, 1.0,
+                    _hip.ptr(self._gU), _hip.ptr(self._gV), _hip.ptr(self._gb), _hip.ptr(self._gU), _hip.ptr(self._gV),
+                    _hip.ptr(self.loss), _hip.ptr(opt.touch), _hip.ptr(opt.grad) if opt.touch is not None else None,
+                    world, rank, 1.0, _hip.stream()))
+                self._exchange_item_grads(bsz, None, None, ids=step_ids[k:k + 1])
+                self.ctx.all_reduce(self.loss)
                 loss_out[k] = self.loss
                 self.optimizer.hot_step()
         else:
