@@ -211,6 +211,10 @@ def lightgcn_leg(args, world, rank, dev, dist, full, K, W, cpu_baseline):
         t_step, cores, sample = CB.time_lightgcn_layer(adj.rowptr.cpu().numpy(), adj.col.cpu().numpy(), adj.val.cpu().numpy(), nU + nI, D)
         del adj
         leg["cpu_baseline"] = {"value": b / t_step, "unit": "train interactions/s", "cores": cores, "kind": "port", "sample": sample}
+        leg["speedup_vs_cpu_baseline"] = leg["value"] / leg["cpu_baseline"]["value"]
+    steps_per_epoch = -(-n_inter_total // gb)
+    leg["epoch"] = {"steps": steps_per_epoch, "seconds_estimated": steps_per_epoch * dt / K,
+                    "note": "steps per epoch x the measured time per step (every step is the same full-graph work)"}
     del eng
     torch.cuda.empty_cache()
     return leg

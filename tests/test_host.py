@@ -242,3 +242,26 @@ def test_device_shuffle_bijection_on_the_host(n):
         assert ((H - exp) ** 2 / exp).sum() / 255 < 2.0           # chi-square per degree of freedom ~ 1
     assert L.skr_shuffle_permutation_host(1, 5, 6, a.ctypes.data) == -1
     assert L.skr_shuffle_permutation_host(1, 1 << 31, 1, a.ctypes.data) == -1
+
+
+def test_bench_roofline_arithmetic():
+    """bench.py's roofline entry of the blocked cold pass is plain arithmetic on the HIP-event times it is given: the
+    mean over EVERY launch, the mean number of optimiser steps the launches applied, 20 B per cold parameter, and the
+    by-traffic figure from the recorded counter bytes -- the numbers a reader re-derives from profiles/"""
+    import importlib
+    bench = importlib.import_module("bench")
+    cold = [(0.50, 32, "pre")] * 6 + [(0.40, 32, "warmup")] + [(0.30, 20, "timed")]
+    n_par, hot = 70_500_000, 5000
+    r = bench.cold_roofline(n_par, hot, 32, cold, 0.39, True, 0.9e9, "profiles/x.json (recorded; command: y)")
+    ms = (6 * 0.50 + 0.40 + 0.30) / 8
+    assert r["launches_averaged"] == 8 and abs(r["avg_launch_ms"] - ms) < 1e-12
+    assert abs(r["optimizer_steps_per_launch"] - (7 * 32 + 20) / 8) < 1e-12
+    cold_bytes = (n_par - 64 * hot) * 20.0
+    assert r["algorithmic_bytes_per_launch"] == cold_bytes
+    assert abs(r["achieved"] - cold_bytes / (ms * 1e-3) / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert abs(r["achieved_by_traffic"] - 0.9e9 / (ms * 1e-3) / 1e9) < 1e-6 and r["traffic_source"].startswith("profiles/")
+    assert r["launches_by_phase"] == {"pre": 6, "warmup": 1, "timed": 1} and r["full_k_launches"] == 7
+    assert r["timed_region_launches"] == [{"ms": 0.30, "optimizer_steps": 20}]
+    assert abs(r["alone"]["achieved"] - cold_bytes / 0.39e-3 / 1e9) < 1e-6
+    r2 = bench.cold_roofline(n_par, hot, 32, cold, None, True, None, "x")
+    assert r2["traffic"] is None and r2["achieved_by_traffic"] is None and r2["traffic_source"] is None and "alone" not in r2
