@@ -389,64 +389,85 @@ class ShardedLayerGCN(object):
     def _axpy(self, a, x, y):
         _hip.check(_hip.lib().skr_axpy(float(a), _hip.ptr(x), _hip.ptr(y), x.numel(), _hip.stream()))
 
-    def propagate(self, train=False):
-        """out = sum_k  w_k * (A X_k),  w_k = cos(A X_k, E0) row-wise,  X_{k+1} = w_k * (A X_k)"""
+    def propagate(self, train=False, last_rows=None):
+        """out = sum_k  w_k * (A X_k),  w_k = cos(A X_k, E0) row-wise,  X_{k+1} = w_k * (A X_k).
+        ``last_rows`` = (uint8 [n_local], uint8 [I]) during training: the rows of ``out`` that will be read; the LAST layer's
+        products are computed (and, item side, exchanged -- compactly) for those rows only.  The rows left out keep older,
+        finite values in y / w / out; nothing reads ``out`` there and their dL/d out is zero."""
         L, st, nl = _hip.lib(), _hip.stream(), self.n_local
         a_ui, a_iu = self.train_blocks if train else self.full_blocks
         n = self.ego.shape[0]
         self.out.zero_()
         x = self.ego
-        for k in range(self.n_layers):
+        K = self.n_layers
+        for k in range(K):
             y = self._y[k]
-            a_ui.spmm(x[nl:], y[:nl])
-            a_iu.spmm(x[:nl], y[nl:])
-            self.ctx.all_reduce(y[nl:])
+            mu, mi = last_rows if (last_rows is not None and k == K - 1) else (None, None)
+            a_iu.spmm(x[:nl], y[nl:], row_mask=mi)                # partial items <- local users
+            # the exchange of this layer runs beside the user-side product
+            compact = self._batch_item_ids if (mi is not None and self.ctx.active) else None
+            if compact is not None:
+                work = ShardedLightGCN._rows_exchange_begin(self, y[nl:], compact)
+            else:
+                work = self.ctx.all_reduce_begin(y[nl:])
+            a_ui.spmm(x[nl:], y[:nl], row_mask=mu)                # local users <- replicated items
+            if compact is not None:
+                ShardedLightGCN._rows_exchange_end(self, work, compact, y[nl:])
+            else:
+                self.ctx.all_reduce_end(work)
             zk = self._z[k & 1]
             _hip.check(L.skr_layer_refine_fwd(_hip.ptr(y), _hip.ptr(self.ego), n, 64, _hip.ptr(zk), _hip.ptr(self._w[k]),
                                               _hip.ptr(self.out), st))
             x = zk
         return self.out
 
+    _batch_rows = ShardedLightGCN._batch_rows
+
     def train_step(self, users, pos, neg):
-        """global batch in, identical on every rank; ``self.loss`` = global (bpr sum, l2) afterwards"""
+        """global batch in (global user ids, identical on every rank); ``self.loss`` = global (bpr sum, l2) afterwards"""
         L, st = _hip.lib(), _hip.stream()
         nl, world, rank, K = self.n_local, self.ctx.world, self.ctx.rank, self.n_layers
         n = self.ego.shape[0]
-        if world > 1:
-            sel = (users % world) == rank
-            ul = torch.div(users[sel], world, rounding_mode="floor").int().contiguous()
-            il, jl = pos[sel].contiguous(), neg[sel].contiguous()
-        else:
-            ul, il, jl = users.contiguous(), pos.contiguous(), neg.contiguous()
+        users, pos, neg = users.contiguous(), pos.contiguous(), neg.contiguous()
         a_ui, a_iu = self.train_blocks
-        self.propagate(train=True)
+        # not computed: rows of the last layer's product the batch does not read and, in the first backward hop, the
+        # products with rows of dY_K that are zero (as in the one-GPU engine, recommender/LayerGCN.py train_step)
+        masks = None if os.environ.get("SKR_LIGHTGCN_DENSE") == "1" else self._batch_rows(users, pos, neg)
+        self.propagate(train=True, last_rows=masks)
         gO, gE = self._g_out, self._g_ego
         gO.zero_()
         self.loss.zero_()
-        if ul.numel() > 0:
-            _hip.check(L.skr_bpr_step(
-                _hip.ptr(self.out[:nl]), _hip.ptr(self.out[nl:]), None, _hip.ptr(self.ego[:nl]), _hip.ptr(self.ego[nl:]),
-                _hip.ptr(ul), _hip.ptr(il), _hip.ptr(jl), ul.numel(), 1.0, self.reg, 1.0,
-                _hip.ptr(gO[:nl]), _hip.ptr(gO[nl:]), None, _hip.ptr(gE[:nl]), _hip.ptr(gE[nl:]), _hip.ptr(self.loss),
-                None, None, st))
+        # the whole GLOBAL batch goes to the kernel, which keeps the triples of the users this rank owns
+        _hip.check(L.skr_bpr_step_sharded(
+            _hip.ptr(self.out[:nl]), _hip.ptr(self.out[nl:]), None, _hip.ptr(self.ego[:nl]), _hip.ptr(self.ego[nl:]),
+            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), 1.0, self.reg, 1.0,
+            _hip.ptr(gO[:nl]), _hip.ptr(gO[nl:]), None, _hip.ptr(gE[:nl]), _hip.ptr(gE[nl:]), _hip.ptr(self.loss),
+            None, None, world, rank, 1.0, st))
         self.ctx.all_reduce(self.loss)
-        self.ctx.all_reduce(gO[nl:])          # dL/d out, item rows: now the full value everywhere
-        self.ctx.all_reduce(gE[nl:])          # the regulariser's part of the item gradient
+        if masks is not None and self.ctx.active:
+            # both item-side blocks are zero outside the global batch's item rows: compact exchanges
+            ids = self._batch_item_ids
+            ShardedLightGCN._rows_exchange_end(self, ShardedLightGCN._rows_exchange_begin(self, gO[nl:], ids), ids, gO[nl:])
+            ShardedLightGCN._rows_exchange_end(self, ShardedLightGCN._rows_exchange_begin(self, gE[nl:], ids), ids, gE[nl:])
+        else:
+            self.ctx.all_reduce(gO[nl:])          # dL/d out, item rows: now the full value everywhere
+            self.ctx.all_reduce(gE[nl:])          # the regulariser's part of the item gradient
         dz = gO
         dy, tmp = self._t
         for k in range(K - 1, -1, -1):
             _hip.check(L.skr_layer_refine_bwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), _hip.ptr(self._w[k]),
                                               _hip.ptr(dz), n, 64, _hip.ptr(dy), _hip.ptr(gE), st))
+            cu, ci = masks if (masks is not None and k == K - 1) else (None, None)
+            a_iu.spmm(dy[:nl], tmp[nl:], col_mask=cu)            # item side first, its exchange beside the user side
+            work = self.ctx.all_reduce_begin(tmp[nl:])
             if k > 0:
-                a_ui.spmm(dy[nl:], tmp[:nl], addend=gO[:nl])
-                a_iu.spmm(dy[:nl], tmp[nl:])
-                self.ctx.all_reduce(tmp[nl:])
+                a_ui.spmm(dy[nl:], tmp[:nl], addend=gO[:nl], col_mask=ci)
+                self.ctx.all_reduce_end(work)
                 self._axpy(1.0, gO[nl:], tmp[nl:])
                 dz = tmp
             else:
-                a_ui.spmm(dy[nl:], tmp[:nl], accum=gE[:nl], accum_scale=1.0)
-                a_iu.spmm(dy[:nl], tmp[nl:])
-                self.ctx.all_reduce(tmp[nl:])
+                a_ui.spmm(dy[nl:], tmp[:nl], accum=gE[:nl], accum_scale=1.0, col_mask=ci)
+                self.ctx.all_reduce_end(work)
                 self._axpy(1.0, tmp[nl:], gE[nl:])
         self.optimizer.step()
 

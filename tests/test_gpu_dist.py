@@ -69,8 +69,11 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_lightgcn_replays_reference(world):
+@pytest.mark.parametrize("world,plan", [(1, "auto"), (2, "auto"), (2, "1"), (3, "1")])
+def test_sharded_lightgcn_replays_reference(world, plan, monkeypatch):
+    """plan "1": the SpMM plan (row / column masks honoured, compact exchanges of exactly the batch's rows) although the
+    graph is tiny; "auto": the plan-free kernel, which computes whole products"""
+    monkeypatch.setenv("SKR_SPMM_PLAN", plan)        # the spawned ranks inherit it
     g = np.load(os.path.join(GOLDEN, "golden_lightgcn.npz"))
     with mp.Manager() as mgr:
         ret = mgr.dict()
@@ -253,10 +256,12 @@ def _layergcn_worker(rank, world, port, data_dir, workdir, dropout, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_layergcn_fit_under_torchrun_contract(world, tiny_dir, tmp_path):
-    """LayerGCN.fit() on N ranks (user-sharded rows, replicated item rows, 2K+2 all-reduces per step)
-    == the reference's single-process run"""
+@pytest.mark.parametrize("world,plan", [(2, "auto"), (2, "1"), (3, "1")])
+def test_layergcn_fit_under_torchrun_contract(world, plan, tiny_dir, tmp_path, monkeypatch):
+    """LayerGCN.fit() on N ranks (user-sharded rows, replicated item rows, one exchange per layer and direction beside the
+    user-side product, compact in the masked layer) == the reference's single-process run; plan "1" forces the SpMM plan
+    (masks honoured) on the tiny graph"""
+    monkeypatch.setenv("SKR_SPMM_PLAN", plan)
     g = np.load(os.path.join(GOLDEN, "golden_layergcn.npz"))
     with mp.Manager() as mgr:
         ret = mgr.dict()
@@ -273,10 +278,12 @@ def test_layergcn_fit_under_torchrun_contract(world, tiny_dir, tmp_path):
     assert np.array_equal(res[0]["V1"], res[1]["V1"]) and np.array_equal(res[0]["reports"], res[world - 1]["reports"])
 
 
-def test_layergcn_sharded_edge_dropout(tiny_dir, tmp_path):
+@pytest.mark.parametrize("plan", ["auto", "1"])
+def test_layergcn_sharded_edge_dropout(plan, tiny_dir, tmp_path, monkeypatch):
     """dropout > 0 on two ranks: every rank prunes the SAME edges (rank 0's draw), so the replicas of the
     item table stay bit-identical and the kept-edge counts add up to int(E * (1 - dropout))"""
     world = 2
+    monkeypatch.setenv("SKR_SPMM_PLAN", plan)
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_layergcn_worker, args=(world, _free_port(), tiny_dir, str(tmp_path), 0.25, ret), nprocs=world, join=True)
