@@ -780,7 +780,16 @@ def main():
                 # step names the rows of its own batch and of the next one
                 ub, bi, bj = uu[lo:hi].view(kk, b), ii[lo:hi].view(kk, b), jj[lo:hi].view(kk, b)
                 return torch.cat([ub, bi + nU, bj + nU, (bi >> 6) + (nU + nI), (bj >> 6) + (nU + nI)], dim=1).reshape(-1)
-            if world == 1:   # every full block of the slice in one vectorised op (as BPRMF.train_epoch does)
+            def fused_plan(q, lo_, kk_):
+                if f_used[q]:
+                    f_plan_stream.wait_event(f_ev_done[q])      # the set's previous block has run
+                rc0 = L.skr_bpr_fused_plan(pu + 4 * lo_, pi + 4 * lo_, pj + 4 * lo_, b, kk_, 0, nU, nU + nI, (n_par + 63) // 64,
+                                           f_scratch.data_ptr(), f_meta[q].data_ptr(), f_sb[q].data_ptr(), f_sf[q].data_ptr(),
+                                           f_ns[q].data_ptr(), f_plan_stream.cuda_stream)
+                if rc0:
+                    _hip.check(rc0)
+                f_ev_plan[q].record(f_plan_stream)
+            if world == 1 and not fused:   # every full block of the slice in one vectorised op
                 nfull = n_steps // kblk
                 blk_all = block_ids(0, nfull * kblk * b, nfull * kblk).view(nfull, kblk * 5 * b)
             for s0 in range(0, n_steps, kblk):
@@ -808,6 +817,18 @@ def main():
                         blk = torch.cat([uu[lo:hi].view(kk, b), torch.where(every < 0, every, every + nU),
                                          torch.where(every < 0, every, (every >> 6) + (nU + nI))], dim=1).view(-1)
                         per = b + 4 * world * b
+                elif fused:
+                    # ONE launch per step (csrc/train.hip K2c, what BPRMF.train_epoch does at N = 1): the references' words of
+                    # the block first (four small launches); its slot table doubles as the list of hot blocks to tag
+                    # -- on a stream of their own, one block ahead, in two sets of buffers
+                    q = (s0 // kblk) & 1
+                    if s0 == 0:
+                        f_plan_stream.wait_stream(torch.cuda.current_stream())      # the columns come from the current stream
+                        fused_plan(q, lo, kk)
+                    if s0 + kblk < n_steps:
+                        fused_plan(q ^ 1, hi, min(kblk, n_steps - s0 - kblk))
+                    torch.cuda.current_stream().wait_event(f_ev_plan[q])
+                    blk = f_sb[q, :kk * 5 * b]
                 else:
                     blk = blk_all[s0 // kblk] if s0 // kblk < blk_all.shape[0] else block_ids(lo, hi, kk)
                     per = 5 * b
@@ -834,7 +855,18 @@ def main():
                     cold_log.append((pair, kk, phase))
                 ev_cold.record(side)
                 pblk, nblk = blk.data_ptr(), blk.numel()
-                for s in range(s0, s0 + kk):
+                if fused:
+                    for s in range(s0, s0 + kk):
+                        o = s * b * 4
+                        rc |= L.skr_bpr_fused_step(P["flat"], P["m1"], P["m2"], n_par, f_work.data_ptr(), f_cap, pu + o, pi + o, pj + o,
+                                                   f_meta[q].data_ptr() + 20 * (s - s0) * b, b, 0, nU, nU + nI, 1e-3, 0.9, 0.999, 1e-8,
+                                                   t0, kk, s - s0, 1e-3, P["loss"], stream)
+                    run_slice.t += kk
+                    rc |= L.skr_bpr_fused_end(P["flat"], P["m1"], P["m2"], n_par, f_work.data_ptr(), f_cap, f_sb[q].data_ptr(),
+                                              f_sf[q].data_ptr(), f_ns[q].data_ptr(), 1e-3, 0.9, 0.999, 1e-8, t0, kk, stream)
+                    f_ev_done[q].record(torch.cuda.current_stream())
+                    f_used[q] = True
+                for s in range(s0, s0 + kk) if not fused else ():
                     o = s * b * 4
                     rc |= L.skr_bpr_step_spread(P["U"], P["V"], P["bias"], P["U"], P["V"], pu + o, pi + o, pj + o, b, 1.0, 1e-3, 1.0,
                                          P["gU"], P["gV"], P["gb"], P["gU"], P["gV"], P["loss"], None, None, stream)
@@ -896,7 +928,17 @@ def main():
             step_events.extend(ev)
     n_user_par = nU * D
     # SKR_ADAM_BLOCK = k (default 32 = the most; N > 1 needs the sparse exchange): look k batches ahead and block the dense Adam; 1 = classic
-    kblk = max(1, min(32, int(os.environ.get("SKR_ADAM_BLOCK", "32")))) if (world == 1 or exchange == "sparse") else 1
+    kblk = max(1, min(64, int(os.environ.get("SKR_ADAM_BLOCK", "32")))) if (world == 1 or exchange == "sparse") else 1
+    # N = 1: the BPR batch and the hot rows' Adam in one launch per step (SKR_BPR_FUSED=0: two dependent launches)
+    fused = world == 1 and kblk > 1 and os.environ.get("SKR_BPR_FUSED", "1") != "0"
+    if fused:
+        f_cap = kblk * 5 * b
+        f_work = torch.zeros(9 * f_cap * 64, device=dev)
+        f_meta, f_sb, f_sf = (torch.empty((2, f_cap), dtype=torch.int32, device=dev) for _ in range(3))
+        f_ns = torch.zeros((2, 1), dtype=torch.int32, device=dev)
+        f_plan_stream = torch.cuda.Stream(device=dev)
+        f_ev_plan, f_ev_done, f_used = [torch.cuda.Event(), torch.cuda.Event()], [torch.cuda.Event(), torch.cuda.Event()], [False, False]
+        f_scratch = torch.zeros(28 * ((n_par + 63) // 64) // 8 + 1, dtype=torch.int64, device=dev)
     blk_tag = torch.zeros((n_par + 63) // 64, dtype=torch.int32, device=dev)
     blk_claim = torch.zeros_like(blk_tag)
     keep_alive = []
@@ -1048,7 +1090,10 @@ def main():
                                f"{args.interactions}-interaction (MovieLens-shaped), exact-stream sampler + fused BPR "
                                f"step + dense Adam; eval = fused MFMA top-{args.top_k}",
                    "users": args.users, "items": args.items, "train_interactions": n_inter_total,
-                   "batch_per_gpu": b, "global_batch": b * world, "sharding": f"users u%{world}, item table replicated"
+                   "batch_per_gpu": b, "global_batch": b * world,
+                   "step_launches": ("1: skr_bpr_fused_step (BPR batch + the touched rows' Adam, evaluated lazily; bit-identical)" if fused
+                                     else "2: skr_bpr_step_spread + skr_adam_block_hot" if kblk > 1 else "2: skr_bpr_step_spread + skr_adam_step"),
+                   "sharding": f"users u%{world}, item table replicated"
                    + ({"sparse": f" + RCCL all-gather of the touched item-gradient rows per step ({2 * b * 66 * 4 / 1e6:.2f} MB per rank)",
                        "dense": " + RCCL all-reduce of the dense item gradient per step (26 MB)", "none": ""}[exchange])},
     }

@@ -337,7 +337,7 @@ int skr_host_permutation(uint32_t* h_key624, int* h_pos, int64_t n, int32_t* h_o
  *                         once per id list: user rows offset 0 stride 64, item rows offset U*64, bias offset
  *                         (U+I)*64 stride 1).  step_t0 = optimiser steps taken before the k-step block.
  *   skr_adam_block_cold   steps step_t0+1 .. step_t0+k with zero gradient on every block whose tag != hot_value
- *   skr_adam_block_hot    ADVANCES the blocks the ids name to step_t (step_t0 < step_t <= step_t0 + 32): a block that
+ *   skr_adam_block_hot    ADVANCES the blocks the ids name to step_t (step_t0 < step_t <= step_t0 + 64): a block that
  *                         d_claim says is at step c gets zero-gradient updates for steps c+1 .. step_t-1 and then
  *                         step_t's update with its accumulated gradient, which is read and cleared; d_claim becomes
  *                         step_t (duplicate ids: one wavefront wins).  Either name every hot block at every step, or
@@ -353,6 +353,40 @@ int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr,
 int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
                        float eps, int64_t step_t0, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
                        int stride_floats, int32_t* d_claim, void* stream);
+
+/* One training step of BPRMF in ONE launch: skr_bpr_step (score rows == regulariser rows, loss_scale 1) and the hot rows'
+ * part of the blocked dense Adam together, for a k-step block whose batches are known (replaces, per step, the pair
+ * skr_bpr_step_spread + skr_adam_block_hot; BPRMF.py:108-127).  Hot rows are evaluated lazily: the wavefronts that read a
+ * row first apply, in registers, the updates the row is behind (its pending gradient of the previous naming, then
+ * zero-gradient updates -- the arithmetic of skr_adam_step, bit for bit), and a step's gradient waits in the block's
+ * workspace until the row is named again or the block ends.  Per reference (step, row) the caller supplies one word
+ *   d_meta[r * n_batch + b], r = 0..4: user row, positive item row, negative item row, the 64-word bias block of the
+ *   positive item, of the negative item;   bits 0-19 slot of the row in the block's workspace (dense numbering 0 .. n_slots-1),
+ *   bits 20-22 (number of EARLIER steps of the block that name the row) mod 6, bit 23 set on exactly one reference per
+ *   (step, row), bits 24-30 1 + the step of the previous naming (0: none), bit 31 set when the reference is the only one
+ *   of its (step, row) pair (its gradient is then stored, not added atomically)
+ * -- skr_bpr_fused_plan writes them, and the slot tables of skr_bpr_fused_end, for the k batches of a block (d_u / d_i / d_j:
+ * k * n_batch entries, step-major) in four small launches:  d_scratch = 28 * n_flat_blocks bytes, 8-byte aligned, ZERO before
+ * the first call and left usable by every call (n_flat_blocks = ceil(n / 64));  d_meta int32[k * 5 * n_batch];
+ * d_slot_block / d_slot_fin int32[k * 5 * n_batch] (d_slot_block: -1 beyond n_slots -- a valid id list for
+ * skr_adam_block_mark);  d_n_slots int32[1].  Which slot a row gets may differ between calls; nothing depends on it.
+ *   d_work   float[9 * cap * 64], ZERO before the first block and left as skr_bpr_fused_end leaves it; cap >= n_slots
+ *   *_block0 index (in 64-float blocks of the flat buffer d_p) of user row 0, item row 0, bias word 0
+ *   s        the step inside the block (0 .. k-1); the k launches of a block are followed by ONE skr_bpr_fused_end, which
+ *            brings every slot (d_slot_block[slot] = its block of the flat buffer, d_slot_fin[slot] = (number of namings
+ *            mod 6) | (step of the last naming << 8), *d_n_slots on the device) to step step_t0 + k and writes it back.
+ * The cold blocks of the k-step block are skr_adam_block_cold's as before (tags from skr_adam_block_mark).
+ * d_loss64: as skr_bpr_step_spread.  1 <= k <= 64. */
+int skr_bpr_fused_plan(const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n_batch, int k, int64_t user_block0,
+                       int64_t item_block0, int64_t bias_block0, int64_t n_flat_blocks, void* d_scratch, int32_t* d_meta,
+                       int32_t* d_slot_block, int32_t* d_slot_fin, int32_t* d_n_slots, void* stream);
+int skr_bpr_fused_step(const float* d_p, const float* d_m, const float* d_v, int64_t n, float* d_work, int64_t cap,
+                       const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch,
+                       int64_t user_block0, int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2,
+                       float eps, int64_t step_t0, int k, int s, float reg, float* d_loss64, void* stream);
+int skr_bpr_fused_end(float* d_p, float* d_m, float* d_v, int64_t n, float* d_work, int64_t cap, const int32_t* d_slot_block,
+                      const int32_t* d_slot_fin, const int32_t* d_n_slots, float lr, float beta1, float beta2, float eps,
+                      int64_t step_t0, int k, void* stream);
 
 /* The cold pass sorts each 64-float block, by the values it starts from, into one of three exact evaluations of
  * the same k updates: AT REST (the update provably rounds to p + q == p for all k steps: only the moments decay),

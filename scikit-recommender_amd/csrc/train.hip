@@ -436,7 +436,7 @@ inline unsigned rows_to_blocks(int64_t n_rows) { return static_cast<unsigned>((n
 // Every parameter still receives every update, in the same arithmetic: results are bit-identical to calling
 // skr_adam_step after every step (tests/test_gpu_train.py::test_blocked_adam_is_bit_identical).
 // ------------------------------------------------------------------------------------------------
-constexpr int AB_KMAX = 32;
+constexpr int AB_KMAX = 64;
 struct AdamBlockArgs {
     float one_minus_b1, b2, one_minus_b2, eps;
     float neg_step_size[AB_KMAX], bc2_sqrt[AB_KMAX];
@@ -818,6 +818,320 @@ __global__ __launch_bounds__(256) void adam_hot_kernel(float* __restrict__ p, fl
     }
     // a row named only because the NEXT batch reads it has no gradient yet: nothing to clear
     if (__builtin_amdgcn_ballot_w64(gg != 0.0f) != 0 && i < n) g[i] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2c: the BPR batch and the hot rows' Adam in ONE launch per step (single GPU).
+//
+// With bpr_step_kernel + adam_hot_kernel a training step is a chain of two dependent launches (6-8 us + 13 us): the
+// gradient of batch t must be complete before any row moves, and batch t+1 reads rows that step t moved.  The chain is
+// cut to one launch by evaluating the hot rows LAZILY: a row is advanced when a batch reads it, by the wavefronts that
+// read it, and a gradient is applied at the row's NEXT naming (or by the block's end launch).  The batches of a k-step
+// block are known in advance, so for every reference (step s, row r) the host precomputes (skrec/recommender/fused.py)
+//     slot   the row's index in the block's compact workspace
+//     n0     how many earlier steps of the block named the row (0-based naming index), modulo 6
+//     prev   the step of the previous naming (or none)
+//     owner  exactly one reference per (step, row) pair
+// The row's state before step s:  n0 == 0: the dense tables (no step of the block has touched it);  n0 > 0: workspace copy
+// n0 & 1, valid through optimiser index prev - 1, plus the gradient of step `prev` waiting in gradient buffer (n0 - 1) % 3.
+// Every wavefront that reads the row applies, in registers, index `prev` with that gradient and the zero-gradient indices
+// prev + 1 .. s - 1 -- the updates the dense optimiser makes, in its arithmetic (adam_elem and the at-rest / ordinary
+// evaluations of the cold pass, which give the same bits) -- and uses the result for its scores.  The pair's OWNER also
+// writes it to copy (n0 + 1) & 1 and clears gradient buffer (n0 + 1) % 3; all of them add this step's gradient into buffer
+// n0 % 3.  Within one launch nobody writes what another wavefront reads: two state copies and three gradient buffers keep
+// readers, the writer and the accumulators apart, so no wavefront waits for another and no hand-off crosses the L2s.
+// bpr_fused_end_kernel brings every slot to the block's last index and writes it back to the dense tables.
+// Same updates of every parameter in the same order and arithmetic as one dense Adam launch per step
+// (tests/test_gpu_train.py::test_fused_step_is_bit_identical).
+// ------------------------------------------------------------------------------------------------
+constexpr int FUSED_SLOT_BITS = 20;
+
+struct FusedRow {
+    float p, m, v, g;
+};
+
+// A run of zero-gradient updates of one row of ordinary magnitudes, indices [s, s_to).  The quotient of update s depends on
+// m_s and v_s only -- not on p -- so the square-root / division chains of consecutive updates are independent of each other:
+// four of them are laid side by side (one wavefront alone on its SIMD otherwise waits out the latency of every one of the
+// ~25 dependent instructions of a chain: ~200 cycles per update instead of ~70), and p takes the quotients in order -- the
+// same operations on the same values as update after update.
+template <bool UNIT_BC2>
+__device__ __forceinline__ void ordinary_run(float& p, float& m, float& v, const AdamBlockArgs& a, int& s, int s_to) {
+    for (; s + 4 <= s_to; s += 4) {
+        float ms[4], vs[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m = m + a.one_minus_b1 * (0.0f - m);
+            v = v * a.b2;
+            ms[u] = m;
+            vs[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float sq = sqrt_ordinary(vs[u]);
+            if (!UNIT_BC2) sq = div_ordinary(sq, a.bc2_sqrt[s + u]);
+            q[u] = div_ordinary(a.neg_step_size[s + u] * ms[u], sq + a.eps);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p = p + q[u];
+    }
+    for (; s < s_to; ++s) {
+        AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
+        adam_one_ordinary<UNIT_BC2>(p, m, v, one);
+    }
+}
+
+// zero-gradient indices [s_from, s_to) and, before them, index g_idx with gradient r.g (g_idx < 0: none)
+__device__ __forceinline__ void fused_advance(FusedRow& r, int g_idx, int s_from, int s_to, const AdamBlockArgs& a) {
+    if (g_idx >= 0) {
+        AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[g_idx], a.bc2_sqrt[g_idx], a.eps};
+        if (__builtin_amdgcn_readfirstlane(__float_as_int(one.bc2_sqrt)) == 0x3f800000)
+            adam_elem_unit_bc2(r.p, r.g, r.m, r.v, one);
+        else
+            adam_elem(r.p, r.g, r.m, r.v, one);
+    }
+    int s = s_from;
+    if (s < s_to) {
+        if (__builtin_amdgcn_ballot_w64(!lane_at_rest(r.p, r.m, r.v, fabsf(a.neg_step_size[s]), a)) == 0) {
+            for (; s < s_to; ++s) {
+                r.m = r.m + a.one_minus_b1 * (0.0f - r.m);
+                r.v = r.v * a.b2;
+            }
+        } else if (__builtin_amdgcn_ballot_w64(!lane_ordinary(r.m, r.v, a)) == 0) {
+            // sqrt(1 - beta2^t) rises with t and stays at 1.0f once it gets there: the run is all-unit, all-non-unit, or
+            // (around step 16 600, once) mixed -- then update by update
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(a.bc2_sqrt[s])) == 0x3f800000)
+                ordinary_run<true>(r.p, r.m, r.v, a, s, s_to);
+            else if (__builtin_amdgcn_readfirstlane(__float_as_int(a.bc2_sqrt[s_to - 1])) != 0x3f800000)
+                ordinary_run<false>(r.p, r.m, r.v, a, s, s_to);
+            else
+                for (; s < s_to; ++s) {
+                    AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
+                    if (__builtin_amdgcn_readfirstlane(__float_as_int(one.bc2_sqrt)) == 0x3f800000)
+                        adam_one_ordinary<true>(r.p, r.m, r.v, one);
+                    else
+                        adam_one_ordinary<false>(r.p, r.m, r.v, one);
+                }
+        }
+    }
+    for (; s < s_to; ++s) {
+        AdamArgs one{a.one_minus_b1, a.b2, a.one_minus_b2, a.neg_step_size[s], a.bc2_sqrt[s], a.eps};
+        if (__builtin_amdgcn_readfirstlane(__float_as_int(one.bc2_sqrt)) == 0x3f800000)
+            adam_elem_unit_bc2(r.p, 0.0f, r.m, r.v, one);
+        else
+            adam_elem(r.p, 0.0f, r.m, r.v, one);
+    }
+}
+
+struct FusedWork {
+    float *wp, *wm, *wv, *g;   // wp / wm / wv: [2][cap][64];  g: [3][cap][64]
+    int64_t cap;
+};
+
+// One wavefront per interaction, its five rows one after the other (dbg: timing switches of tools/fused_lab.py).  A
+// workgroup of five wavefronts per interaction (one per row, the rows meeting in LDS) was tried and is slower (18.4 vs 12.7 us
+// per launch alone on the chip): a CU holds four interactions either way, so the catch-up arithmetic per SIMD is the same,
+// and the barrier and the second id load come on top.
+__global__ __launch_bounds__(BPR_WAVES * 64) void bpr_fused_step_kernel(
+    const float* __restrict__ P, const float* __restrict__ M, const float* __restrict__ V, int64_t n_par, FusedWork w,
+    const int32_t* __restrict__ u_ids, const int32_t* __restrict__ i_ids, const int32_t* __restrict__ j_ids,
+    const int32_t* __restrict__ meta, int n, int64_t ublk0, int64_t iblk0, int64_t bblk0, int s_now, AdamBlockArgs a,
+    float reg, float* __restrict__ loss, int loss_slots, int dbg) {
+    __shared__ float s_loss[BPR_WAVES], s_l2[BPR_WAVES];
+    // dbg & 16: issue priority over the cold pass that shares the SIMDs (side stream).  Measured (bench.py, 200 steps): the
+    // step +6 % (42.2 -> 44.9 M interactions/s) but the cold pass 0.47 -> 0.57 ms, which then bounds the block; off
+    if (dbg & 16) __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float acc_loss = 0.0f, acc_l2 = 0.0f;
+    for (int b = blockIdx.x * BPR_WAVES + wv; b < n; b += gridDim.x * BPR_WAVES) {
+        const int64_t u = u_ids[b], i = i_ids[b], j = j_ids[b];
+        int32_t mt[5];
+        int64_t blk[5] = {ublk0 + u, iblk0 + i, iblk0 + j, bblk0 + (i >> 6), bblk0 + (j >> 6)};
+#pragma unroll
+        for (int r = 0; r < 5; ++r) mt[r] = __builtin_amdgcn_readfirstlane(meta[static_cast<int64_t>(r) * n + b]);
+        FusedRow row[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int64_t slot = mt[r] & ((1 << FUSED_SLOT_BITS) - 1);
+            const int n0 = (mt[r] >> FUSED_SLOT_BITS) & 7;
+            row[r] = FusedRow{1.0f, 0.0f, 0.0f, 0.0f};
+            if (((mt[r] >> 24) & 0x7f) == 0) {
+                const int64_t e = blk[r] * 64 + lane;
+                if (e < n_par) {
+                    row[r].p = P[e];
+                    row[r].m = M[e];
+                    row[r].v = V[e];
+                }
+            } else {
+                const int64_t e = ((n0 & 1) * w.cap + slot) * 64 + lane;
+                row[r].p = w.wp[e];
+                row[r].m = w.wm[e];
+                row[r].v = w.wv[e];
+                row[r].g = w.g[(((n0 + 2) % 3) * w.cap + slot) * 64 + lane];
+            }
+        }
+        if (!(dbg & 1)) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int prev1 = (mt[r] >> 24) & 0x7f;
+                fused_advance(row[r], prev1 - 1, prev1, s_now, a);
+            }
+        }
+        if (!(dbg & 4)) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                if ((mt[r] >> 23) & 1) {
+                    const int64_t slot = mt[r] & ((1 << FUSED_SLOT_BITS) - 1);
+                    const int n0 = (mt[r] >> FUSED_SLOT_BITS) & 7;
+                    const int64_t e = (((n0 + 1) & 1) * w.cap + slot) * 64 + lane;
+                    w.wp[e] = row[r].p;
+                    w.wm[e] = row[r].m;
+                    w.wv[e] = row[r].v;
+                    w.g[(((n0 + 1) % 3) * w.cap + slot) * 64 + lane] = 0.0f;
+                }
+            }
+        }
+        const float pu = row[0].p, qi = row[1].p, qj = row[2].p;
+        const float bi = __shfl(row[3].p, static_cast<int>(i & 63)), bj = __shfl(row[4].p, static_cast<int>(j & 63));
+        const float xi = skr::wave_sum(pu * qi) + bi, xj = skr::wave_sum(pu * qj) + bj;
+        const float x = xi - xj;
+        const float z = expf(-fabsf(x));
+        const float l = -(fminf(0.0f, x) - log1pf(z));
+        const float sig_neg = (x >= 0.0f) ? z / (1.0f + z) : 1.0f / (1.0f + z);
+        const float c = -sig_neg;
+        float sq = skr::wave_sum(pu * pu + qi * qi + qj * qj);
+        float* gcur[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int64_t slot = mt[r] & ((1 << FUSED_SLOT_BITS) - 1);
+            const int n0 = (mt[r] >> FUSED_SLOT_BITS) & 7;
+            gcur[r] = w.g + ((n0 % 3) * w.cap + slot) * 64;
+        }
+        if (!(dbg & 2)) {
+            // a row only this interaction names at this step takes a plain store (its buffer holds nothing that counts: it was
+            // cleared two namings ago, or never written); shared rows are summed by the memory-side atomic units
+            const float gu = c * (qi - qj) + reg * pu, gi = c * pu + reg * qi, gj = -c * pu + reg * qj;
+            if (mt[0] < 0) gcur[0][lane] = gu; else atomicAdd(&gcur[0][lane], gu);
+            if (mt[1] < 0) gcur[1][lane] = gi; else atomicAdd(&gcur[1][lane], gi);
+            if (mt[2] < 0) gcur[2][lane] = gj; else atomicAdd(&gcur[2][lane], gj);
+        }
+        sq += bi * bi + bj * bj;
+        if (lane == 0 && !(dbg & 2)) {
+            atomicAdd(&gcur[3][i & 63], c + reg * bi);
+            atomicAdd(&gcur[4][j & 63], -c + reg * bj);
+        }
+        acc_loss += l;
+        acc_l2 += 0.5f * sq;
+    }
+    if (lane == 0) {
+        s_loss[wv] = acc_loss;
+        s_l2[wv] = acc_l2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && !(dbg & 8)) {
+        float x = 0.0f, y = 0.0f;
+        for (int q = 0; q < BPR_WAVES; ++q) {
+            x += s_loss[q];
+            y += s_l2[q];
+        }
+        const int sl = 2 * (static_cast<int>(blockIdx.x) % loss_slots);
+        atomicAdd(&loss[sl], x);
+        atomicAdd(&loss[sl + 1], y);
+    }
+}
+
+// end of a k-step block: every slot is brought to the block's last index and written back; its gradient buffers are
+// left zero for the next block.  fin = (number of namings mod 6) | (step of the last naming << 8)
+__global__ __launch_bounds__(256) void bpr_fused_end_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
+                                                            int64_t n_par, FusedWork w, const int32_t* __restrict__ slot_blk,
+                                                            const int32_t* __restrict__ slot_fin,
+                                                            const int32_t* __restrict__ n_slots, AdamBlockArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= *n_slots) return;
+    const int64_t blk = slot_blk[slot];
+    const int fin = slot_fin[slot], nn = fin & 7, last = fin >> 8;
+    FusedRow r;
+    {
+        const int64_t e = ((nn & 1) * w.cap + slot) * 64 + lane;
+        r.p = w.wp[e];
+        r.m = w.wm[e];
+        r.v = w.wv[e];
+        r.g = w.g[(((nn + 2) % 3) * w.cap + slot) * 64 + lane];
+    }
+    const int64_t e = blk * 64 + lane;
+    if (e >= n_par) r = FusedRow{1.0f, 0.0f, 0.0f, 0.0f};
+    fused_advance(r, last, last + 1, a.k, a);
+    if (e < n_par) {
+        P[e] = r.p;
+        M[e] = r.m;
+        V[e] = r.v;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) w.g[(q * w.cap + slot) * 64 + lane] = 0.0f;
+}
+
+// ---- the references' words of a k-step block (skr_bpr_fused_plan): four small launches, no sort -------------------------
+// named[blk] collects, as a 64-bit mask, the steps of the block that name flat block `blk`; everything a reference needs
+// follows from the mask: n0 = popcount below its own step, prev = the highest set bit below it.  claimed[blk] hands out
+// one owner per (step, row); the owner of a row's FIRST naming draws the row's slot.  named / claimed are all-zero between
+// calls (the last launch clears what the first two set).
+struct FusedPlanArgs {
+    const int32_t *u, *i, *j;
+    int k, b;
+    int64_t ublk0, iblk0, bblk0;
+    unsigned long long *named, *claimed, *shared;
+    int32_t *slot_of, *meta, *slot_block, *slot_fin, *n_slots;
+};
+
+__device__ __forceinline__ void fused_plan_refs(const FusedPlanArgs& a, int64_t t, int64_t blk[5]) {
+    const int64_t u = a.u[t], i = a.i[t], j = a.j[t];
+    blk[0] = a.ublk0 + u;
+    blk[1] = a.iblk0 + i;
+    blk[2] = a.iblk0 + j;
+    blk[3] = a.bblk0 + (i >> 6);
+    blk[4] = a.bblk0 + (j >> 6);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void fused_plan_kernel(FusedPlanArgs a) {
+    const int64_t t = blockIdx.x * 256ll + threadIdx.x;      // position in the block's step-major columns
+    if (PASS == 0 && t == 0) *a.n_slots = 0;
+    if (t >= static_cast<int64_t>(a.k) * a.b) return;
+    const int s = static_cast<int>(t / a.b);
+    const int64_t col = t - static_cast<int64_t>(s) * a.b;
+    int64_t blk[5];
+    fused_plan_refs(a, t, blk);
+    const unsigned long long bit = 1ull << s;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int64_t e = (static_cast<int64_t>(s) * 5 + r) * a.b + col;      // this reference's word
+        if (PASS == 0) {
+            atomicOr(&a.named[blk[r]], bit);
+            a.slot_block[e] = -1;
+        } else if (PASS == 1) {
+            const bool owner = (atomicOr(&a.claimed[blk[r]], bit) & bit) == 0;
+            if (!owner) atomicOr(&a.shared[blk[r]], bit);                     // a second reference to the pair
+            a.meta[e] = owner ? (1 << 23) : 0;
+            const unsigned long long mask = a.named[blk[r]];
+            if (owner && (mask & (bit - 1)) == 0) {                           // the row's first naming: draw its slot
+                const int slot = atomicAdd(a.n_slots, 1);
+                a.slot_of[blk[r]] = slot;
+                a.slot_block[slot] = static_cast<int32_t>(blk[r]);
+                a.slot_fin[slot] = (__popcll(mask) % 6) | ((63 - __clzll(static_cast<long long>(mask))) << 8);
+            }
+        } else if (PASS == 2) {
+            const unsigned long long below = a.named[blk[r]] & (bit - 1);
+            const int n0 = __popcll(below), prev1 = below ? 64 - __clzll(static_cast<long long>(below)) : 0;
+            const int sole = (a.shared[blk[r]] & bit) ? 0 : 1;                // the pair's only reference (bit 31)
+            a.meta[e] = a.meta[e] | a.slot_of[blk[r]] | ((n0 % 6) << FUSED_SLOT_BITS) | (prev1 << 24) |
+                        static_cast<int32_t>(static_cast<uint32_t>(sole) << 31);
+        } else {
+            a.named[blk[r]] = 0;
+            a.claimed[blk[r]] = 0;
+            a.shared[blk[r]] = 0;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1328,6 +1642,95 @@ int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n
     hipLaunchKernelGGL(adam_hot_kernel, dim3(static_cast<unsigned>((n_ids + 3) / 4)), dim3(256), 0, skr::as_stream(stream), d_p,
                        d_g, d_m, d_v, n, a, static_cast<int32_t>(step_t0), static_cast<int32_t>(step_t), d_ids, n_ids,
                        offset_floats, stride_floats, d_claim);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+// scalars and thresholds of a k-step block, kept between the k + 1 launches of the block (2k pow() calls otherwise)
+static const AdamBlockArgs& fused_block_args(float lr, float beta1, float beta2, float eps, int64_t step_t0, int k) {
+    struct Key {
+        float lr, b1, b2, eps;
+        int64_t t0;
+        int k;
+    };
+    thread_local Key key{0, 0, 0, 0, -1, 0};
+    thread_local AdamBlockArgs a{};
+    if (key.lr != lr || key.b1 != beta1 || key.b2 != beta2 || key.eps != eps || key.t0 != step_t0 || key.k != k) {
+        a = AdamBlockArgs{};
+        a.one_minus_b1 = static_cast<float>(1.0 - static_cast<double>(beta1));
+        a.b2 = beta2;
+        a.one_minus_b2 = static_cast<float>(1.0 - static_cast<double>(beta2));
+        a.eps = eps;
+        a.k = k;
+        for (int s = 0; s < k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s]);
+        adam_block_thresholds(a, lr, beta1, beta2, eps, k);
+        key = Key{lr, beta1, beta2, eps, step_t0, k};
+    }
+    return a;
+}
+
+static FusedWork fused_work(float* d_work, int64_t cap) {
+    const int64_t plane = cap * 64;
+    return FusedWork{d_work, d_work + 2 * plane, d_work + 4 * plane, d_work + 6 * plane, cap};
+}
+
+int skr_bpr_fused_step(const float* d_p, const float* d_m, const float* d_v, int64_t n, float* d_work, int64_t cap,
+                       const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch,
+                       int64_t user_block0, int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2,
+                       float eps, int64_t step_t0, int k, int s, float reg, float* d_loss64, void* stream) {
+    SKR_REQUIRE(d_p && d_m && d_v && d_work && d_u && d_i && d_j && d_meta && d_loss64, "skr_bpr_fused_step: NULL argument");
+    SKR_REQUIRE(n >= 0 && n_batch >= 0 && cap >= 1 && cap <= (1 << FUSED_SLOT_BITS), "skr_bpr_fused_step: need 1 <= cap <= 2^%d",
+                FUSED_SLOT_BITS);
+    SKR_REQUIRE(step_t0 >= 0 && k >= 1 && k <= AB_KMAX && s >= 0 && s < k, "skr_bpr_fused_step: need 0 <= s < k <= %d", AB_KMAX);
+    SKR_REQUIRE(user_block0 >= 0 && item_block0 >= 0 && bias_block0 >= 0, "skr_bpr_fused_step: bad table offsets");
+    if (n_batch == 0) return SKR_OK;
+    const AdamBlockArgs& a = fused_block_args(lr, beta1, beta2, eps, step_t0, k);
+    static const int dbg = [] { const char* e = getenv("SKR_FUSED_DBG"); return e ? atoi(e) : 0; }();
+    int blocks = (n_batch + BPR_WAVES - 1) / BPR_WAVES;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(bpr_fused_step_kernel, dim3(blocks), dim3(BPR_WAVES * 64), 0, skr::as_stream(stream), d_p, d_m, d_v, n,
+                       fused_work(d_work, cap), d_u, d_i, d_j, d_meta, n_batch, user_block0, item_block0, bias_block0, s, a, reg,
+                       d_loss64, SKR_LOSS_SLOTS, dbg);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_bpr_fused_plan(const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n_batch, int k, int64_t user_block0,
+                       int64_t item_block0, int64_t bias_block0, int64_t n_flat_blocks, void* d_scratch, int32_t* d_meta,
+                       int32_t* d_slot_block, int32_t* d_slot_fin, int32_t* d_n_slots, void* stream) {
+    SKR_REQUIRE(d_u && d_i && d_j && d_scratch && d_meta && d_slot_block && d_slot_fin && d_n_slots, "skr_bpr_fused_plan: NULL argument");
+    SKR_REQUIRE(n_batch >= 1 && k >= 1 && k <= AB_KMAX && static_cast<int64_t>(k) * 5 * n_batch <= (1 << FUSED_SLOT_BITS),
+                "skr_bpr_fused_plan: need 1 <= k <= %d and k * 5 * n_batch <= 2^%d", AB_KMAX, FUSED_SLOT_BITS);
+    SKR_REQUIRE(user_block0 >= 0 && item_block0 >= 0 && bias_block0 >= 0 && n_flat_blocks >= 1 && n_flat_blocks < INT32_MAX,
+                "skr_bpr_fused_plan: bad table offsets");
+    SKR_REQUIRE((reinterpret_cast<uintptr_t>(d_scratch) & 7) == 0, "skr_bpr_fused_plan: scratch must be 8-byte aligned");
+    FusedPlanArgs a;
+    a.u = d_u, a.i = d_i, a.j = d_j;
+    a.k = k, a.b = n_batch;
+    a.ublk0 = user_block0, a.iblk0 = item_block0, a.bblk0 = bias_block0;
+    a.named = static_cast<unsigned long long*>(d_scratch);
+    a.claimed = a.named + n_flat_blocks;
+    a.shared = a.claimed + n_flat_blocks;
+    a.slot_of = reinterpret_cast<int32_t*>(a.shared + n_flat_blocks);
+    a.meta = d_meta, a.slot_block = d_slot_block, a.slot_fin = d_slot_fin, a.n_slots = d_n_slots;
+    const dim3 grid(static_cast<unsigned>((static_cast<int64_t>(k) * n_batch + 255) / 256)), wg(256);
+    hipLaunchKernelGGL(fused_plan_kernel<0>, grid, wg, 0, skr::as_stream(stream), a);
+    hipLaunchKernelGGL(fused_plan_kernel<1>, grid, wg, 0, skr::as_stream(stream), a);
+    hipLaunchKernelGGL(fused_plan_kernel<2>, grid, wg, 0, skr::as_stream(stream), a);
+    hipLaunchKernelGGL(fused_plan_kernel<3>, grid, wg, 0, skr::as_stream(stream), a);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_bpr_fused_end(float* d_p, float* d_m, float* d_v, int64_t n, float* d_work, int64_t cap, const int32_t* d_slot_block,
+                      const int32_t* d_slot_fin, const int32_t* d_n_slots, float lr, float beta1, float beta2, float eps,
+                      int64_t step_t0, int k, void* stream) {
+    SKR_REQUIRE(d_p && d_m && d_v && d_work && d_slot_block && d_slot_fin && d_n_slots, "skr_bpr_fused_end: NULL argument");
+    SKR_REQUIRE(n >= 0 && cap >= 1 && cap <= (1 << FUSED_SLOT_BITS), "skr_bpr_fused_end: need 1 <= cap <= 2^%d", FUSED_SLOT_BITS);
+    SKR_REQUIRE(step_t0 >= 0 && k >= 1 && k <= AB_KMAX, "skr_bpr_fused_end: need 1 <= k <= %d", AB_KMAX);
+    const AdamBlockArgs& a = fused_block_args(lr, beta1, beta2, eps, step_t0, k);
+    hipLaunchKernelGGL(bpr_fused_end_kernel, dim3(static_cast<unsigned>((cap + 3) / 4)), dim3(256), 0, skr::as_stream(stream), d_p,
+                       d_m, d_v, n, fused_work(d_work, cap), d_slot_block, d_slot_fin, d_n_slots, a);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

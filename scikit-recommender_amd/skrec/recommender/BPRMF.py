@@ -84,7 +84,10 @@ class BPRMF(AbstractRecommender):
         self.item_embeddings = self._flat[nu * d:(nu + ni) * d].view(ni, d)
         self.item_biases = self._flat[(nu + ni) * d:]
         # SKR_ADAM_BLOCK = k: look k batches ahead and block the dense Adam over them (1: one dense launch per step)
-        self.adam_block = max(1, min(32, int(os.environ.get("SKR_ADAM_BLOCK", "32"))))
+        self.adam_block = max(1, min(64, int(os.environ.get("SKR_ADAM_BLOCK", "32"))))
+        # SKR_BPR_FUSED=0: two launches per step (skr_bpr_step_spread + skr_adam_block_hot) instead of one (skr_bpr_fused_step)
+        self.fused_step = os.environ.get("SKR_BPR_FUSED", "1") != "0"
+        self._fused = None
         self.optimizer = DenseAdam(self._flat, lr=self.config.lr, track_touch=self.adam_block <= 1)
         self._grads = (self.optimizer.grad_view(0, (nu, d)), self.optimizer.grad_view(nu * d, (ni, d)),
                        self.optimizer.grad_view((nu + ni) * d, (ni,)))
@@ -158,8 +161,17 @@ class BPRMF(AbstractRecommender):
         n_full_blocks = (len(cu) // bsz) // kblk
         rows = n_full_blocks * kblk * bsz
         ids_all = block_ids(*(c[:rows].view(n_full_blocks, kblk, bsz) for c in (cu, ci, cj)), dim=2).view(n_full_blocks, -1) \
-            if n_full_blocks else None
-        for s0 in range(0, len(bounds), kblk):
+            if n_full_blocks and not self.fused_step else None
+        first = 0
+        if self.fused_step and n_full_blocks:
+            # full blocks: ONE launch per step -- the hot rows' Adam is evaluated inside the BPR kernel (csrc/train.hip K2c)
+            from .fused import FusedBlocks
+            if self._fused is None:
+                self._fused = FusedBlocks(opt, 0, nu, nu + ni, reg)
+            fb = self._fused
+            fb.run_blocks(pcu, pci, pcj, n_full_blocks, kblk, bsz, ploss, 8 * S)
+            first = n_full_blocks * kblk
+        for s0 in range(first, len(bounds), kblk):
             blk = bounds[s0:s0 + kblk]
             lo, hi = blk[0][0], blk[-1][1]
             if s0 // kblk < n_full_blocks:

@@ -1,0 +1,149 @@
+"""Host side of the one-launch BPRMF step (csrc/train.hip K2c: ``skr_bpr_fused_step`` / ``skr_bpr_fused_end``).
+
+The reference's step is ``loss.backward(); optimizer.step()`` with a DENSE Adam (BPRMF.py:108-127): every row moves at
+every step.  The blocked optimiser (base.DenseAdam.begin_block) already gives the rows no batch of a k-step block touches
+their k zero-gradient updates in one pass; this module prepares what lets the TOUCHED rows be evaluated lazily inside the
+BPR kernel itself, so that a step is one launch instead of two dependent ones: for every reference (step, row) of a block
+the row's slot in the block's workspace, how many earlier steps named the row, the step of the previous naming, and one
+owner per (step, row) pair.  All of it follows from the epoch's batches, which are known before the epoch starts
+(data_iterator.py:230-234 builds them from one permutation); ``skr_bpr_fused_plan`` computes it per block on the device --
+no value is read back.
+"""
+import torch
+
+from .. import _hip
+
+SLOT_BITS = 20
+
+
+def build_fused_meta(cu, ci, cj, n_blocks, k, bsz, user_block0, item_block0, bias_block0, chunk_blocks=64):
+    """The words ``skr_bpr_fused_plan`` writes, derived independently with sorts and scans (tests compare the two, modulo
+    the numbering of the slots).  cu / ci / cj: the epoch's int32 columns (step-major, contiguous); the first n_blocks * k * bsz entries are the full
+    blocks.  Returns (meta [n_blocks, k, 5, bsz] int32, slot_block [n_blocks, L] int32 (-1 padded), slot_fin [n_blocks, L]
+    int32, n_slots [n_blocks] int32) with L = k * 5 * bsz; formats: include/skrec_hip.h, skr_bpr_fused_step."""
+    L = k * 5 * bsz
+    assert L <= (1 << SLOT_BITS) and k <= 64
+    dev = cu.device
+    rows = n_blocks * k * bsz
+    meta = torch.empty((n_blocks, L), dtype=torch.int32, device=dev)
+    slot_block = torch.empty((n_blocks, L), dtype=torch.int32, device=dev)
+    slot_fin = torch.empty((n_blocks, L), dtype=torch.int32, device=dev)
+    n_slots = torch.empty(n_blocks, dtype=torch.int32, device=dev)
+    U, I, J = (c[:rows].view(n_blocks, k, bsz) for c in (cu, ci, cj))
+    step = torch.arange(k, device=dev, dtype=torch.int64).view(1, k, 1, 1)
+    idx = torch.arange(L, device=dev, dtype=torch.int64).view(1, L)
+    for b0 in range(0, n_blocks, chunk_blocks):
+        b1 = min(n_blocks, b0 + chunk_blocks)
+        nb = b1 - b0
+        u, i, j = U[b0:b1].long(), I[b0:b1].long(), J[b0:b1].long()
+        refs = torch.stack([u + user_block0, i + item_block0, j + item_block0, (i >> 6) + bias_block0, (j >> 6) + bias_block0],
+                           dim=2)                                            # [nb, k, 5, bsz]: 64-float blocks of the flat buffer
+        key = (refs * 64 + step).view(nb, L)
+        skey, perm = torch.sort(key, dim=1)
+        blk, stp = skey >> 6, skey & 63
+        new_pair = torch.ones((nb, L), dtype=torch.bool, device=dev)
+        new_pair[:, 1:] = skey[:, 1:] != skey[:, :-1]
+        new_row = torch.ones((nb, L), dtype=torch.bool, device=dev)
+        new_row[:, 1:] = blk[:, 1:] != blk[:, :-1]
+        c_pair = torch.cumsum(new_pair, dim=1)                               # pairs seen so far (1-based)
+        zero = torch.zeros((), dtype=torch.int64, device=dev)
+        row_first = torch.cummax(torch.where(new_row, c_pair, zero), dim=1).values
+        n0 = c_pair - row_first                                              # earlier namings of the row in this block
+        slot = torch.cumsum(new_row, dim=1) - 1
+        pair_start = torch.cummax(torch.where(new_pair, idx, zero), dim=1).values
+        prev_step = torch.gather(stp, 1, (pair_start - 1).clamp_(min=0))
+        first_naming = torch.gather(new_row, 1, pair_start)
+        prev1 = torch.where(first_naming, zero, prev_step + 1)
+        word = slot | ((n0 % 6) << SLOT_BITS) | (new_pair.long() << 23) | (prev1 << 24)
+        meta[b0:b1].scatter_(1, perm, word.int())
+        # per slot: its block of the flat buffer; number of namings and the step of the last one
+        sb = torch.full((nb, L + 1), -1, dtype=torch.int32, device=dev)
+        sb.scatter_(1, torch.where(new_row, slot, torch.full_like(slot, L)), blk.int())
+        slot_block[b0:b1] = sb[:, :L]
+        row_last = torch.ones((nb, L), dtype=torch.bool, device=dev)
+        row_last[:, :-1] = new_row[:, 1:]
+        sf = torch.zeros((nb, L + 1), dtype=torch.int32, device=dev)
+        sf.scatter_(1, torch.where(row_last, slot, torch.full_like(slot, L)), (((n0 + 1) % 6) | (stp << 8)).int())
+        slot_fin[b0:b1] = sf[:, :L]
+        n_slots[b0:b1] = (slot[:, -1] + 1).int()
+    return meta.view(n_blocks, k, 5, bsz), slot_block, slot_fin, n_slots
+
+
+class FusedBlocks(object):
+    """Runs k-step blocks of full batches through ``skr_bpr_fused_step``: per block the references' words
+    (``skr_bpr_fused_plan``, four small launches on a stream of their own, one block ahead), the tags + the cold pass of
+    ``DenseAdam.begin_block`` (side stream), k step launches, one end launch.
+
+    ``opt``: the model's DenseAdam over the flat [U | V | bias] buffer; table offsets in 64-float blocks."""
+
+    def __init__(self, opt, user_block0, item_block0, bias_block0, reg):
+        self.opt = opt
+        self.offsets = (int(user_block0), int(item_block0), int(bias_block0))
+        self.reg = float(reg)
+        self.cap = 0
+        dev = opt.flat.device
+        self.n_flat_blocks = (opt.flat.numel() + 63) // 64
+        self.scratch = torch.zeros(28 * self.n_flat_blocks // 8 + 1, dtype=torch.int64, device=dev)   # zero between calls
+
+    def _size(self, k, bsz):
+        cap = k * 5 * bsz
+        if cap > self.cap:
+            dev = self.opt.flat.device
+            self.cap = cap
+            self.work = torch.zeros(9 * cap * 64, dtype=torch.float32, device=dev)     # zero: the invariant between blocks
+            # two sets of the references' words / slot tables: block n + 1 is planned (side stream) while block n runs
+            self.meta, self.slot_block, self.slot_fin = (torch.empty((2, cap), dtype=torch.int32, device=dev) for _ in range(3))
+            self.n_slots = torch.zeros((2, 1), dtype=torch.int32, device=dev)
+            self._plan_stream = torch.cuda.Stream(device=dev)
+            self._ev_plan = [torch.cuda.Event(), torch.cuda.Event()]
+            self._ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self._used = [False, False]
+
+    def _plan(self, q, pu, pi, pj, k, bsz):
+        """references' words of one block into buffer set q, on the planning stream"""
+        u0, i0, b0 = self.offsets
+        ps = self._plan_stream
+        if self._used[q]:
+            ps.wait_event(self._ev_done[q])       # the set's previous block has run
+        rc = _hip.lib().skr_bpr_fused_plan(pu, pi, pj, bsz, k, u0, i0, b0, self.n_flat_blocks, self.scratch.data_ptr(),
+                                           self.meta[q].data_ptr(), self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(),
+                                           self.n_slots[q].data_ptr(), ps.cuda_stream)
+        if rc:
+            _hip.check(rc)
+        self._ev_plan[q].record(ps)
+
+    def run_blocks(self, pu, pi, pj, n_blocks, k, bsz, ploss, loss_stride_bytes):
+        """n_blocks * k batches of bsz triples each at the device addresses pu / pi / pj (int32, step-major); the loss sums
+        of step s go to ploss + s * loss_stride_bytes (SKR_LOSS_SLOTS pairs of floats each)"""
+        opt, L, st = self.opt, _hip.lib(), _hip.stream()
+        self._size(k, bsz)
+        cur = torch.cuda.current_stream()
+        n_ref, blk_bytes = k * 5 * bsz, 4 * k * bsz
+        u0, i0, b0 = self.offsets
+        pp, pm, pv, n_par = opt.flat.data_ptr(), opt.m.data_ptr(), opt.v.data_ptr(), opt.flat.numel()
+        pw, cap = self.work.data_ptr(), self.cap
+        lr, (b1, b2), eps, reg = opt.lr, opt.betas, opt.eps, self.reg
+        fn = L.skr_bpr_fused_step
+        self._plan_stream.wait_stream(cur)        # the columns were produced on the current stream
+        if n_blocks > 0:
+            self._plan(0, pu, pi, pj, k, bsz)
+        for blk in range(n_blocks):
+            q, o = blk & 1, blk * blk_bytes
+            if blk + 1 < n_blocks:
+                self._plan(q ^ 1, pu + o + blk_bytes, pi + o + blk_bytes, pj + o + blk_bytes, k, bsz)
+            cur.wait_event(self._ev_plan[q])
+            opt.begin_block(self.slot_block[q, :n_ref], k)  # tags the hot blocks, starts the cold pass beside us
+            t0 = opt.t
+            pmeta = self.meta[q].data_ptr()
+            rc = 0
+            for s in range(k):
+                os_ = o + 4 * s * bsz
+                rc |= fn(pp, pm, pv, n_par, pw, cap, pu + os_, pi + os_, pj + os_, pmeta + 20 * s * bsz, bsz, u0, i0, b0, lr, b1, b2,
+                         eps, t0, k, s, reg, ploss + (blk * k + s) * loss_stride_bytes, st)
+            rc |= L.skr_bpr_fused_end(pp, pm, pv, n_par, pw, cap, self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(),
+                                      self.n_slots[q].data_ptr(), lr, b1, b2, eps, t0, k, st)
+            self._ev_done[q].record(cur)
+            self._used[q] = True
+            opt.t = t0 + k
+            if rc:
+                _hip.check(rc)

@@ -49,13 +49,19 @@ def _check_reports(got, want, names):
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=0, err_msg=str(names))
 
 
-@pytest.mark.parametrize("adam_block", [None, "8", "1", "3"])
+@pytest.mark.parametrize("adam_block", [None, "8", "1", "3", "3/two-launch", "2"])
 def test_bprmf_replays_reference(golden, tiny_dir, monkeypatch, tmp_path, adam_block):
     """the reference's recorded fit() trajectory, with the temporally blocked Adam (None = the shipped default, 32 batches
-    per block; 8; and 3: blocks that do not divide the epoch) and with one dense launch per step"""
+    per block; 8; 3 and 2: blocks that do not divide the epoch -- full blocks take the one-launch step, skr_bpr_fused_step,
+    the tail the two-launch step; "/two-launch": SKR_BPR_FUSED=0) and with one dense launch per step"""
     from skrec.recommender.BPRMF import BPRMF
     from skrec.utils.py.random import reset_global_sampler
     monkeypatch.chdir(tmp_path)
+    if adam_block is not None and adam_block.endswith("/two-launch"):
+        adam_block = adam_block.split("/")[0]
+        monkeypatch.setenv("SKR_BPR_FUSED", "0")
+    else:
+        monkeypatch.delenv("SKR_BPR_FUSED", raising=False)
     if adam_block is None:
         monkeypatch.delenv("SKR_ADAM_BLOCK", raising=False)
     else:

@@ -301,7 +301,7 @@ def test_gather_axpy_scale():
 
 @pytest.mark.parametrize("lazy", [True, False])
 @pytest.mark.parametrize("k,n_steps,t0", [(8, 37, 0), (1, 5, 0), (16, 16, 0), (3, 10, 0), (8, 20, 16595), (8, 16, 40000),
-                                          (32, 70, 0), (32, 64, 16580), (32, 32, 300)])
+                                          (32, 70, 0), (32, 64, 16580), (32, 32, 300), (64, 130, 0), (64, 64, 16570)])
 def test_blocked_adam_is_bit_identical(k, n_steps, t0, lazy):
     """temporally blocked dense Adam (cold blocks: k zero-gradient updates in one pass; hot blocks: the ordinary
     update every step -- or, `lazy`, when a batch is about to read them / has written their gradient, catching up
@@ -363,10 +363,130 @@ def test_blocked_adam_is_bit_identical(k, n_steps, t0, lazy):
     np.testing.assert_allclose(la.cpu().numpy(), lc.cpu().numpy(), rtol=1e-5)
 
 
+def _fused_case(k, n_blocks, t0, distinct, seed, nU=5000, nI=777, b=256, lr=1e-2):
+    """classic (skr_bpr_step + one dense skr_adam_step per batch) and fused (skr_bpr_fused_step, one launch per batch)
+    optimisers after the same n_blocks * k batches"""
+    import torch
+    from skrec import _hip
+    from skrec.recommender.base import DenseAdam
+    from skrec.recommender.fused import FusedBlocks
+    L, st = _hip.lib(), _hip.stream
+    rng = np.random.default_rng(seed)
+    n_steps = k * n_blocks
+    n_par = (nU + nI) * 64 + nI
+    init = torch.from_numpy((rng.standard_normal(n_par) * 0.05).astype(np.float32)).cuda()
+    if distinct:      # rows distinct within a step (each float atomic then happens once: deterministic gradients)
+        u = np.stack([rng.permutation(nU)[:b] for _ in range(n_steps)])
+        ij = np.stack([rng.permutation(nI)[:2 * b] for _ in range(n_steps)])
+        i, j = ij[:, :b], ij[:, b:]
+    else:             # popular items and repeated users inside a step, like real batches
+        u = rng.integers(0, nU // 50, (n_steps, b))
+        i = np.minimum((rng.pareto(1.2, (n_steps, b)) * 5).astype(np.int64), nI - 1)
+        j = (i + 1 + rng.integers(0, nI - 1, (n_steps, b))) % nI
+    u, i, j = (torch.from_numpy(np.ascontiguousarray(x).astype(np.int32)).cuda() for x in (u, i, j))
+    a = DenseAdam(init.clone(), lr=lr, track_touch=True)
+    a.t = t0
+    la = torch.zeros((n_steps, 2), device="cuda")
+    f, g = a.flat, a.grad
+    sl = lambda t: (t[:nU * 64].view(nU, 64), t[nU * 64:(nU + nI) * 64].view(nI, 64), t[(nU + nI) * 64:])  # noqa: E731
+    (U, V, bias), (gU, gV, gb) = sl(f), sl(g)
+    for s in range(n_steps):
+        _hip.check(L.skr_bpr_step(_hip.ptr(U), _hip.ptr(V), _hip.ptr(bias), _hip.ptr(U), _hip.ptr(V), _hip.ptr(u[s]), _hip.ptr(i[s]),
+                                  _hip.ptr(j[s]), b, 1.0, 1e-3, 1.0, _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(gb), _hip.ptr(gU),
+                                  _hip.ptr(gV), _hip.ptr(la[s]), _hip.ptr(a.touch), _hip.ptr(a.grad), st()))
+        a.step()
+    c = DenseAdam(init.clone(), lr=lr)
+    c.t = t0
+    S = _hip.SKR_LOSS_SLOTS
+    lc = torch.zeros((n_steps, S, 2), device="cuda")
+    fb = FusedBlocks(c, 0, nU, nU + nI, 1e-3)
+    fb.run_blocks(u.data_ptr(), i.data_ptr(), j.data_ptr(), n_blocks, k, b, lc.data_ptr(), 8 * S)
+    c.end_blocks()
+    torch.cuda.synchronize()
+    assert c.t == a.t == t0 + n_steps
+    return a, c, la, lc.sum(1), fb
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n_blocks,t0", [(8, 3, 0), (1, 3, 0), (3, 4, 0), (32, 2, 0), (32, 2, 16580), (64, 1, 300), (64, 2, 16560),
+                                           (16, 2, 40000)])
+def test_fused_step_is_bit_identical(k, n_blocks, t0):
+    """one launch per step (the hot rows' Adam evaluated lazily inside the BPR kernel, pending gradients applied at the
+    row's next naming or by the block's end launch) == skr_bpr_step + a dense skr_adam_step after every batch, BIT FOR
+    BIT: parameters and both moments.  Bias blocks are shared by many references of a step (the sharers each recompute
+    the block's state, one owner writes it); item and user rows repeat across the steps of a block."""
+    import torch
+    a, c, la, lc, fb = _fused_case(k, n_blocks, t0, True, 300 + k)
+    assert int((a.flat != c.flat).sum()) == 0
+    assert torch.equal(a.m, c.m) and torch.equal(a.v, c.v)
+    assert float(fb.work[6 * fb.cap * 64:].abs().max()) == 0.0          # every gradient was consumed, the buffers are clear
+    np.testing.assert_allclose(la.cpu().numpy(), lc.cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,b,nU,nI", [(32, 256, 3000, 500), (64, 64, 100, 40), (1, 128, 50, 70), (7, 100, 20, 1000)])
+def test_fused_plan_matches_the_sort_based_derivation(k, b, nU, nI):
+    """skr_bpr_fused_plan (bit masks of the naming steps, atomics) against build_fused_meta (sort + scans): the same earlier-naming
+    counts, previous steps, one owner per (step, row), and the same slot tables up to the numbering of the slots; the
+    scratch is left zero"""
+    import torch
+    from skrec import _hip
+    from skrec.recommender.fused import build_fused_meta
+    L, st = _hip.lib(), _hip.stream
+    rng = np.random.default_rng(k + b)
+    u = torch.from_numpy(rng.integers(0, nU, k * b).astype(np.int32)).cuda()
+    i = torch.from_numpy(np.minimum((rng.pareto(1.0, k * b) * 3).astype(np.int64), nI - 1).astype(np.int32)).cuda()
+    j = torch.from_numpy(rng.integers(0, nI, k * b).astype(np.int32)).cuda()
+    nfb = nU + nI + (nI + 63) // 64
+    n_ref = k * 5 * b
+    scratch = torch.zeros(28 * nfb // 8 + 1, dtype=torch.int64, device="cuda")
+    meta, sb, sf = (torch.full((n_ref,), -7, dtype=torch.int32, device="cuda") for _ in range(3))
+    ns = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+    for _ in range(2):      # twice: the second call starts from the scratch the first one left
+        _hip.check(L.skr_bpr_fused_plan(_hip.ptr(u), _hip.ptr(i), _hip.ptr(j), b, k, 0, nU, nU + nI, nfb, _hip.ptr(scratch),
+                                        _hip.ptr(meta), _hip.ptr(sb), _hip.ptr(sf), _hip.ptr(ns), st()))
+    torch.cuda.synchronize()
+    assert int(scratch[:3 * nfb].abs().sum()) == 0          # the three masks per flat block; the slot numbers behind them may stay
+    wm, wsb, wsf, wns = build_fused_meta(u, i, j, 1, k, b, 0, nU, nU + nI)
+    n = int(ns)
+    assert n == int(wns[0])
+    got, want = meta.cpu().numpy().astype(np.int64), wm.reshape(-1).cpu().numpy().astype(np.int64)
+    sole, got = (got >> 31) & 1, got & 0x7fffffff
+    assert np.array_equal(got >> 24, want >> 24) and np.array_equal((got >> 20) & 7, (want >> 20) & 7)     # prev + 1, n0 mod 6
+    gsb, wsb_ = sb.cpu().numpy(), wsb[0].cpu().numpy()
+    assert (gsb[n:] == -1).all() and sorted(gsb[:n]) == list(wsb_[:n]) and len(set(gsb[:n])) == n
+    # the same row behind every reference's slot; the slots' final words belong to the same rows
+    assert np.array_equal(gsb[got & 0xfffff], wsb_[want & 0xfffff])
+    order_g, order_w = np.argsort(gsb[:n]), np.argsort(wsb_[:n])
+    assert np.array_equal(sf.cpu().numpy()[:n][order_g], wsf[0].cpu().numpy()[:n][order_w])
+    # one owner per (step, row)
+    step = np.repeat(np.arange(k), 5 * b)
+    pair = gsb[got & 0xfffff].astype(np.int64) * 64 + step
+    owners = pair[((got >> 23) & 1) == 1]
+    assert len(owners) == len(np.unique(pair)) == len(np.unique(owners))
+    # "sole": exactly the references whose (step, row) pair occurs once
+    _, inv, cnt = np.unique(pair, return_inverse=True, return_counts=True)
+    assert np.array_equal(sole == 1, cnt[inv] == 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n_blocks", [(32, 2), (8, 4)])
+def test_fused_step_with_rows_shared_inside_a_step(k, n_blocks):
+    """popular items and repeated users inside one batch: several wavefronts of a launch read (and recompute) the same
+    row, one of them writes it, all of them add into its gradient.  The float atomics then sum in an order that differs
+    from launch to launch -- in the two-launch path too -- so the comparison is to rounding, not to the bit."""
+    a, c, la, lc, fb = _fused_case(k, n_blocks, 0, False, 77 + k, lr=1e-3)
+    np.testing.assert_allclose(c.flat.cpu().numpy(), a.flat.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(c.m.cpu().numpy(), a.m.cpu().numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(c.v.cpu().numpy(), a.v.cpu().numpy(), rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(la.cpu().numpy(), lc.cpu().numpy(), rtol=1e-4)
+    assert float(fb.work[6 * fb.cap * 64:].abs().max()) == 0.0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,t0,eps,lr", [(8, 0, 1e-8, 1e-3), (16, 20000, 1e-8, 1e-3), (5, 16596, 1e-8, 5e-2), (8, 100, 0.0, 1e-3),
                                          (8, 3, 1e-3, 1e-3), (32, 0, 1e-8, 1e-3), (32, 16580, 1e-8, 1e-3), (32, 777, 1e-8, 1e-2),
-                                         (32, 50000, 0.0, 1e-3)])
+                                         (32, 50000, 0.0, 1e-3), (64, 0, 1e-8, 1e-3), (64, 16570, 1e-8, 1e-3), (64, 900, 1e-8, 1e-2)])
 def test_cold_pass_rest_regime_is_bit_identical(k, t0, eps, lr):
     """cold pass (rows at rest skip the square root and the divisions of the update, see adam_cold_rows_kernel) == k
     calls of skr_adam_step with a zero gradient, BIT FOR BIT, over rows of every age (moments decayed by 0 ... 3000
@@ -514,8 +634,8 @@ def test_blocked_adam_lists_may_hold_empty_slots():
     p, m, v, g = p0.clone(), m0.clone(), v0.clone(), grad0.clone()
     args = (_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8)
     assert L.skr_adam_block_hot(*args, 10, 10, _hip.ptr(d), 1, 0, 64, _hip.ptr(claim), st()) == -1      # step_t must exceed step_t0
-    assert L.skr_adam_block_hot(*args, 10, 43, _hip.ptr(d), 1, 0, 64, _hip.ptr(claim), st()) == -1      # more than 32 steps
+    assert L.skr_adam_block_hot(*args, 10, 75, _hip.ptr(d), 1, 0, 64, _hip.ptr(claim), st()) == -1      # more than 64 steps
     assert L.skr_adam_block_hot(*args, 10, 11, None, 1, 0, 64, _hip.ptr(claim), st()) == -1
     tag = torch.zeros(50, dtype=torch.int32, device="cuda")
-    assert L.skr_adam_block_cold(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0, 33, _hip.ptr(tag), 1, st()) == -1
+    assert L.skr_adam_block_cold(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0, 65, _hip.ptr(tag), 1, st()) == -1
     assert L.skr_adam_block_cold(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0, 0, _hip.ptr(tag), 1, st()) == -1
