@@ -694,22 +694,48 @@ __global__ __launch_bounds__(256) void adam_cold_rows_kernel(float* __restrict__
                 vv[u] = __builtin_nontemporal_load(&v[i]);
             }
         }
+        // rows at rest (4 of 5 cold rows): only the moments decay, 3 vector instructions per element and step -- as much
+        // vector-ALU time over the pass as the rows of ordinary magnitudes.  Neighbours (u, u + 1) that are both at rest
+        // decay together in packed fp32 (the same multiply and add on each half); a row whose moments are all zero
+        // (never touched) has nothing to decay.
+        bool rest[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            rest[u] = cold[u] && __builtin_amdgcn_ballot_w64(!lane_at_rest(pp[u], mm[u], vv[u], fabsf(a.neg_step_size[0]), a)) == 0;
+        auto store_rest = [&](int64_t i, float m0, float v0, float m1, float v1) {
+            if (__builtin_amdgcn_ballot_w64(__float_as_uint(m1) != __float_as_uint(m0)) != 0) __builtin_nontemporal_store(m1, &m[i]);
+            if (__builtin_amdgcn_ballot_w64(__float_as_uint(v1) != __float_as_uint(v0)) != 0) __builtin_nontemporal_store(v1, &v[i]);
+        };
+#pragma unroll
+        for (int u = 0; u + 1 < U; u += 2) {
+            if (!(rest[u] && rest[u + 1])) continue;
+            if (a.stats && lane == 0) atomicAdd(&a.stats[0], 2ull);
+            f32x2 m2{mm[u], mm[u + 1]}, v2{vv[u], vv[u + 1]};
+            if (__builtin_amdgcn_ballot_w64((__float_as_uint(m2.x) | __float_as_uint(m2.y) | __float_as_uint(v2.x) |
+                                             __float_as_uint(v2.y)) != 0) != 0) {
+                for (int s = 0; s < a.k; ++s) {
+                    // -m for (0 - m): a sign modifier on the multiply instead of an instruction.  They differ for m = +-0
+                    // only (+0 vs -0 into the product), and m + (+-0) is m, resp. +0 for m = +-0, either way
+                    m2 = m2 + a.one_minus_b1 * (-m2);
+                    v2 = v2 * a.b2;
+                }
+                store_rest(((b0 + u * n_waves) << 6) + lane, mm[u], vv[u], m2.x, v2.x);
+                store_rest(((b0 + (u + 1) * n_waves) << 6) + lane, mm[u + 1], vv[u + 1], m2.y, v2.y);
+            }
+            cold[u] = cold[u + 1] = false;      // done
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!cold[u]) continue;
             const int64_t i = ((b0 + u * n_waves) << 6) + lane;
-            const bool lane_rest = lane_at_rest(pp[u], mm[u], vv[u], fabsf(a.neg_step_size[0]), a);
-            if (__builtin_amdgcn_ballot_w64(!lane_rest) == 0) {
+            if (rest[u]) {
                 if (a.stats && lane == 0) atomicAdd(&a.stats[0], 1ull);
                 float m1 = mm[u], v1 = vv[u];
                 for (int s = 0; s < a.k; ++s) {
                     m1 = m1 + a.one_minus_b1 * (0.0f - m1);
                     v1 = v1 * a.b2;
                 }
-                if (__builtin_amdgcn_ballot_w64(__float_as_uint(m1) != __float_as_uint(mm[u])) != 0)
-                    __builtin_nontemporal_store(m1, &m[i]);
-                if (__builtin_amdgcn_ballot_w64(__float_as_uint(v1) != __float_as_uint(vv[u])) != 0)
-                    __builtin_nontemporal_store(v1, &v[i]);
+                store_rest(i, mm[u], vv[u], m1, v1);
                 continue;
             }
             const bool lane_ord = lane_ordinary(mm[u], vv[u], a);
