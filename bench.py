@@ -846,13 +846,21 @@ def main():
                 # it is launched on (pairs created before the timed region): the roofline averages over all of them, like
                 # rocprofv3 --stats of this command does
                 pair = cold_pool.pop() if (phase is not None and cold_pool) else None
+                if phase is None and epoch_probe is not None and 200 <= s0 // kblk < 400:    # diagnosis: blocks of a whole epoch
+                    pair = mk_pair()
+                    blk_pair = mk_pair()
+                    blk_pair[0].record(cur)
+                    epoch_probe.append((pair, blk_pair))
+                else:
+                    blk_pair = None
                 if pair is not None:
                     pair[0].record(side)
                 rc |= L.skr_adam_block_cold(P["flat"], P["m1"], P["m2"], n_par, 1e-3, 0.9, 0.999, 1e-8, run_slice.t, kk,
                                             blk_tag.data_ptr(), run_slice.serial, side.cuda_stream)
                 if pair is not None:
                     pair[1].record(side)
-                    cold_log.append((pair, kk, phase))
+                    if phase is not None:
+                        cold_log.append((pair, kk, phase))
                 ev_cold.record(side)
                 pblk, nblk = blk.data_ptr(), blk.numel()
                 if fused:
@@ -886,6 +894,8 @@ def main():
                                                    run_slice.t, pblk, nblk, 0, 64, blk_claim.data_ptr(), stream)
                 if rc:
                     _hip.check(rc)
+                if blk_pair is not None:
+                    blk_pair[1].record(cur)
                 keep_alive.append(blk)
             torch.cuda.current_stream().wait_event(ev_cold)
             return
@@ -994,6 +1004,8 @@ def main():
     for pair in event_pool + cold_pool:
         pair[0].record(); pair[1].record()       # first record creates the HIP event
     cold_log, step_events = [], []
+    # SKR_BENCH_EPOCH_PROBE=1: HIP events around the cold pass and around the step launches of 200 blocks of each whole epoch
+    epoch_probe = [] if os.environ.get("SKR_BENCH_EPOCH_PROBE") == "1" else None
     if pre is not None:
         run_slice(pre, n_pre, "pre")
     if W > 0:
@@ -1074,6 +1086,14 @@ def main():
         del neg_ahead
         box.clear()
         keep_alive.clear()
+        if epoch_probe:
+            torch.cuda.synchronize()
+            last = epoch_probe[-200:]            # the third epoch's blocks
+            print("[bench] epoch probe (third epoch, blocks 200-399): cold pass %.3f ms, step launches of a block %.3f ms, "
+                  "block start to next block start %.3f ms" % (
+                      float(np.mean([a_.elapsed_time(z_) for (a_, z_), _ in last])),
+                      float(np.mean([a_.elapsed_time(z_) for _, (a_, z_) in last])),
+                      float(np.mean([last[i][1][0].elapsed_time(last[i + 1][1][0]) for i in range(len(last) - 1)]))), file=sys.stderr)
         epoch_leg = {"interactions_per_sec": n_ep * b / te3, "seconds": te3, "steps": n_ep, "first_epoch_seconds": te,
                      "first_epoch_interactions_per_sec": n_ep * b / te,
                      "unpipelined_seconds": te, "epoch_drawing_ahead_too_seconds": te2,
