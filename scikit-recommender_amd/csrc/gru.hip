@@ -23,6 +23,7 @@ constexpr int G_SMALL_B = 2048;
 constexpr int G_T = 256;
 constexpr int G_KMAX = 256;    // in_dim + hid
 constexpr int G_HMAX = 128;
+constexpr int G_CH = 32;      // weights in flight per thread in the forward kernel (SKR tuning: 16 / 32 / 64)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float hidden_act(float x, int act) { return act == 0 ? tanhf(x) : fmaxf(x, 0.0f); }
@@ -72,12 +73,13 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
         float acc[ROWS];
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) acc[i] = 0.0f;
-        for (int k0 = 0; k0 < K; k0 += 16) {      // 16 weight loads in flight per thread; the tail is guarded
-            float w[16];
+        for (int k0 = 0; k0 < K; k0 += G_CH) {    // G_CH weight loads in flight per thread (the kernel is a chain of
+                                                  // K / G_CH L2 round trips per phase: 16 in flight gave 91 us per call at B = 128); tail guarded
+            float w[G_CH];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) w[q] = (k0 + q < K) ? Wg[static_cast<int64_t>(k0 + q) * C + j] : 0.0f;
+            for (int q = 0; q < G_CH; ++q) w[q] = (k0 + q < K) ? Wg[static_cast<int64_t>(k0 + q) * C + j] : 0.0f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
+            for (int q = 0; q < G_CH; ++q)
 #pragma unroll
                 for (int i = 0; i < ROWS; ++i)
                     if (i < per && k0 + q < K) acc[i] = fmaf(a[g0 + i * ng][k0 + q], w[q], acc[i]);
@@ -105,22 +107,22 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
         float acc[ROWS];
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) acc[i] = 0.0f;
-        for (int k0 = 0; k0 < IN; k0 += 16) {
-            float w[16];
+        for (int k0 = 0; k0 < IN; k0 += G_CH) {
+            float w[G_CH];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) w[q] = (k0 + q < IN) ? Wc[static_cast<int64_t>(k0 + q) * H + j] : 0.0f;
+            for (int q = 0; q < G_CH; ++q) w[q] = (k0 + q < IN) ? Wc[static_cast<int64_t>(k0 + q) * H + j] : 0.0f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
+            for (int q = 0; q < G_CH; ++q)
 #pragma unroll
                 for (int i = 0; i < ROWS; ++i)
                     if (i < per && k0 + q < IN) acc[i] = fmaf(a[g0 + i * ng][k0 + q], w[q], acc[i]);
         }
-        for (int k0 = 0; k0 < H; k0 += 16) {       // H is a multiple of 16
-            float w[16];
+        for (int k0 = 0; k0 < H; k0 += G_CH) {     // H is a multiple of 32
+            float w[G_CH];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) w[q] = Wc[static_cast<int64_t>(IN + k0 + q) * H + j];
+            for (int q = 0; q < G_CH; ++q) w[q] = Wc[static_cast<int64_t>(IN + k0 + q) * H + j];
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
+            for (int q = 0; q < G_CH; ++q)
 #pragma unroll
                 for (int i = 0; i < ROWS; ++i)
                     if (i < per) acc[i] = fmaf(rh[g0 + i * ng][k0 + q], w[q], acc[i]);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_weights_kernel(GruIn g, const flo
     if (t < n_g) {
         const int k = static_cast<int>(t / (2 * H)), j = static_cast<int>(t - static_cast<int64_t>(k) * 2 * H);
         float s = 0.0f;
-#pragma unroll 8
+#pragma unroll 32      // sessions in flight per thread: the loop is a chain of B / unroll L2 round trips
         for (int b = 0; b < g.B; ++b) {
             const float av = (k < IN) ? x_row(g, b)[k] : g.h[static_cast<int64_t>(b) * H + (k - IN)];
             s = fmaf(av, dgp[static_cast<int64_t>(b) * 2 * H + j], s);
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_weights_kernel(GruIn g, const flo
         const int64_t q = t - n_g;
         const int k = static_cast<int>(q / H), j = static_cast<int>(q - static_cast<int64_t>(k) * H);
         float s = 0.0f;
-#pragma unroll 8
+#pragma unroll 32      // sessions in flight per thread: the loop is a chain of B / unroll L2 round trips
         for (int b = 0; b < g.B; ++b) {
             const int64_t o = static_cast<int64_t>(b) * H + (k - IN);
             const float av = (k < IN) ? x_row(g, b)[k] : r_in[o] * g.h[o];

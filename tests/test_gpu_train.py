@@ -639,3 +639,19 @@ def test_blocked_adam_lists_may_hold_empty_slots():
     tag = torch.zeros(50, dtype=torch.int32, device="cuda")
     assert L.skr_adam_block_cold(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0, 65, _hip.ptr(tag), 1, st()) == -1
     assert L.skr_adam_block_cold(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0, 0, _hip.ptr(tag), 1, st()) == -1
+    # the one-launch step: k and s ranges, workspace capacity (slot numbers have 20 bits), NULL pointers
+    w = torch.zeros(9 * 64 * 64, device="cuda")
+    i32 = torch.zeros(64, dtype=torch.int32, device="cuda")
+    loss = torch.zeros(64, device="cuda")
+    fs = lambda cap, k, s_, meta=i32: L.skr_bpr_fused_step(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, _hip.ptr(w), cap, _hip.ptr(i32),  # noqa: E731
+                                                          _hip.ptr(i32), _hip.ptr(i32), _hip.ptr(meta) if meta is not None else None, 1,
+                                                          0, 10, 40, 1e-3, 0.9, 0.999, 1e-8, 0, k, s_, 1e-3, _hip.ptr(loss), st())
+    assert fs(64, 65, 0) == -1 and fs(64, 4, 4) == -1 and fs(64, 4, -1) == -1 and fs(0, 4, 0) == -1 and fs((1 << 20) + 1, 4, 0) == -1
+    assert fs(64, 4, 0, None) == -1
+    scratch = torch.zeros(28 * 50 // 8 + 1, dtype=torch.int64, device="cuda")
+    fp = lambda b_, k: L.skr_bpr_fused_plan(_hip.ptr(i32), _hip.ptr(i32), _hip.ptr(i32), b_, k, 0, 10, 40, 50, _hip.ptr(scratch),  # noqa: E731
+                                            _hip.ptr(i32), _hip.ptr(i32), _hip.ptr(i32), _hip.ptr(i32), st())
+    assert fp(1, 65) == -1 and fp(0, 1) == -1 and fp(1 << 18, 1) == -1          # k * 5 * n_batch beyond 2^20
+    assert L.skr_bpr_fused_end(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, _hip.ptr(w), 64, _hip.ptr(i32), _hip.ptr(i32), None, 1e-3, 0.9,
+                               0.999, 1e-8, 0, 4, st()) == -1
+    torch.cuda.synchronize()
