@@ -1120,6 +1120,8 @@ def main():
     if epoch_leg is not None:
         out["full_epoch"] = epoch_leg
     pmc_traffic, pmc_source = pmc_lookup()
+    if world > 1:
+        pmc_traffic = None       # the recorded counters belong to the N = 1 command: a shard's pass moves other bytes
     # ---- roofline of the dominant kernel (adam_kernel over the flat parameter buffer) ---------------
     # 7 fp32 per parameter per step (p,g,m,v in; p,m,v out).  For N > 1 the timed launch is the
     # replicated [V | b] part (the user part overlaps the all-reduce and is not bracketed by the events).
