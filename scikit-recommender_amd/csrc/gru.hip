@@ -15,6 +15,7 @@
 #include "skr_common.h"
 
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
@@ -47,7 +48,10 @@ __device__ __forceinline__ const float* x_row(const GruIn& g, int row) {
 // 16 sessions per workgroup, their [x, h] rows staged in LDS; a thread owns one output column and
 // 16 / (256 / columns) of the rows, so each weight is read once per workgroup from L2.
 // ------------------------------------------------------------------------------------------------
-template <int ROWS>
+// H (32 / 64 / 128) and ALIGNED (in_dim a multiple of G_CH) are template parameters so that every loop bound and the
+// thread -> (column, rows) mapping are compile-time: with runtime bounds and per-element guards the kernel compiled to
+// 33 k instructions (260 KB of code, four times the instruction cache) and took 91 us per call at B = 128.
+template <int ROWS, int H, bool ALIGNED>
 __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __restrict__ active,
                                                       const float* __restrict__ Wg, const float* __restrict__ bg,
                                                       const float* __restrict__ Wc, const float* __restrict__ bc, int act,
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
     __shared__ float rh[ROWS][G_HMAX];
     __shared__ float us[ROWS][G_HMAX];
     const int tid = threadIdx.x;
-    const int IN = g.in_dim, H = g.hid, K = IN + H;
+    const int IN = g.in_dim, K = IN + H;
     const int row0 = blockIdx.x * ROWS;
     for (int idx = tid; idx < ROWS * K; idx += G_T) {
         const int r = idx / K, k = idx - r * K;
@@ -67,81 +71,84 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
         a[r][k] = v;
     }
     __syncthreads();
-    {   // gates
-        const int C = 2 * H;
-        const int j = tid % C, g0 = tid / C, ng = G_T / C, per = ROWS / ng;   // ng <= 4 <= ROWS
-        float acc[ROWS];
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) acc[i] = 0.0f;
-        for (int k0 = 0; k0 < K; k0 += G_CH) {    // G_CH weight loads in flight per thread (the kernel is a chain of
-                                                  // K / G_CH L2 round trips per phase: 16 in flight gave 91 us per call at B = 128); tail guarded
+    // acc[i] += sum_k src[rows of this thread][k] * W[(w_row0 + k) * ld + j] for k in [0, n): G_CH weights in flight
+    auto accumulate = [&](auto& acc, auto per_c, const float (*src)[G_KMAX], int src_off, const float* __restrict__ W, int w_row0, int ld,
+                          int j, int g0, int ng, int n, bool aligned) {
+        constexpr int PER = decltype(per_c)::value;
+        int k0 = 0;
+        for (; k0 + G_CH <= n; k0 += G_CH) {
             float w[G_CH];
 #pragma unroll
-            for (int q = 0; q < G_CH; ++q) w[q] = (k0 + q < K) ? Wg[static_cast<int64_t>(k0 + q) * C + j] : 0.0f;
+            for (int q = 0; q < G_CH; ++q) w[q] = W[static_cast<int64_t>(w_row0 + k0 + q) * ld + j];
 #pragma unroll
             for (int q = 0; q < G_CH; ++q)
 #pragma unroll
-                for (int i = 0; i < ROWS; ++i)
-                    if (i < per && k0 + q < K) acc[i] = fmaf(a[g0 + i * ng][k0 + q], w[q], acc[i]);
+                for (int i = 0; i < PER; ++i) acc[i] = fmaf(src[g0 + i * ng][src_off + k0 + q], w[q], acc[i]);
         }
+        if (!aligned)
+            for (; k0 < n; ++k0) {
+                const float w = W[static_cast<int64_t>(w_row0 + k0) * ld + j];
+#pragma unroll
+                for (int i = 0; i < PER; ++i) acc[i] = fmaf(src[g0 + i * ng][src_off + k0], w, acc[i]);
+            }
+    };
+    {   // gates: C = 2H output columns, NG thread groups share the ROWS rows
+        constexpr int C = 2 * H, NG = G_T / C, PER = ROWS / NG;      // NG in {1, 2, 4} <= ROWS
+        const int j = tid % C, g0 = tid / C;
+        float acc[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) acc[i] = 0.0f;
+        accumulate(acc, std::integral_constant<int, PER>{}, a, 0, Wg, 0, C, j, g0, NG, ALIGNED ? K : IN, ALIGNED);
+        if (!ALIGNED) accumulate(acc, std::integral_constant<int, PER>{}, a, IN, Wg, IN, C, j, g0, NG, H, true);   // H is a multiple of G_CH
         const float b = bg[j];
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            if (i < per) {
-                const int r = g0 + i * ng, row = row0 + r;
-                const float s = sigmoidf_(acc[i] + b);
-                if (j < H) {
-                    rh[r][j] = s * a[r][IN + j];
-                    if (r_out && row < g.B) r_out[static_cast<int64_t>(row) * H + j] = s;
-                } else {
-                    us[r][j - H] = s;
-                    if (u_out && row < g.B) u_out[static_cast<int64_t>(row) * H + (j - H)] = s;
-                }
+        for (int i = 0; i < PER; ++i) {
+            const int r = g0 + i * NG, row = row0 + r;
+            const float s = sigmoidf_(acc[i] + b);
+            if (j < H) {
+                rh[r][j] = s * a[r][IN + j];
+                if (r_out && row < g.B) r_out[static_cast<int64_t>(row) * H + j] = s;
+            } else {
+                us[r][j - H] = s;
+                if (u_out && row < g.B) u_out[static_cast<int64_t>(row) * H + (j - H)] = s;
             }
         }
     }
     __syncthreads();
-    {   // candidate and new state
-        const int j = tid % H, g0 = tid / H, ng = G_T / H;
-        const int per = (ROWS >= ng) ? ROWS / ng : (g0 < ROWS ? 1 : 0);   // more thread groups than rows: the rest idle
-        float acc[ROWS];
+    {   // candidate and new state: H output columns
+        constexpr int NG = G_T / H, PER = (ROWS >= NG) ? ROWS / NG : 1;
+        const int j = tid % H;
+        const bool live = (ROWS >= NG) || (tid / H) < ROWS;             // more thread groups than rows: the rest idle
+        const int g0 = live ? tid / H : 0;
+        float acc[PER];
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) acc[i] = 0.0f;
-        for (int k0 = 0; k0 < IN; k0 += G_CH) {
-            float w[G_CH];
+        for (int i = 0; i < PER; ++i) acc[i] = 0.0f;
+        accumulate(acc, std::integral_constant<int, PER>{}, a, 0, Wc, 0, H, j, g0, NG, IN, ALIGNED);
+        // the recurrent half reads r*h: same [ROWS][.] shape as `a` is needed by the helper, so it lives in `a`'s h columns
+        // from here on (the old state is kept in registers first)
+        float ho[PER];
 #pragma unroll
-            for (int q = 0; q < G_CH; ++q) w[q] = (k0 + q < IN) ? Wc[static_cast<int64_t>(k0 + q) * H + j] : 0.0f;
+        for (int i = 0; i < PER; ++i) ho[i] = a[g0 + i * NG][IN + j];
+        __syncthreads();
+        if (live)
 #pragma unroll
-            for (int q = 0; q < G_CH; ++q)
-#pragma unroll
-                for (int i = 0; i < ROWS; ++i)
-                    if (i < per && k0 + q < IN) acc[i] = fmaf(a[g0 + i * ng][k0 + q], w[q], acc[i]);
-        }
-        for (int k0 = 0; k0 < H; k0 += G_CH) {     // H is a multiple of 32
-            float w[G_CH];
-#pragma unroll
-            for (int q = 0; q < G_CH; ++q) w[q] = Wc[static_cast<int64_t>(IN + k0 + q) * H + j];
-#pragma unroll
-            for (int q = 0; q < G_CH; ++q)
-#pragma unroll
-                for (int i = 0; i < ROWS; ++i)
-                    if (i < per) acc[i] = fmaf(rh[g0 + i * ng][k0 + q], w[q], acc[i]);
-        }
+            for (int i = 0; i < PER; ++i) a[g0 + i * NG][IN + j] = rh[g0 + i * NG][j];
+        __syncthreads();
+        accumulate(acc, std::integral_constant<int, PER>{}, a, IN, Wc, IN, H, j, g0, NG, H, true);
         const float b = bc[j];
+        if (live)
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            if (i < per) {
-                const int r = g0 + i * ng, row = row0 + r;
+            for (int i = 0; i < PER; ++i) {
+                const int r = g0 + i * NG, row = row0 + r;
                 if (row < g.B) {
                     const float c = hidden_act(acc[i] + b, act);
-                    const float ho = a[r][IN + j], u = us[r][j];
-                    float hn = u * ho + (1.0f - u) * c;
-                    if (active && !active[row]) hn = ho;        // finished history: the state is carried
+                    const float u = us[r][j];
+                    float hn = u * ho[i] + (1.0f - u) * c;
+                    if (active && !active[row]) hn = ho[i];        // finished history: the state is carried
                     if (c_out) c_out[static_cast<int64_t>(row) * H + j] = c;
                     h_new[static_cast<int64_t>(row) * H + j] = hn;
                 }
             }
-        }
     }
 }
 
@@ -150,7 +157,27 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
 //   dc~ = dh' (1-u) act'(c) ;  du~ = dh' (h - c) u (1-u) ;  d(rh) = dc~ Wc[in:,:]^T ;  dr~ = d(rh) h r (1-r)
 //   dx  = dc~ Wc[:in,:]^T + [dr~ | du~] Wg[:in,:]^T
 // ------------------------------------------------------------------------------------------------
-template <int ROWS>
+// sixteen per-lane partial sums -> their sixteen totals in 17 shuffles instead of 16 x 6: each butterfly step hands the
+// half of the values a lane does not keep to the partner that does.  Lane L ends with the total of value (L >> 2) & 15.
+__device__ __forceinline__ float reduce16(float (&v)[16], int lane) {
+    float w8[8], w4[4], w2[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w8[i] = (b5 ? v[8 + i] : v[i]) + __shfl_xor(b5 ? v[i] : v[8 + i], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = (b4 ? w8[4 + i] : w8[i]) + __shfl_xor(b4 ? w8[i] : w8[4 + i], 16, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w2[i] = (b3 ? w4[2 + i] : w4[i]) + __shfl_xor(b3 ? w4[i] : w4[2 + i], 8, 64);
+    float t = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 1, 64);
+    return t;
+}
+
+// The two products with TRANSPOSED weights are taken a weight row per wavefront, lanes along the row (coalesced reads, 16 / ROWS
+// rows in flight), partial products of all ROWS sessions reduced across the lanes by reduce16.  (A thread per (session,
+// output) walking along its weight row reads 64 different cache lines per wave instruction: 31 us per call at B = 128.)
+template <int ROWS, int H>
 __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float* __restrict__ Wg,
                                                            const float* __restrict__ Wc, int act,
                                                            const float* __restrict__ r_in, const float* __restrict__ u_in,
@@ -162,7 +189,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float*
     __shared__ float hh[ROWS][G_HMAX];
     __shared__ float rr[ROWS][G_HMAX];
     const int tid = threadIdx.x;
-    const int IN = g.in_dim, H = g.hid;
+    const int IN = g.in_dim;
     const int row0 = blockIdx.x * ROWS;
     for (int idx = tid; idx < ROWS * H; idx += G_T) {
         const int r = idx / H, j = idx - r * H, row = row0 + r;
@@ -181,24 +208,68 @@ __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float*
         rr[r][j] = vr;
     }
     __syncthreads();
-    for (int idx = tid; idx < ROWS * H; idx += G_T) {
-        const int r = idx / H, k = idx - r * H;
-        const float* w = Wc + static_cast<int64_t>(IN + k) * H;
-        float s = 0.0f;
-        for (int j = 0; j < H; ++j) s = fmaf(dcp[r][j], w[j], s);
-        const float rv = rr[r][k];
-        dg[r][k] = s * hh[r][k] * rv * (1.0f - rv);
+    const int lane = tid & 63, wv = tid >> 6;
+    constexpr int QN = 16 / ROWS;                      // weight rows per reduction group (ROWS is 4 or 16)
+    constexpr int EH = (H + 63) / 64, EG = (2 * H + 63) / 64;
+    const int vq = ((lane >> 2) & 15) / ROWS, vr_ = ((lane >> 2) & 15) % ROWS;     // the value this lane ends up holding
+    for (int k0 = wv * QN; k0 < H; k0 += (G_T / 64) * QN) {      // d(rh) = dc~ Wc[in:, :]^T ; dr~ = d(rh) h r (1 - r)
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            float w[EH];
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                const int j = lane + 64 * e;
+                const float x = Wc[static_cast<int64_t>(IN + k0 + q) * H + (j < H ? j : 0)];
+                w[e] = j < H ? x : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                float part = 0.0f;
+#pragma unroll
+                for (int e = 0; e < EH; ++e) part = fmaf(dcp[r][(lane + 64 * e) & (G_HMAX - 1)], w[e], part);
+                v[q * ROWS + r] = part;
+            }
+        }
+        const float total = reduce16(v, lane);
+        if ((lane & 3) == 0) {
+            const int k = k0 + vq;
+            const float rv = rr[vr_][k];
+            dg[vr_][k] = total * hh[vr_][k] * rv * (1.0f - rv);
+        }
     }
     __syncthreads();
-    for (int idx = tid; idx < ROWS * IN; idx += G_T) {
-        const int r = idx / IN, i = idx - r * IN, row = row0 + r;
-        if (row >= g.B) continue;
-        const float* wc = Wc + static_cast<int64_t>(i) * H;
-        const float* wg = Wg + static_cast<int64_t>(i) * 2 * H;
-        float s = 0.0f;
-        for (int j = 0; j < H; ++j) s = fmaf(dcp[r][j], wc[j], s);
-        for (int j = 0; j < 2 * H; ++j) s = fmaf(dg[r][j], wg[j], s);
-        dx_out[static_cast<int64_t>(row) * IN + i] = s;
+    for (int i0 = wv * QN; i0 < IN; i0 += (G_T / 64) * QN) {      // dx = dc~ Wc[:in, :]^T + [dr~ | du~] Wg[:in, :]^T
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            const int i = (i0 + q < IN) ? i0 + q : IN - 1;       // a row past the end is computed and not stored
+            float wc[EH], wg[EG];
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                const int j = lane + 64 * e;
+                const float x = Wc[static_cast<int64_t>(i) * H + (j < H ? j : 0)];
+                wc[e] = j < H ? x : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < EG; ++e) {
+                const int j = lane + 64 * e;
+                const float x = Wg[static_cast<int64_t>(i) * 2 * H + (j < 2 * H ? j : 0)];
+                wg[e] = j < 2 * H ? x : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                float part = 0.0f;
+#pragma unroll
+                for (int e = 0; e < EH; ++e) part = fmaf(dcp[r][(lane + 64 * e) & (G_HMAX - 1)], wc[e], part);
+#pragma unroll
+                for (int e = 0; e < EG; ++e) part = fmaf(dg[r][(lane + 64 * e) & (2 * G_HMAX - 1)], wg[e], part);
+                v[q * ROWS + r] = part;
+            }
+        }
+        const float total = reduce16(v, lane);
+        const int i = i0 + vq, row = row0 + vr_;
+        if ((lane & 3) == 0 && i < IN && row < g.B) dx_out[static_cast<int64_t>(row) * IN + i] = total;
     }
     for (int idx = tid; idx < ROWS * H; idx += G_T) {
         const int r = idx / H, j = idx - r * H, row = row0 + r;
@@ -522,12 +593,22 @@ int skr_gru_cell_fwd(const float* d_x, const int32_t* d_x_index, const float* d_
     GruIn g{d_x, d_x_index, d_h, B, in_dim, hid};
     // few sessions (a training batch): 4 rows per workgroup so that more than a handful of CUs work;
     // many (the inference sweep): 16 rows, each weight read once per 16 sessions
-    if (B <= G_SMALL_B)
-        hipLaunchKernelGGL(gru_fwd_kernel<4>, dim3((B + 3) / 4), dim3(G_T), 0, skr::as_stream(stream), g, d_active, d_Wg,
+    const bool aligned = in_dim % G_CH == 0;
+    auto launch = [&](auto rows_c, auto hid_c, auto al_c) {
+        constexpr int R = decltype(rows_c)::value, HH = decltype(hid_c)::value;
+        constexpr bool AL = decltype(al_c)::value;
+        hipLaunchKernelGGL((gru_fwd_kernel<R, HH, AL>), dim3((B + R - 1) / R), dim3(G_T), 0, skr::as_stream(stream), g, d_active, d_Wg,
                            d_bg, d_Wc, d_bc, hidden_act_kind, d_r, d_u, d_c, d_h_new);
-    else
-        hipLaunchKernelGGL(gru_fwd_kernel<G_ROWS>, dim3((B + G_ROWS - 1) / G_ROWS), dim3(G_T), 0, skr::as_stream(stream), g,
-                           d_active, d_Wg, d_bg, d_Wc, d_bc, hidden_act_kind, d_r, d_u, d_c, d_h_new);
+    };
+    auto by_align = [&](auto rows_c, auto hid_c) {
+        if (aligned) launch(rows_c, hid_c, std::true_type{}); else launch(rows_c, hid_c, std::false_type{});
+    };
+    auto by_hid = [&](auto rows_c) {
+        if (hid == 32) by_align(rows_c, std::integral_constant<int, 32>{});
+        else if (hid == 64) by_align(rows_c, std::integral_constant<int, 64>{});
+        else by_align(rows_c, std::integral_constant<int, 128>{});
+    };
+    if (B <= G_SMALL_B) by_hid(std::integral_constant<int, 4>{}); else by_hid(std::integral_constant<int, G_ROWS>{});
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
@@ -546,12 +627,17 @@ int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_
     GruIn g{d_x, d_x_index, d_h, B, in_dim, hid};
     float* dcp = d_work;                                   // [B, hid]
     float* dgp = d_work + static_cast<int64_t>(B) * hid;   // [B, 2 hid]
-    if (B <= G_SMALL_B)
-        hipLaunchKernelGGL(gru_bwd_rows_kernel<4>, dim3((B + 3) / 4), dim3(G_T), 0, st, g, d_Wg, d_Wc, hidden_act_kind, d_r,
+    auto rows = [&](auto rows_c, auto hid_c) {
+        constexpr int R = decltype(rows_c)::value, HH = decltype(hid_c)::value;
+        hipLaunchKernelGGL((gru_bwd_rows_kernel<R, HH>), dim3((B + R - 1) / R), dim3(G_T), 0, st, g, d_Wg, d_Wc, hidden_act_kind, d_r,
                            d_u, d_c, d_dh_new, dcp, dgp, d_dx);
-    else
-        hipLaunchKernelGGL(gru_bwd_rows_kernel<G_ROWS>, dim3((B + G_ROWS - 1) / G_ROWS), dim3(G_T), 0, st, g, d_Wg, d_Wc,
-                           hidden_act_kind, d_r, d_u, d_c, d_dh_new, dcp, dgp, d_dx);
+    };
+    auto by_hid = [&](auto rows_c) {
+        if (hid == 32) rows(rows_c, std::integral_constant<int, 32>{});
+        else if (hid == 64) rows(rows_c, std::integral_constant<int, 64>{});
+        else rows(rows_c, std::integral_constant<int, 128>{});
+    };
+    if (B <= G_SMALL_B) by_hid(std::integral_constant<int, 4>{}); else by_hid(std::integral_constant<int, G_ROWS>{});
     SKR_LAUNCH_CHECK();
     const int64_t n_out = static_cast<int64_t>(in_dim + hid) * 3 * hid + 3 * hid;
     hipLaunchKernelGGL(gru_bwd_weights_kernel, dim3(static_cast<unsigned>((n_out + G_T - 1) / G_T)), dim3(G_T), 0, st, g,
