@@ -595,18 +595,20 @@ class ShardedBPRMF(object):
             U, I, J = ub.view(kk, bsz), ib.view(kk, bsz), jb.view(kk, bsz)
             step_ids = unique_padded_rows(torch.cat([I, J], dim=1))
             opt = self.optimizer
+            # the loss sums are only reported: every step adds its part into its own row, ONE all-reduce per block sums the
+            # rows over the ranks (a collective per step just for them doubled the step's collectives)
+            lo = loss_out[:kk]
+            lo.zero_()
             for k in range(kk):
-                self.loss.zero_()
                 _hip.check(_hip.lib().skr_bpr_step_sharded(
                     _hip.ptr(self.user_rows), _hip.ptr(self.item_rows), _hip.ptr(self.item_bias), _hip.ptr(self.user_rows),
                     _hip.ptr(self.item_rows), _hip.ptr(U[k]), _hip.ptr(I[k]), _hip.ptr(J[k]), bsz, 1.0, self.reg, 1.0,
                     _hip.ptr(self._gU), _hip.ptr(self._gV), _hip.ptr(self._gb), _hip.ptr(self._gU), _hip.ptr(self._gV),
-                    _hip.ptr(self.loss), _hip.ptr(opt.touch), _hip.ptr(opt.grad) if opt.touch is not None else None,
+                    _hip.ptr(lo[k]), _hip.ptr(opt.touch), _hip.ptr(opt.grad) if opt.touch is not None else None,
                     world, rank, 1.0, _hip.stream()))
                 self._exchange_item_grads(bsz, None, None, ids=step_ids[k:k + 1])
-                self.ctx.all_reduce(self.loss)
-                loss_out[k] = self.loss
                 self.optimizer.hot_step()
+            self.ctx.all_reduce(lo)
         else:
             for k, (a, b) in enumerate(bounds):
                 self._step_grads(users[a:b], pos[a:b], neg[a:b])
