@@ -940,7 +940,7 @@ def main():
     # SKR_ADAM_BLOCK = k (default 32 = the most; N > 1 needs the sparse exchange): look k batches ahead and block the dense Adam; 1 = classic
     kblk = max(1, min(64, int(os.environ.get("SKR_ADAM_BLOCK", "32")))) if (world == 1 or exchange == "sparse") else 1
     # N = 1: the BPR batch and the hot rows' Adam in one launch per step (SKR_BPR_FUSED=0: two dependent launches)
-    fused = world == 1 and kblk > 1 and os.environ.get("SKR_BPR_FUSED", "1") != "0"
+    fused = world == 1 and kblk > 1 and os.environ.get("SKR_BPR_FUSED", "1") != "0" and kblk * 5 * b <= (1 << 20)
     if fused:
         f_cap = kblk * 5 * b
         f_work = torch.zeros(9 * f_cap * 64, device=dev)

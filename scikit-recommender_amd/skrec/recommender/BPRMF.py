@@ -161,9 +161,9 @@ class BPRMF(AbstractRecommender):
         n_full_blocks = (len(cu) // bsz) // kblk
         rows = n_full_blocks * kblk * bsz
         ids_all = block_ids(*(c[:rows].view(n_full_blocks, kblk, bsz) for c in (cu, ci, cj)), dim=2).view(n_full_blocks, -1) \
-            if n_full_blocks and not self.fused_step else None
+            if n_full_blocks and not (self.fused_step and kblk * 5 * bsz <= (1 << 20)) else None
         first = 0
-        if self.fused_step and n_full_blocks:
+        if self.fused_step and n_full_blocks and kblk * 5 * bsz <= (1 << 20):      # slot numbers have 20 bits
             # full blocks: ONE launch per step -- the hot rows' Adam is evaluated inside the BPR kernel (csrc/train.hip K2c)
             from .fused import FusedBlocks
             if self._fused is None:
