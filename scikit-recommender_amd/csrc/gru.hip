@@ -289,26 +289,39 @@ __global__ __launch_bounds__(G_T) void gru_bwd_weights_kernel(GruIn g, const flo
     const int IN = g.in_dim, H = g.hid, K = IN + H;
     const int64_t n_g = static_cast<int64_t>(K) * 2 * H, n_c = static_cast<int64_t>(K) * H;
     const int64_t t = static_cast<int64_t>(blockIdx.x) * G_T + threadIdx.x;
+    // sum over the sessions of A[b][k] * D[b * ld + j]; where A comes from is decided ONCE, outside the loop: a choice inside it
+    // (input or state column, gathered or dense input rows) kept the loads of consecutive sessions from being issued together
+    // (36 us per call at B = 128; the sums and their order are unchanged)
+    auto dot = [&](int k, const float* __restrict__ D, int ld, int j, const float* __restrict__ hsrc, const float* __restrict__ rsrc) {
+        float s = 0.0f;
+        if (k < IN) {
+            if (g.x_index) {
+#pragma unroll 32
+                for (int b = 0; b < g.B; ++b)
+                    s = fmaf(g.x[static_cast<int64_t>(g.x_index[b]) * IN + k], D[static_cast<int64_t>(b) * ld + j], s);
+            } else {
+#pragma unroll 32
+                for (int b = 0; b < g.B; ++b) s = fmaf(g.x[static_cast<int64_t>(b) * IN + k], D[static_cast<int64_t>(b) * ld + j], s);
+            }
+        } else if (rsrc) {
+#pragma unroll 32
+            for (int b = 0; b < g.B; ++b) {
+                const int64_t o = static_cast<int64_t>(b) * H + (k - IN);
+                s = fmaf(rsrc[o] * hsrc[o], D[static_cast<int64_t>(b) * ld + j], s);
+            }
+        } else {
+#pragma unroll 32
+            for (int b = 0; b < g.B; ++b) s = fmaf(hsrc[static_cast<int64_t>(b) * H + (k - IN)], D[static_cast<int64_t>(b) * ld + j], s);
+        }
+        return s;
+    };
     if (t < n_g) {
         const int k = static_cast<int>(t / (2 * H)), j = static_cast<int>(t - static_cast<int64_t>(k) * 2 * H);
-        float s = 0.0f;
-#pragma unroll 32      // sessions in flight per thread: the loop is a chain of B / unroll L2 round trips
-        for (int b = 0; b < g.B; ++b) {
-            const float av = (k < IN) ? x_row(g, b)[k] : g.h[static_cast<int64_t>(b) * H + (k - IN)];
-            s = fmaf(av, dgp[static_cast<int64_t>(b) * 2 * H + j], s);
-        }
-        gWg[t] += s;
+        gWg[t] += dot(k, dgp, 2 * H, j, g.h, nullptr);
     } else if (t < n_g + n_c) {
         const int64_t q = t - n_g;
         const int k = static_cast<int>(q / H), j = static_cast<int>(q - static_cast<int64_t>(k) * H);
-        float s = 0.0f;
-#pragma unroll 32      // sessions in flight per thread: the loop is a chain of B / unroll L2 round trips
-        for (int b = 0; b < g.B; ++b) {
-            const int64_t o = static_cast<int64_t>(b) * H + (k - IN);
-            const float av = (k < IN) ? x_row(g, b)[k] : r_in[o] * g.h[o];
-            s = fmaf(av, dcp[static_cast<int64_t>(b) * H + j], s);
-        }
-        gWc[q] += s;
+        gWc[q] += dot(k, dcp, H, j, g.h, r_in);
     } else if (t < n_g + n_c + 2 * H) {
         const int j = static_cast<int>(t - n_g - n_c);
         float s = 0.0f;
@@ -362,7 +375,8 @@ __device__ __forceinline__ float final_act_grad(float l, int kind) {  // through
 //     read ONCE (coalesced) into LDS and used by every session -- b * n_y dot products, n_y row reads.
 constexpr int L_TY = 16;
 
-__global__ __launch_bounds__(G_T) void session_logits_kernel(const float* __restrict__ out, int B, int H,
+template <int H>      // compile-time hidden size: index arithmetic by shifts, staging loads issued together
+__global__ __launch_bounds__(G_T) void session_logits_kernel(const float* __restrict__ out, int B, int /*hid*/,
                                                              const float* __restrict__ E, const float* __restrict__ bias,
                                                              const int32_t* __restrict__ Y, int n_y, int fact,
                                                              float* __restrict__ logits) {
@@ -476,7 +490,8 @@ __global__ __launch_bounds__(G_T) void session_rowloss_kernel(int B, int n_y, in
 constexpr int L_CY = 64;
 constexpr int L_CB = 16;
 
-__global__ __launch_bounds__(G_T) void session_dout_kernel(const float* __restrict__ dlogits, int B, int H,
+template <int H>
+__global__ __launch_bounds__(G_T) void session_dout_kernel(const float* __restrict__ dlogits, int B, int /*hid*/,
                                                            const float* __restrict__ E, const int32_t* __restrict__ Y,
                                                            int n_y, float* __restrict__ dout) {
     __shared__ float et[L_CY][G_HMAX];
@@ -492,21 +507,20 @@ __global__ __launch_bounds__(G_T) void session_dout_kernel(const float* __restri
         gl[r][y] = (b0 + r < B && y < ny) ? dlogits[static_cast<int64_t>(b0 + r) * n_y + y0 + y] : 0.0f;
     }
     __syncthreads();
-    const int d = tid % H, grp = tid / H, ng = G_T / H;      // ng in {2, 4, 8}: L_CB / ng sessions per thread
-    float acc[L_CB / 2];
+    constexpr int ng = G_T / H, per = L_CB / ng;             // ng in {2, 4, 8}: L_CB / ng sessions per thread
+    const int d = tid % H, grp = tid / H;
+    float acc[per];
 #pragma unroll
-    for (int i = 0; i < L_CB / 2; ++i) acc[i] = 0.0f;
-    const int per = L_CB / ng;
+    for (int i = 0; i < per; ++i) acc[i] = 0.0f;
     for (int y = 0; y < ny; ++y) {
         const float e = et[y][d];
 #pragma unroll
-        for (int i = 0; i < L_CB / 2; ++i)
-            if (i < per) acc[i] = fmaf(gl[grp + i * ng][y], e, acc[i]);
+        for (int i = 0; i < per; ++i) acc[i] = fmaf(gl[grp + i * ng][y], e, acc[i]);
     }
 #pragma unroll
-    for (int i = 0; i < L_CB / 2; ++i) {
+    for (int i = 0; i < per; ++i) {
         const int b = b0 + grp + i * ng;
-        if (i < per && b < B) atomicAdd(&dout[static_cast<int64_t>(b) * H + d], acc[i]);
+        if (b < B) atomicAdd(&dout[static_cast<int64_t>(b) * H + d], acc[i]);
     }
 }
 
@@ -520,8 +534,9 @@ __device__ __forceinline__ void mark_range(uint8_t* touch, const float* base, co
 // output-side gradients: one wavefront per target y.
 //   gE[Y[y]] += sum_b dlogits[b, y] out[b] + reg E[Y[y]] ;  gb[Y[y]] += sum_b dlogits[b, y] + reg bias[Y[y]]
 // (an item that occurs several times in Y is counted each time, like tf.gather's gradient and l2_loss)
+template <int H>
 __global__ __launch_bounds__(G_T) void session_out_grads_kernel(const float* __restrict__ dlogits,
-                                                                const float* __restrict__ out, int B, int H,
+                                                                const float* __restrict__ out, int B, int /*hid*/,
                                                                 const int32_t* __restrict__ Y, int n_y,
                                                                 const float* __restrict__ E, const float* __restrict__ bias,
                                                                 float reg, float* __restrict__ gE, float* __restrict__ gb,
@@ -536,11 +551,12 @@ __global__ __launch_bounds__(G_T) void session_out_grads_kernel(const float* __r
         const float mine = bl < B ? dlogits[static_cast<int64_t>(bl) * n_y + y] : 0.0f;
         colsum += mine;
         const int lim = (B - b0) < 64 ? (B - b0) : 64;
+#pragma unroll 16
         for (int k = 0; k < lim; ++k) {
-            const float gk = __shfl(mine, k, 64);
+            const float gk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), k));   // k is wave-uniform
             const float* o = out + static_cast<int64_t>(b0 + k) * H;
-            acc0 = fmaf(gk, lane < H ? o[lane] : 0.0f, acc0);
-            if (H > 64) acc1 = fmaf(gk, o[64 + lane], acc1);
+            acc0 = fmaf(gk, o[lane & (H - 1)], acc0);        // H < 64: lanes >= H repeat a row element and are not stored
+            if (H > 64) acc1 = fmaf(gk, o[(64 + lane) & (H - 1)], acc1);
         }
     }
     colsum = skr::wave_sum(colsum);
@@ -656,14 +672,22 @@ static int session_loss_launch(const float* d_out, int B, int hid, const float* 
     SKR_REQUIRE(final_act_kind >= 0 && final_act_kind <= 2, "There is not final_act named '%d'.", final_act_kind);
     SKR_REQUIRE(loss_kind == 0 || loss_kind == 1, "There is not loss named '%d'.", loss_kind);
     hipStream_t st = skr::as_stream(stream);
-    hipLaunchKernelGGL(session_logits_kernel, dim3((n_y + L_TY - 1) / L_TY), dim3(G_T), 0, st, d_out, B, hid, d_item_table,
+if (hid == 32) hipLaunchKernelGGL(session_logits_kernel<32>, dim3((n_y + L_TY - 1) / L_TY), dim3(G_T), 0, st, d_out, B, hid, d_item_table,
+                       d_item_bias, d_y, n_y, final_act_kind, d_dlogits);
+    else if (hid == 64) hipLaunchKernelGGL(session_logits_kernel<64>, dim3((n_y + L_TY - 1) / L_TY), dim3(G_T), 0, st, d_out, B, hid, d_item_table,
+                       d_item_bias, d_y, n_y, final_act_kind, d_dlogits);
+    else hipLaunchKernelGGL(session_logits_kernel<128>, dim3((n_y + L_TY - 1) / L_TY), dim3(G_T), 0, st, d_out, B, hid, d_item_table,
                        d_item_bias, d_y, n_y, final_act_kind, d_dlogits);
     SKR_LAUNCH_CHECK();
     hipLaunchKernelGGL(session_rowloss_kernel, dim3(B), dim3(G_T), 0, st, B, n_y, final_act_kind, loss_kind, bpr_reg,
                        d_dlogits, d_loss, pos_off, B_mean);
     SKR_LAUNCH_CHECK();
     SKR_HIP(hipMemsetAsync(d_dout, 0, static_cast<size_t>(B) * hid * sizeof(float), st));
-    hipLaunchKernelGGL(session_dout_kernel, dim3((n_y + L_CY - 1) / L_CY, (B + L_CB - 1) / L_CB), dim3(G_T), 0, st, d_dlogits,
+if (hid == 32) hipLaunchKernelGGL(session_dout_kernel<32>, dim3((n_y + L_CY - 1) / L_CY, (B + L_CB - 1) / L_CB), dim3(G_T), 0, st, d_dlogits,
+                       B, hid, d_item_table, d_y, n_y, d_dout);
+    else if (hid == 64) hipLaunchKernelGGL(session_dout_kernel<64>, dim3((n_y + L_CY - 1) / L_CY, (B + L_CB - 1) / L_CB), dim3(G_T), 0, st, d_dlogits,
+                       B, hid, d_item_table, d_y, n_y, d_dout);
+    else hipLaunchKernelGGL(session_dout_kernel<128>, dim3((n_y + L_CY - 1) / L_CY, (B + L_CB - 1) / L_CB), dim3(G_T), 0, st, d_dlogits,
                        B, hid, d_item_table, d_y, n_y, d_dout);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
@@ -691,7 +715,13 @@ int skr_session_out_grads(const float* d_dlogits, const float* d_out, int B, int
     SKR_REQUIRE(hid == 32 || hid == 64 || hid == 128, "skr_session_out_grads: hid must be 32, 64 or 128 (got %d)", hid);
     SKR_REQUIRE(B >= 1 && n_y >= 1, "skr_session_out_grads: empty batch");
     SKR_REQUIRE((d_touch == nullptr) == (d_touch_base == nullptr), "touch: both pointers or neither");
-    hipLaunchKernelGGL(session_out_grads_kernel, dim3((n_y + G_T / 64 - 1) / (G_T / 64)), dim3(G_T), 0,
+if (hid == 32) hipLaunchKernelGGL(session_out_grads_kernel<32>, dim3((n_y + G_T / 64 - 1) / (G_T / 64)), dim3(G_T), 0,
+                       skr::as_stream(stream), d_dlogits, d_out, B, hid, d_y, n_y, d_item_table, d_item_bias, reg, d_g_table,
+                       d_g_bias, d_touch, d_touch_base);
+    else if (hid == 64) hipLaunchKernelGGL(session_out_grads_kernel<64>, dim3((n_y + G_T / 64 - 1) / (G_T / 64)), dim3(G_T), 0,
+                       skr::as_stream(stream), d_dlogits, d_out, B, hid, d_y, n_y, d_item_table, d_item_bias, reg, d_g_table,
+                       d_g_bias, d_touch, d_touch_base);
+    else hipLaunchKernelGGL(session_out_grads_kernel<128>, dim3((n_y + G_T / 64 - 1) / (G_T / 64)), dim3(G_T), 0,
                        skr::as_stream(stream), d_dlogits, d_out, B, hid, d_y, n_y, d_item_table, d_item_bias, reg, d_g_table,
                        d_g_bias, d_touch, d_touch_base);
     SKR_LAUNCH_CHECK();
