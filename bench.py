@@ -864,14 +864,11 @@ def main():
                 ev_cold.record(side)
                 pblk, nblk = blk.data_ptr(), blk.numel()
                 if fused:
-                    for s in range(s0, s0 + kk):
-                        o = s * b * 4
-                        rc |= L.skr_bpr_fused_step(P["flat"], P["m1"], P["m2"], n_par, f_work.data_ptr(), f_cap, pu + o, pi + o, pj + o,
-                                                   f_meta[q].data_ptr() + 20 * (s - s0) * b, b, 0, nU, nU + nI, 1e-3, 0.9, 0.999, 1e-8,
-                                                   t0, kk, s - s0, 1e-3, P["loss"], stream)
+                    o = s0 * b * 4
+                    rc |= L.skr_bpr_fused_block(P["flat"], P["m1"], P["m2"], n_par, f_work.data_ptr(), f_cap, pu + o, pi + o, pj + o,
+                                                f_meta[q].data_ptr(), b, 0, nU, nU + nI, 1e-3, 0.9, 0.999, 1e-8, t0, kk, 1e-3, P["loss"], 0,
+                                                f_sb[q].data_ptr(), f_sf[q].data_ptr(), f_ns[q].data_ptr(), stream)
                     run_slice.t += kk
-                    rc |= L.skr_bpr_fused_end(P["flat"], P["m1"], P["m2"], n_par, f_work.data_ptr(), f_cap, f_sb[q].data_ptr(),
-                                              f_sf[q].data_ptr(), f_ns[q].data_ptr(), 1e-3, 0.9, 0.999, 1e-8, t0, kk, stream)
                     f_ev_done[q].record(torch.cuda.current_stream())
                     f_used[q] = True
                 for s in range(s0, s0 + kk) if not fused else ():
@@ -1080,6 +1077,7 @@ def main():
         t2e = time.perf_counter()
         th.start()
         run_slice(whole, n_ep, neg=neg_ahead)
+        te3_host = time.perf_counter() - t2e      # every launch of the epoch queued (the GPU may still be working)
         th.join()
         barrier()
         te3 = time.perf_counter() - t2e
@@ -1096,7 +1094,7 @@ def main():
                       float(np.mean([last[i][1][0].elapsed_time(last[i + 1][1][0]) for i in range(len(last) - 1)]))), file=sys.stderr)
         epoch_leg = {"interactions_per_sec": n_ep * b / te3, "seconds": te3, "steps": n_ep, "first_epoch_seconds": te,
                      "first_epoch_interactions_per_sec": n_ep * b / te,
-                     "unpipelined_seconds": te, "epoch_drawing_ahead_too_seconds": te2,
+                     "unpipelined_seconds": te, "epoch_drawing_ahead_too_seconds": te2, "host_queued_after_seconds": te3_host,
                      "note": "third of three consecutive full epochs (every row's moments aged by real training), pipelined as "
                              "BPRMF.fit() runs: its negatives were drawn during the previous epoch and it draws the next "
                              "epoch's while training; includes the epoch permutation.  first_epoch = sampling in line."}

@@ -387,6 +387,14 @@ int skr_bpr_fused_step(const float* d_p, const float* d_m, const float* d_v, int
 int skr_bpr_fused_end(float* d_p, float* d_m, float* d_v, int64_t n, float* d_work, int64_t cap, const int32_t* d_slot_block,
                       const int32_t* d_slot_fin, const int32_t* d_n_slots, float lr, float beta1, float beta2, float eps,
                       int64_t step_t0, int k, void* stream);
+/* The k skr_bpr_fused_step launches of a block (batch s at d_u / d_i / d_j + s * n_batch, its words at d_meta + 5 * s * n_batch, its
+ * loss sums at d_loss64 + s * loss_stride_floats) followed by skr_bpr_fused_end, in one call: the host side of a step is then a
+ * loop in C, not 24-argument calls from the caller's language. */
+int skr_bpr_fused_block(float* d_p, float* d_m, float* d_v, int64_t n, float* d_work, int64_t cap, const int32_t* d_u,
+                        const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch, int64_t user_block0,
+                        int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2, float eps, int64_t step_t0,
+                        int k, float reg, float* d_loss64, int64_t loss_stride_floats, const int32_t* d_slot_block,
+                        const int32_t* d_slot_fin, const int32_t* d_n_slots, void* stream);
 
 /* The cold pass sorts each 64-float block, by the values it starts from, into one of three exact evaluations of
  * the same k updates: AT REST (the update provably rounds to p + q == p for all k steps: only the moments decay),

@@ -1761,6 +1761,22 @@ int skr_bpr_fused_end(float* d_p, float* d_m, float* d_v, int64_t n, float* d_wo
     return SKR_OK;
 }
 
+int skr_bpr_fused_block(float* d_p, float* d_m, float* d_v, int64_t n, float* d_work, int64_t cap, const int32_t* d_u,
+                        const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch, int64_t user_block0,
+                        int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2, float eps, int64_t step_t0,
+                        int k, float reg, float* d_loss64, int64_t loss_stride_floats, const int32_t* d_slot_block,
+                        const int32_t* d_slot_fin, const int32_t* d_n_slots, void* stream) {
+    SKR_REQUIRE(k >= 1 && k <= AB_KMAX && n_batch >= 0 && loss_stride_floats >= 0, "skr_bpr_fused_block: bad shape");
+    for (int s = 0; s < k; ++s) {
+        const int64_t o = static_cast<int64_t>(s) * n_batch;
+        const int rc = skr_bpr_fused_step(d_p, d_m, d_v, n, d_work, cap, d_u + o, d_i + o, d_j + o, d_meta + 5 * o, n_batch, user_block0,
+                                          item_block0, bias_block0, lr, beta1, beta2, eps, step_t0, k, s, reg,
+                                          d_loss64 + s * loss_stride_floats, stream);
+        if (rc != SKR_OK) return rc;
+    }
+    return skr_bpr_fused_end(d_p, d_m, d_v, n, d_work, cap, d_slot_block, d_slot_fin, d_n_slots, lr, beta1, beta2, eps, step_t0, k, stream);
+}
+
 int skr_selftest_cold_math(uint64_t n_pairs, uint64_t* h_mismatches, void* stream) {
     SKR_REQUIRE(h_mismatches, "skr_selftest_cold_math: NULL argument");
     unsigned long long* d_bad = nullptr;

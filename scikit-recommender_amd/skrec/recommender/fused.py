@@ -123,7 +123,6 @@ class FusedBlocks(object):
         pp, pm, pv, n_par = opt.flat.data_ptr(), opt.m.data_ptr(), opt.v.data_ptr(), opt.flat.numel()
         pw, cap = self.work.data_ptr(), self.cap
         lr, (b1, b2), eps, reg = opt.lr, opt.betas, opt.eps, self.reg
-        fn = L.skr_bpr_fused_step
         self._plan_stream.wait_stream(cur)        # the columns were produced on the current stream
         if n_blocks > 0:
             self._plan(0, pu, pi, pj, k, bsz)
@@ -134,14 +133,9 @@ class FusedBlocks(object):
             cur.wait_event(self._ev_plan[q])
             opt.begin_block(self.slot_block[q, :n_ref], k)  # tags the hot blocks, starts the cold pass beside us
             t0 = opt.t
-            pmeta = self.meta[q].data_ptr()
-            rc = 0
-            for s in range(k):
-                os_ = o + 4 * s * bsz
-                rc |= fn(pp, pm, pv, n_par, pw, cap, pu + os_, pi + os_, pj + os_, pmeta + 20 * s * bsz, bsz, u0, i0, b0, lr, b1, b2,
-                         eps, t0, k, s, reg, ploss + (blk * k + s) * loss_stride_bytes, st)
-            rc |= L.skr_bpr_fused_end(pp, pm, pv, n_par, pw, cap, self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(),
-                                      self.n_slots[q].data_ptr(), lr, b1, b2, eps, t0, k, st)
+            rc = L.skr_bpr_fused_block(pp, pm, pv, n_par, pw, cap, pu + o, pi + o, pj + o, self.meta[q].data_ptr(), bsz, u0, i0, b0, lr,
+                                       b1, b2, eps, t0, k, reg, ploss + blk * k * loss_stride_bytes, loss_stride_bytes // 4,
+                                       self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(), self.n_slots[q].data_ptr(), st)
             self._ev_done[q].record(cur)
             self._used[q] = True
             opt.t = t0 + k

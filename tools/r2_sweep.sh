@@ -6,7 +6,7 @@ run() {
 import json,sys
 d=json.loads(open("gpurun_out/r2_sweep.json").read().strip().splitlines()[-1])
 r=d["roofline"]; e=d["full_epoch"]
-print(sys.argv[1].ljust(44), "value %.4g" % d["value"], "cold %.3f ms frac %.3f" % (r["avg_launch_ms"], r["frac"]), "epoch %.4g /s %.3f s first %.3f" % (e["interactions_per_sec"], e["seconds"], e["first_epoch_seconds"]))
+print(sys.argv[1].ljust(44), "value %.4g" % d["value"], "cold %.3f ms frac %.3f" % (r["avg_launch_ms"], r["frac"]), "epoch %.4g /s %.3f s (host queued %.3f) second %.3f first %.3f" % (e["interactions_per_sec"], e["seconds"], e["host_queued_after_seconds"], e["epoch_drawing_ahead_too_seconds"], e["first_epoch_seconds"]))
 PY
 }
-run X=0 && run SKR_FUSED_DBG=16 && run SKR_ADAM_BLOCK=64 && run SKR_COLD_BPC=2 && run SKR_COLD_BPC=3 && run SKR_FUSED_DBG=16 SKR_COLD_BPC=2 && run SKR_ADAM_BLOCK=48 && run SKR_BPR_FUSED=0 && run X=1
+for cfg in "$@"; do run $cfg || exit 1; done
