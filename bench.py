@@ -780,15 +780,22 @@ def main():
                 # step names the rows of its own batch and of the next one
                 ub, bi, bj = uu[lo:hi].view(kk, b), ii[lo:hi].view(kk, b), jj[lo:hi].view(kk, b)
                 return torch.cat([ub, bi + nU, bj + nU, (bi >> 6) + (nU + nI), (bj >> 6) + (nU + nI)], dim=1).reshape(-1)
-            def fused_plan(q, lo_, kk_):
-                if f_used[q]:
-                    f_plan_stream.wait_event(f_ev_done[q])      # the set's previous block has run
-                rc0 = L.skr_bpr_fused_plan(pu + 4 * lo_, pi + 4 * lo_, pj + 4 * lo_, b, kk_, 0, nU, nU + nI, (n_par + 63) // 64,
-                                           f_scratch.data_ptr(), f_meta[q].data_ptr(), f_sb[q].data_ptr(), f_sf[q].data_ptr(),
-                                           f_ns[q].data_ptr(), f_plan_stream.cuda_stream)
-                if rc0:
-                    _hip.check(rc0)
-                f_ev_plan[q].record(f_plan_stream)
+            if fused:
+                # ONE launch per step (csrc/train.hip K2c), through the class BPRMF.train_epoch uses: the next block's words and
+                # tags on a stream of their own, the cold pass and the write-back of the rows the next block does not touch
+                # on the side stream
+                f_opt.t = run_slice.t
+                f_opt.cold_timing = [] if phase is not None else None
+                nfull, rem = divmod(n_steps, kblk)
+                fb.run_blocks(pu, pi, pj, nfull, kblk, b, P["loss"], 0)
+                if rem:
+                    o = 4 * nfull * kblk * b
+                    fb.run_blocks(pu + o, pi + o, pj + o, 1, rem, b, P["loss"], 0)
+                f_opt.end_blocks()
+                run_slice.t = f_opt.t
+                if phase is not None:
+                    cold_log.extend(((e0_, e1_), kk_, phase) for e0_, e1_, kk_ in f_opt.cold_timing)
+                return
             if world == 1 and not fused:   # every full block of the slice in one vectorised op
                 nfull = n_steps // kblk
                 blk_all = block_ids(0, nfull * kblk * b, nfull * kblk).view(nfull, kblk * 5 * b)
@@ -817,18 +824,6 @@ def main():
                         blk = torch.cat([uu[lo:hi].view(kk, b), torch.where(every < 0, every, every + nU),
                                          torch.where(every < 0, every, (every >> 6) + (nU + nI))], dim=1).view(-1)
                         per = b + 4 * world * b
-                elif fused:
-                    # ONE launch per step (csrc/train.hip K2c, what BPRMF.train_epoch does at N = 1): the references' words of
-                    # the block first (four small launches); its slot table doubles as the list of hot blocks to tag
-                    # -- on a stream of their own, one block ahead, in two sets of buffers
-                    q = (s0 // kblk) & 1
-                    if s0 == 0:
-                        f_plan_stream.wait_stream(torch.cuda.current_stream())      # the columns come from the current stream
-                        fused_plan(q, lo, kk)
-                    if s0 + kblk < n_steps:
-                        fused_plan(q ^ 1, hi, min(kblk, n_steps - s0 - kblk))
-                    torch.cuda.current_stream().wait_event(f_ev_plan[q])
-                    blk = f_sb[q, :kk * 5 * b]
                 else:
                     blk = blk_all[s0 // kblk] if s0 // kblk < blk_all.shape[0] else block_ids(lo, hi, kk)
                     per = 5 * b
@@ -863,15 +858,7 @@ def main():
                         cold_log.append((pair, kk, phase))
                 ev_cold.record(side)
                 pblk, nblk = blk.data_ptr(), blk.numel()
-                if fused:
-                    o = s0 * b * 4
-                    rc |= L.skr_bpr_fused_block(P["flat"], P["m1"], P["m2"], n_par, f_work.data_ptr(), f_cap, pu + o, pi + o, pj + o,
-                                                f_meta[q].data_ptr(), b, 0, nU, nU + nI, 1e-3, 0.9, 0.999, 1e-8, t0, kk, 1e-3, P["loss"], 0,
-                                                f_sb[q].data_ptr(), f_sf[q].data_ptr(), f_ns[q].data_ptr(), stream)
-                    run_slice.t += kk
-                    f_ev_done[q].record(torch.cuda.current_stream())
-                    f_used[q] = True
-                for s in range(s0, s0 + kk) if not fused else ():
+                for s in range(s0, s0 + kk):
                     o = s * b * 4
                     rc |= L.skr_bpr_step_spread(P["U"], P["V"], P["bias"], P["U"], P["V"], pu + o, pi + o, pj + o, b, 1.0, 1e-3, 1.0,
                                          P["gU"], P["gV"], P["gb"], P["gU"], P["gV"], P["loss"], None, None, stream)
@@ -939,13 +926,11 @@ def main():
     # N = 1: the BPR batch and the hot rows' Adam in one launch per step (SKR_BPR_FUSED=0: two dependent launches)
     fused = world == 1 and kblk > 1 and os.environ.get("SKR_BPR_FUSED", "1") != "0" and kblk * 5 * b <= (1 << 20)
     if fused:
-        f_cap = kblk * 5 * b
-        f_work = torch.zeros(9 * f_cap * 64, device=dev)
-        f_meta, f_sb, f_sf = (torch.empty((2, f_cap), dtype=torch.int32, device=dev) for _ in range(3))
-        f_ns = torch.zeros((2, 1), dtype=torch.int32, device=dev)
-        f_plan_stream = torch.cuda.Stream(device=dev)
-        f_ev_plan, f_ev_done, f_used = [torch.cuda.Event(), torch.cuda.Event()], [torch.cuda.Event(), torch.cuda.Event()], [False, False]
-        f_scratch = torch.zeros(28 * ((n_par + 63) // 64) // 8 + 1, dtype=torch.int64, device=dev)
+        from skrec.recommender.base import DenseAdam
+        from skrec.recommender.fused import FusedBlocks
+        f_opt = DenseAdam(flat, lr=1e-3)
+        f_opt.grad, f_opt.m, f_opt.v = grad, m1, m2        # the loop's own buffers
+        fb = FusedBlocks(f_opt, 0, nU, nU + nI, 1e-3)
     blk_tag = torch.zeros((n_par + 63) // 64, dtype=torch.int32, device=dev)
     blk_claim = torch.zeros_like(blk_tag)
     keep_alive = []
@@ -1023,6 +1008,8 @@ def main():
     else:
         adam_ms = float(np.mean([a.elapsed_time(z) for a, z in step_events]))
     value = K * b * world / dt
+    if fused:       # the tags of the last block FusedBlocks ran
+        blk_tag, run_slice.serial = fb.tags[fb.last_q], fb.serial
     n_hot_blocks = int((blk_tag == run_slice.serial).sum()) if kblk > 1 else 0     # hot blocks of the last timed k-step block
     # the same pass ALONE on the chip (copies of the buffers, same tags, same step count): what the kernel does when it
     # does not share HBM and CUs with the step kernels -- its own quality, next to the live (overlapped) figure

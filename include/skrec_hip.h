@@ -384,17 +384,22 @@ int skr_bpr_fused_step(const float* d_p, const float* d_m, const float* d_v, int
                        const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch,
                        int64_t user_block0, int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2,
                        float eps, int64_t step_t0, int k, int s, float reg, float* d_loss64, void* stream);
+/* skr_bpr_fused_end, `which`: 0 every slot; with the NEXT block's tags (d_tag_next[flat block] == tag_next_value: the next block
+ * touches the row too -- skr_adam_block_mark of its slot table) 1 = only those rows, which the next block must find in the
+ * dense tables, 2 = only the others, which may be written back beside the next block's steps (another stream; they must be
+ * back before the next block's cold pass, and the two blocks then need workspaces of their own). */
 int skr_bpr_fused_end(float* d_p, float* d_m, float* d_v, int64_t n, float* d_work, int64_t cap, const int32_t* d_slot_block,
                       const int32_t* d_slot_fin, const int32_t* d_n_slots, float lr, float beta1, float beta2, float eps,
-                      int64_t step_t0, int k, void* stream);
+                      int64_t step_t0, int k, const int32_t* d_tag_next, int32_t tag_next_value, int which, void* stream);
 /* The k skr_bpr_fused_step launches of a block (batch s at d_u / d_i / d_j + s * n_batch, its words at d_meta + 5 * s * n_batch, its
- * loss sums at d_loss64 + s * loss_stride_floats) followed by skr_bpr_fused_end, in one call: the host side of a step is then a
+ * loss sums at d_loss64 + s * loss_stride_floats) followed by skr_bpr_fused_end (which = 1 when d_tag_next is given, else 0), in one call: the host side of a step is then a
  * loop in C, not 24-argument calls from the caller's language. */
 int skr_bpr_fused_block(float* d_p, float* d_m, float* d_v, int64_t n, float* d_work, int64_t cap, const int32_t* d_u,
                         const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch, int64_t user_block0,
                         int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2, float eps, int64_t step_t0,
                         int k, float reg, float* d_loss64, int64_t loss_stride_floats, const int32_t* d_slot_block,
-                        const int32_t* d_slot_fin, const int32_t* d_n_slots, void* stream);
+                        const int32_t* d_slot_fin, const int32_t* d_n_slots, const int32_t* d_tag_next, int32_t tag_next_value,
+                        void* stream);
 
 /* The cold pass sorts each 64-float block, by the values it starts from, into one of three exact evaluations of
  * the same k updates: AT REST (the update provably rounds to p + q == p for all k steps: only the moments decay),

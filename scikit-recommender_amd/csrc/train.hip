@@ -1071,11 +1071,15 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_fused_step_kernel(
 __global__ __launch_bounds__(256) void bpr_fused_end_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
                                                             int64_t n_par, FusedWork w, const int32_t* __restrict__ slot_blk,
                                                             const int32_t* __restrict__ slot_fin,
-                                                            const int32_t* __restrict__ n_slots, AdamBlockArgs a) {
+                                                            const int32_t* __restrict__ n_slots, AdamBlockArgs a,
+                                                            const int32_t* __restrict__ tag_next, int32_t tag_next_value, int which) {
     const int lane = threadIdx.x & 63;
     const int64_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= *n_slots) return;
     const int64_t blk = slot_blk[slot];
+    // which = 1: only the rows the NEXT block touches too (it must find them in the dense tables); 2: only the others (they
+    // can be written back beside the next block's steps); 0: all
+    if (which != 0 && ((tag_next[blk] == tag_next_value) != (which == 1))) return;
     const int fin = slot_fin[slot], nn = fin & 7, last = fin >> 8;
     FusedRow r;
     {
@@ -1750,13 +1754,14 @@ int skr_bpr_fused_plan(const int32_t* d_u, const int32_t* d_i, const int32_t* d_
 
 int skr_bpr_fused_end(float* d_p, float* d_m, float* d_v, int64_t n, float* d_work, int64_t cap, const int32_t* d_slot_block,
                       const int32_t* d_slot_fin, const int32_t* d_n_slots, float lr, float beta1, float beta2, float eps,
-                      int64_t step_t0, int k, void* stream) {
+                      int64_t step_t0, int k, const int32_t* d_tag_next, int32_t tag_next_value, int which, void* stream) {
     SKR_REQUIRE(d_p && d_m && d_v && d_work && d_slot_block && d_slot_fin && d_n_slots, "skr_bpr_fused_end: NULL argument");
     SKR_REQUIRE(n >= 0 && cap >= 1 && cap <= (1 << FUSED_SLOT_BITS), "skr_bpr_fused_end: need 1 <= cap <= 2^%d", FUSED_SLOT_BITS);
     SKR_REQUIRE(step_t0 >= 0 && k >= 1 && k <= AB_KMAX, "skr_bpr_fused_end: need 1 <= k <= %d", AB_KMAX);
+    SKR_REQUIRE(which >= 0 && which <= 2 && (which == 0 || d_tag_next), "skr_bpr_fused_end: which must be 0, or 1 / 2 with the next block's tags");
     const AdamBlockArgs& a = fused_block_args(lr, beta1, beta2, eps, step_t0, k);
     hipLaunchKernelGGL(bpr_fused_end_kernel, dim3(static_cast<unsigned>((cap + 3) / 4)), dim3(256), 0, skr::as_stream(stream), d_p,
-                       d_m, d_v, n, fused_work(d_work, cap), d_slot_block, d_slot_fin, d_n_slots, a);
+                       d_m, d_v, n, fused_work(d_work, cap), d_slot_block, d_slot_fin, d_n_slots, a, d_tag_next, tag_next_value, which);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
@@ -1765,7 +1770,8 @@ int skr_bpr_fused_block(float* d_p, float* d_m, float* d_v, int64_t n, float* d_
                         const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch, int64_t user_block0,
                         int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2, float eps, int64_t step_t0,
                         int k, float reg, float* d_loss64, int64_t loss_stride_floats, const int32_t* d_slot_block,
-                        const int32_t* d_slot_fin, const int32_t* d_n_slots, void* stream) {
+                        const int32_t* d_slot_fin, const int32_t* d_n_slots, const int32_t* d_tag_next, int32_t tag_next_value,
+                        void* stream) {
     SKR_REQUIRE(k >= 1 && k <= AB_KMAX && n_batch >= 0 && loss_stride_floats >= 0, "skr_bpr_fused_block: bad shape");
     for (int s = 0; s < k; ++s) {
         const int64_t o = static_cast<int64_t>(s) * n_batch;
@@ -1774,7 +1780,8 @@ int skr_bpr_fused_block(float* d_p, float* d_m, float* d_v, int64_t n, float* d_
                                           d_loss64 + s * loss_stride_floats, stream);
         if (rc != SKR_OK) return rc;
     }
-    return skr_bpr_fused_end(d_p, d_m, d_v, n, d_work, cap, d_slot_block, d_slot_fin, d_n_slots, lr, beta1, beta2, eps, step_t0, k, stream);
+    return skr_bpr_fused_end(d_p, d_m, d_v, n, d_work, cap, d_slot_block, d_slot_fin, d_n_slots, lr, beta1, beta2, eps, step_t0, k,
+                             d_tag_next, tag_next_value, d_tag_next ? 1 : 0, stream);
 }
 
 int skr_selftest_cold_math(uint64_t n_pairs, uint64_t* h_mismatches, void* stream) {

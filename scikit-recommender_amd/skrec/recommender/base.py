@@ -95,11 +95,7 @@ class DenseAdam(object):
             self._blk_claim = torch.zeros(nb, dtype=torch.int32, device=self.flat.device)
             self._blk_serial = 0
         cur = torch.cuda.current_stream()
-        if getattr(self, "_side", None) is None:
-            import os
-            self._side = torch.cuda.Stream(device=self.flat.device) if os.environ.get("SKR_ADAM_OVERLAP", "1") != "0" else cur
-            self._ev_marked, self._ev_cold = torch.cuda.Event(), torch.cuda.Event()
-        else:
+        if not self._ensure_side():
             cur.wait_event(self._ev_cold)    # the previous block's cold pass still reads the tags and writes cold rows
         assert per_step is None or block_ids.numel() == int(k) * int(per_step)
         self._blk_serial += 1
@@ -110,20 +106,38 @@ class DenseAdam(object):
         # k small bpr / hot-step launches
         self._ev_marked.record(cur)
         self._side.wait_event(self._ev_marked)
+        self.launch_cold(self._blk_tag, self._blk_serial, int(k))
+        self._hot = (L.skr_adam_block_hot, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                     self.flat.numel(), block_ids.data_ptr(), block_ids.numel(), self._blk_claim.data_ptr(), st,
+                     self.t, int(k), None if per_step is None else int(per_step))
+
+    def _ensure_side(self):
+        """the side stream of the cold passes and its events; True when they were created by this call"""
+        import os
+        import torch
+        if getattr(self, "_side", None) is not None:
+            return False
+        cur = torch.cuda.current_stream()
+        self._side = torch.cuda.Stream(device=self.flat.device) if os.environ.get("SKR_ADAM_OVERLAP", "1") != "0" else cur
+        self._ev_marked, self._ev_cold = torch.cuda.Event(), torch.cuda.Event()
+        return True
+
+    def launch_cold(self, tag, serial, k):
+        """the cold pass of a k-step block that starts at step self.t, on the side stream (the caller has made that stream
+        wait for whatever the pass depends on); records ``_ev_cold`` behind it"""
+        import torch
+        from .. import _hip
         timing = getattr(self, "cold_timing", None)     # measurement hook (bench.py): a list that receives (start, end, k)
         if timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(self._side)
-        _hip.check(L.skr_adam_block_cold(_hip.ptr(self.flat), _hip.ptr(self.m), _hip.ptr(self.v), self.flat.numel(), self.lr,
-                                         self.betas[0], self.betas[1], self.eps, self.t, int(k), _hip.ptr(self._blk_tag),
-                                         self._blk_serial, self._side.cuda_stream))
+        _hip.check(_hip.lib().skr_adam_block_cold(_hip.ptr(self.flat), _hip.ptr(self.m), _hip.ptr(self.v), self.flat.numel(), self.lr,
+                                                  self.betas[0], self.betas[1], self.eps, self.t, int(k), _hip.ptr(tag),
+                                                  int(serial), self._side.cuda_stream))
         if timing is not None:
             e1.record(self._side)
             timing.append((e0, e1, int(k)))
         self._ev_cold.record(self._side)
-        self._hot = (L.skr_adam_block_hot, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                     self.flat.numel(), block_ids.data_ptr(), block_ids.numel(), self._blk_claim.data_ptr(), st,
-                     self.t, int(k), None if per_step is None else int(per_step))
 
     def end_blocks(self):
         """join the side stream: call after the last block, before anything else reads the parameters"""

@@ -70,13 +70,24 @@ def build_fused_meta(cu, ci, cj, n_blocks, k, bsz, user_block0, item_block0, bia
 
 
 class FusedBlocks(object):
-    """Runs k-step blocks of full batches through ``skr_bpr_fused_step``: per block the references' words
-    (``skr_bpr_fused_plan``, four small launches on a stream of their own, one block ahead), the tags + the cold pass of
-    ``DenseAdam.begin_block`` (side stream), k step launches, one end launch.
+    """Runs k-step blocks of full batches through ``skr_bpr_fused_step``.  Three streams:
 
-    ``opt``: the model's DenseAdam over the flat [U | V | bias] buffer; table offsets in 64-float blocks."""
+    * planning stream: block n + 1's words (``skr_bpr_fused_plan``) and its hot-block tags, while block n runs;
+    * current stream: the k step launches of block n, then the write-back of the rows block n + 1 touches too;
+    * the optimiser's side stream: block n's cold pass, then the write-back of the REST of block n's rows (beside block
+      n + 1's steps, before block n + 1's cold pass, which updates those rows).
+
+    Two sets of words / slot tables / tags / workspaces alternate, so that a block's leftovers can be written back while the
+    next block accumulates.  ``opt``: the model's DenseAdam over the flat [U | V | bias] buffer; table offsets in 64-float
+    blocks.
+
+    The split write-back is OFF by default (``SKR_FUSED_SPLIT_END=1`` turns it on): it takes 50 of the write-back's 63 us
+    off the current stream, but the side stream -- whose cold pass (0.54 ms of a 0.70 ms block in the steady state of an
+    epoch) is the other bound -- gets them, and the next cold pass starts that much later: an epoch took 1.19 s instead of
+    1.09 s.  Without it the whole write-back runs on the current stream after the block's last step."""
 
     def __init__(self, opt, user_block0, item_block0, bias_block0, reg):
+        import os
         self.opt = opt
         self.offsets = (int(user_block0), int(item_block0), int(bias_block0))
         self.reg = float(reg)
@@ -84,30 +95,40 @@ class FusedBlocks(object):
         dev = opt.flat.device
         self.n_flat_blocks = (opt.flat.numel() + 63) // 64
         self.scratch = torch.zeros(28 * self.n_flat_blocks // 8 + 1, dtype=torch.int64, device=dev)   # zero between calls
+        self.tags = torch.zeros((2, self.n_flat_blocks), dtype=torch.int32, device=dev)
+        self.serial = 0
+        self.split_end = os.environ.get("SKR_FUSED_SPLIT_END", "0") == "1"
+        self._plan_stream = torch.cuda.Stream(device=dev)
+        self._ev_plan = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ev_block = torch.cuda.Event()
+        self._used = [False, False]
 
     def _size(self, k, bsz):
         cap = k * 5 * bsz
         if cap > self.cap:
             dev = self.opt.flat.device
+            torch.cuda.synchronize(dev)               # nothing in flight refers to the buffers that are replaced
             self.cap = cap
-            self.work = torch.zeros(9 * cap * 64, dtype=torch.float32, device=dev)     # zero: the invariant between blocks
-            # two sets of the references' words / slot tables: block n + 1 is planned (side stream) while block n runs
+            self.work = torch.zeros((2, 9 * cap * 64), dtype=torch.float32, device=dev)   # zero: the invariant between blocks
             self.meta, self.slot_block, self.slot_fin = (torch.empty((2, cap), dtype=torch.int32, device=dev) for _ in range(3))
             self.n_slots = torch.zeros((2, 1), dtype=torch.int32, device=dev)
-            self._plan_stream = torch.cuda.Stream(device=dev)
-            self._ev_plan = [torch.cuda.Event(), torch.cuda.Event()]
-            self._ev_done = [torch.cuda.Event(), torch.cuda.Event()]
             self._used = [False, False]
 
-    def _plan(self, q, pu, pi, pj, k, bsz):
-        """references' words of one block into buffer set q, on the planning stream"""
+    def _plan(self, q, pu, pi, pj, k, bsz, serial):
+        """words, slot tables and hot-block tags of one block into set q, on the planning stream"""
         u0, i0, b0 = self.offsets
-        ps = self._plan_stream
+        ps, L = self._plan_stream, _hip.lib()
         if self._used[q]:
-            ps.wait_event(self._ev_done[q])       # the set's previous block has run
-        rc = _hip.lib().skr_bpr_fused_plan(pu, pi, pj, bsz, k, u0, i0, b0, self.n_flat_blocks, self.scratch.data_ptr(),
-                                           self.meta[q].data_ptr(), self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(),
-                                           self.n_slots[q].data_ptr(), ps.cuda_stream)
+            ps.wait_event(self._ev_done[q])       # the set's previous block is done with its tables and its workspace
+        # the tags of set q were last read by the cold pass of the set's previous block (and by the write-backs of the
+        # block before that one, which sit in front of it on the side stream)
+        ps.wait_event(self.opt._ev_cold)
+        rc = L.skr_bpr_fused_plan(pu, pi, pj, bsz, k, u0, i0, b0, self.n_flat_blocks, self.scratch.data_ptr(),
+                                  self.meta[q].data_ptr(), self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(),
+                                  self.n_slots[q].data_ptr(), ps.cuda_stream)
+        rc |= L.skr_adam_block_mark(self.slot_block[q].data_ptr(), k * 5 * bsz, 0, 64, self.tags[q].data_ptr(), serial, None,
+                                    self.opt.t, ps.cuda_stream)
         if rc:
             _hip.check(rc)
         self._ev_plan[q].record(ps)
@@ -115,29 +136,61 @@ class FusedBlocks(object):
     def run_blocks(self, pu, pi, pj, n_blocks, k, bsz, ploss, loss_stride_bytes):
         """n_blocks * k batches of bsz triples each at the device addresses pu / pi / pj (int32, step-major); the loss sums
         of step s go to ploss + s * loss_stride_bytes (SKR_LOSS_SLOTS pairs of floats each)"""
+        if n_blocks <= 0:
+            return
         opt, L, st = self.opt, _hip.lib(), _hip.stream()
         self._size(k, bsz)
         cur = torch.cuda.current_stream()
-        n_ref, blk_bytes = k * 5 * bsz, 4 * k * bsz
+        if opt._ensure_side():
+            opt._ev_cold.record(cur)              # nothing to wait for yet
+        side = opt._side
+        blk_bytes = 4 * k * bsz
         u0, i0, b0 = self.offsets
         pp, pm, pv, n_par = opt.flat.data_ptr(), opt.m.data_ptr(), opt.v.data_ptr(), opt.flat.numel()
-        pw, cap = self.work.data_ptr(), self.cap
+        cap = self.cap
         lr, (b1, b2), eps, reg = opt.lr, opt.betas, opt.eps, self.reg
         self._plan_stream.wait_stream(cur)        # the columns were produced on the current stream
-        if n_blocks > 0:
-            self._plan(0, pu, pi, pj, k, bsz)
+        side.wait_stream(cur)                     # ... and whatever wrote the tables before is on it too
+        serial0 = self.serial + 1
+        self.serial += n_blocks
+        self._plan(0, pu, pi, pj, k, bsz, serial0)
         for blk in range(n_blocks):
             q, o = blk & 1, blk * blk_bytes
-            if blk + 1 < n_blocks:
-                self._plan(q ^ 1, pu + o + blk_bytes, pi + o + blk_bytes, pj + o + blk_bytes, k, bsz)
-            cur.wait_event(self._ev_plan[q])
-            opt.begin_block(self.slot_block[q, :n_ref], k)  # tags the hot blocks, starts the cold pass beside us
+            more = blk + 1 < n_blocks
+            if more:
+                self._plan(q ^ 1, pu + o + blk_bytes, pi + o + blk_bytes, pj + o + blk_bytes, k, bsz, serial0 + blk + 1)
+            cur.wait_event(self._ev_plan[q])      # this block's words and tags
+            cur.wait_event(opt._ev_cold)          # the previous cold pass wrote rows this block may read
+            if self._used[q]:
+                cur.wait_event(self._ev_done[q])  # the set's workspace: its previous block's leftovers are written back
+            side.wait_event(self._ev_plan[q])
+            opt.launch_cold(self.tags[q], serial0 + blk, k)          # behind the previous block's write-back on that stream
             t0 = opt.t
+            split = more and self.split_end
+            if split:
+                cur.wait_event(self._ev_plan[q ^ 1])                 # the next block's tags decide what is written back where
+            ptag = self.tags[q ^ 1].data_ptr() if split else None
+            pw = self.work[q].data_ptr()
             rc = L.skr_bpr_fused_block(pp, pm, pv, n_par, pw, cap, pu + o, pi + o, pj + o, self.meta[q].data_ptr(), bsz, u0, i0, b0, lr,
                                        b1, b2, eps, t0, k, reg, ploss + blk * k * loss_stride_bytes, loss_stride_bytes // 4,
-                                       self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(), self.n_slots[q].data_ptr(), st)
-            self._ev_done[q].record(cur)
+                                       self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(), self.n_slots[q].data_ptr(),
+                                       ptag, serial0 + blk + 1, st)
+            self._ev_block.record(cur)
+            side.wait_event(self._ev_block)       # the next cold pass updates rows this block has just written back
+            if split:
+                # the rows the next block does not touch go back beside its steps, in front of its cold pass
+                side.wait_event(self._ev_plan[q ^ 1])
+                rc |= L.skr_bpr_fused_end(pp, pm, pv, n_par, pw, cap, self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(),
+                                          self.n_slots[q].data_ptr(), lr, b1, b2, eps, t0, k, ptag, serial0 + blk + 1, 2,
+                                          side.cuda_stream)
+                self._ev_done[q].record(side)
+            else:
+                self._ev_done[q].record(cur)
             self._used[q] = True
+            self.last_q = q
             opt.t = t0 + k
             if rc:
                 _hip.check(rc)
+        if self.split_end and n_blocks > 1:
+            # the last write-back on the side stream is in front of nothing: make the optimiser's event cover it
+            opt._ev_cold.record(side)

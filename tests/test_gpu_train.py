@@ -419,7 +419,7 @@ def test_fused_step_is_bit_identical(k, n_blocks, t0):
     a, c, la, lc, fb = _fused_case(k, n_blocks, t0, True, 300 + k)
     assert int((a.flat != c.flat).sum()) == 0
     assert torch.equal(a.m, c.m) and torch.equal(a.v, c.v)
-    assert float(fb.work[6 * fb.cap * 64:].abs().max()) == 0.0          # every gradient was consumed, the buffers are clear
+    assert float(fb.work[:, 6 * fb.cap * 64:].abs().max()) == 0.0          # every gradient was consumed, the buffers are clear
     np.testing.assert_allclose(la.cpu().numpy(), lc.cpu().numpy(), rtol=1e-5)
 
 
@@ -480,7 +480,7 @@ def test_fused_step_with_rows_shared_inside_a_step(k, n_blocks):
     np.testing.assert_allclose(c.m.cpu().numpy(), a.m.cpu().numpy(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(c.v.cpu().numpy(), a.v.cpu().numpy(), rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(la.cpu().numpy(), lc.cpu().numpy(), rtol=1e-4)
-    assert float(fb.work[6 * fb.cap * 64:].abs().max()) == 0.0
+    assert float(fb.work[:, 6 * fb.cap * 64:].abs().max()) == 0.0
 
 
 @pytest.mark.gpu
@@ -653,5 +653,7 @@ def test_blocked_adam_lists_may_hold_empty_slots():
                                             _hip.ptr(i32), _hip.ptr(i32), _hip.ptr(i32), _hip.ptr(i32), st())
     assert fp(1, 65) == -1 and fp(0, 1) == -1 and fp(1 << 18, 1) == -1          # k * 5 * n_batch beyond 2^20
     assert L.skr_bpr_fused_end(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, _hip.ptr(w), 64, _hip.ptr(i32), _hip.ptr(i32), None, 1e-3, 0.9,
-                               0.999, 1e-8, 0, 4, st()) == -1
+                               0.999, 1e-8, 0, 4, None, 0, 0, st()) == -1
+    assert L.skr_bpr_fused_end(_hip.ptr(p), _hip.ptr(m), _hip.ptr(v), n, _hip.ptr(w), 64, _hip.ptr(i32), _hip.ptr(i32), _hip.ptr(i32), 1e-3,
+                               0.9, 0.999, 1e-8, 0, 4, None, 0, 1, st()) == -1          # which = 1 needs the next block's tags
     torch.cuda.synchronize()

@@ -50,7 +50,7 @@ for blk in range(n_blocks):
                                    1e-8, t, k, s, 1e-3, loss.data_ptr(), st)
     e[2].record()
     rc |= L.skr_bpr_fused_end(flat.data_ptr(), m1.data_ptr(), m2.data_ptr(), n_par, work.data_ptr(), cap, sb.data_ptr(), sf.data_ptr(),
-                              ns.data_ptr(), 1e-3, 0.9, 0.999, 1e-8, t, k, st)
+                              ns.data_ptr(), 1e-3, 0.9, 0.999, 1e-8, t, k, None, 0, 0, st)
     e[3].record()
     _hip.check(rc)
     t += k
