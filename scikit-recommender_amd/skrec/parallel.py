@@ -40,7 +40,9 @@ class DistContext(object):
 
     @property
     def active(self):
-        return self.world > 1
+        # SKR_DIST_FORCE_ACTIVE=1: a one-rank group still goes through every collective (rehearsal of the RCCL calls on a
+        # box with one GPU: tests/test_gpu_dist.py::test_fit_on_a_single_rank_rccl_group)
+        return self.world > 1 or os.environ.get("SKR_DIST_FORCE_ACTIVE") == "1"
 
     def owned_users(self, num_users):
         return np.arange(self.rank, num_users, self.world, dtype=np.int64)
@@ -84,7 +86,7 @@ def init_from_env():
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("SKR_DIST_FORCE_ACTIVE") == "1") and not dist.is_initialized():
         local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         backend = os.environ.get("SKR_DIST_BACKEND", "nccl")

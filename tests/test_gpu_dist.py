@@ -91,10 +91,10 @@ def test_sharded_lightgcn_replays_reference(world, plan, monkeypatch):
         assert np.array_equal(res[0]["V1"], res[1]["V1"])
 
 
-def _api_worker(rank, world, port, data_dir, workdir, ret):
+def _api_worker(rank, world, port, data_dir, workdir, ret, backend="gloo"):
     """what `torchrun ... run_skrec.py --recommender LightGCN` does on every rank"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
-                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo")
+                      WORLD_SIZE=str(world), SKR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     os.chdir(workdir)
     import random
     from skrec import RunConfig
@@ -158,7 +158,7 @@ def _bprmf_worker(rank, world, port, data_dir, workdir, exchange, ret, backend="
     rc = RunConfig(recommender="BPRMF", data_dir=data_dir, file_column="UIRT", sep="\t",
                    metric=("Precision", "Recall", "MAP", "NDCG", "MRR"), top_k=(5, 10, 20), test_batch_size=16, seed=2021)
     m = BPRMF(rc, dict(lr=1e-3, reg=1e-3, n_dim=64, batch_size=256, epochs=3))
-    assert m.engine is not None and m.engine.n_local in (32, 22, 21)
+    assert m.engine is not None and m.engine.n_local in (64, 32, 22, 21)
     reports, losses = [], []
     ev, te = m.evaluate, m.train_epoch
 
@@ -218,9 +218,9 @@ def test_bprmf_fit_on_rccl(exchange, tiny_dir, tmp_path):
     assert np.array_equal(res[0]["V1"], res[1]["V1"])
 
 
-def _layergcn_worker(rank, world, port, data_dir, workdir, dropout, ret):
+def _layergcn_worker(rank, world, port, data_dir, workdir, dropout, ret, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
-                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo")
+                      WORLD_SIZE=str(world), SKR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     os.chdir(workdir)
     import random
     from skrec import RunConfig
@@ -293,3 +293,37 @@ def test_layergcn_sharded_edge_dropout(plan, tiny_dir, tmp_path, monkeypatch):
         assert sum(r["nnz"][ep] for r in res.values()) == int(n_edges * 0.75)
     assert np.array_equal(res[0]["V1"], res[1]["V1"]) and np.array_equal(res[0]["reports"], res[1]["reports"])
     assert np.isfinite(res[0]["losses"]).all()
+
+
+@pytest.mark.parametrize("model", ["bprmf-sparse", "bprmf-dense", "lightgcn", "layergcn"])
+def test_fit_on_a_single_rank_rccl_group(model, tiny_dir, tmp_path, monkeypatch):
+    """The boxes of this environment have one GPU, so the multi-rank tests above run on gloo.  This one runs the SAME sharded
+    engines on backend "nccl" (= RCCL) with a group of ONE rank forced through every collective (SKR_DIST_FORCE_ACTIVE=1):
+    init_process_group(device_id=...), all_gather_into_tensor, all_reduce(async_op=True) + wait beside the side-stream cold
+    pass, broadcast, barrier -- the calls an N-GPU run makes, against the reference's recorded trajectories."""
+    monkeypatch.setenv("SKR_DIST_FORCE_ACTIVE", "1")
+    monkeypatch.setenv("SKR_SPMM_PLAN", "1")
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        if model.startswith("bprmf"):
+            g = np.load(os.path.join(GOLDEN, "golden_bprmf.npz"))
+            mp.spawn(_bprmf_worker, args=(1, _free_port(), tiny_dir, str(tmp_path), model.split("-")[1] + "/32", ret, "nccl"), nprocs=1, join=True)
+            r = ret[0]
+            np.testing.assert_allclose(r["losses"][:, 0], g["bpr_sum"], rtol=1e-5)
+            np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(r["U1"], g["U1"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(r["reports"], g["reports"], rtol=1e-5, atol=2e-4)
+        elif model == "lightgcn":
+            g = np.load(os.path.join(GOLDEN, "golden_lightgcn.npz"))
+            mp.spawn(_api_worker, args=(1, _free_port(), tiny_dir, str(tmp_path), ret, "nccl"), nprocs=1, join=True)
+            r = ret[0]
+            np.testing.assert_allclose(r["losses"][:, 0], g["bpr_mean"], rtol=1e-5)
+            np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=3e-6)
+            np.testing.assert_allclose(r["reports"], g["reports"], rtol=1e-5, atol=2e-4)
+        else:
+            g = np.load(os.path.join(GOLDEN, "golden_layergcn.npz"))
+            mp.spawn(_layergcn_worker, args=(1, _free_port(), tiny_dir, str(tmp_path), 0.0, ret, "nccl"), nprocs=1, join=True)
+            r = ret[0]
+            total = r["losses"][:, 0] + np.float32(1e-2) * r["losses"][:, 1]
+            np.testing.assert_allclose(total, g["loss"], rtol=1e-5)
+            np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=3e-6)

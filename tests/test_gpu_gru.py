@@ -227,7 +227,7 @@ def test_pop_sampler_is_numpys_searchsorted():
     assert np.abs(freq - want).max() < 5 * np.sqrt(want.max() / len(got)) + 1e-4
 
 
-def _sharded_gru_worker(rank, world, port, ret):
+def _sharded_gru_worker(rank, world, port, ret, rccl_one=False):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -235,13 +235,17 @@ def _sharded_gru_worker(rank, world, port, ret):
     from skrec.recommender.GRU4RecPlus import SessionGRU, ShardedSessionGRU
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rccl_one:      # a group of one rank on RCCL, forced through the sharded engine's collectives
+        os.environ["SKR_DIST_FORCE_ACTIVE"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        world = 2     # the branches below: "sharded"
     rng = np.random.default_rng(21)
     n_items, b, n_s, steps = 400, 24, 40, 12
     E_in = rng.normal(0, 0.1, (n_items, 64)).astype(np.float32)
     E_out = rng.normal(0, 0.1, (n_items, 128)).astype(np.float32)
     cells = [_cell(rng, 64, 64), _cell(rng, 64, 128)]
     args = (E_in, cells, E_out, np.zeros(n_items, np.float32), "tanh", "linear", "bpr_max", 1.0, 1e-3, 1e-2)
-    net = ShardedSessionGRU(DistContext(rank, world), *args) if world > 1 else SessionGRU(*args)
+    net = ShardedSessionGRU(DistContext(rank, 1 if rccl_one else world), *args) if world > 1 else SessionGRU(*args)
     lo, hi = net.slots(b) if world > 1 else (0, b)
     states = net.zero_states(hi - lo)
     losses = []
@@ -260,6 +264,23 @@ def _sharded_gru_worker(rank, world, port, ret):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def test_session_sharded_engine_on_a_single_rank_rccl_group():
+    """the sharded engine's exchange (all_gather_into_tensor of the compact block, rank-ordered sum) on backend "nccl" with a
+    group of one rank == the single-process engine"""
+    import torch.multiprocessing as mp
+    from test_gpu_dist import _free_port
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_sharded_gru_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+        one = ret[0]
+        ret2 = mgr.dict()
+        mp.spawn(_sharded_gru_worker, args=(1, _free_port(), ret2, True), nprocs=1, join=True)
+        r = ret2[0]
+    np.testing.assert_allclose(r["losses"], one["losses"], rtol=2e-5)
+    np.testing.assert_allclose(r["flat"], one["flat"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(r["state"], one["state"], rtol=0, atol=3e-5)
 
 
 @pytest.mark.parametrize("world", [2, 3])
