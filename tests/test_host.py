@@ -265,3 +265,43 @@ def test_bench_roofline_arithmetic():
     assert abs(r["alone"]["achieved"] - cold_bytes / 0.39e-3 / 1e9) < 1e-6
     r2 = bench.cold_roofline(n_par, hot, 32, cold, None, True, None, "x")
     assert r2["traffic"] is None and r2["achieved_by_traffic"] is None and r2["traffic_source"] is None and "alone" not in r2
+
+
+def test_fused_step_words_on_the_host():
+    """The words of the one-launch BPRMF step (include/skrec_hip.h, skr_bpr_fused_step) as skrec.recommender.fused.build_fused_meta
+    derives them with sorts and scans (the GPU suite compares skr_bpr_fused_plan with it), against a literal walk over the
+    steps of a small block: slot, earlier namings mod 6, previous naming step, one owner per (step, row), slot tables"""
+    import torch
+    from skrec.recommender.fused import build_fused_meta
+    rng = np.random.default_rng(3)
+    k, b, nU, nI = 9, 16, 12, 150
+    u = rng.integers(0, nU, k * b).astype(np.int32)
+    i = rng.integers(0, nI, k * b).astype(np.int32)
+    j = rng.integers(0, nI, k * b).astype(np.int32)
+    meta, slot_block, slot_fin, n_slots = build_fused_meta(torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(j), 1, k, b, 0, nU, nU + nI)
+    meta, slot_block, slot_fin = meta[0].numpy().astype(np.int64), slot_block[0].numpy(), slot_fin[0].numpy()
+    seen, last = {}, {}                                # row -> namings so far / last naming step
+    owners = set()
+    for s in range(k):
+        sl = slice(s * b, (s + 1) * b)
+        refs = np.stack([u[sl], nU + i[sl], nU + j[sl], nU + nI + (i[sl] >> 6), nU + nI + (j[sl] >> 6)])       # [5, b]
+        named_now = set()
+        for r in range(5):
+            for c in range(b):
+                row, w = int(refs[r, c]), int(meta[s, r, c])
+                slot, n0, own, prev1 = w & 0xfffff, (w >> 20) & 7, (w >> 23) & 1, (w >> 24) & 0x7f
+                assert slot_block[slot] == row
+                assert n0 == seen.get(row, 0) % 6 and prev1 == (last[row] + 1 if row in last else 0)
+                if own:
+                    assert (s, row) not in owners
+                    owners.add((s, row))
+                named_now.add(row)
+        assert {(s, r_) for r_ in named_now} <= owners          # every pair of this step has its owner
+        for row in named_now:
+            seen[row] = seen.get(row, 0) + 1
+            last[row] = s
+    n = int(n_slots[0])
+    assert n == len(seen) and sorted(slot_block[:n]) == sorted(seen) and (slot_block[n:] == -1).all()
+    for slot in range(n):
+        row = int(slot_block[slot])
+        assert slot_fin[slot] == (seen[row] % 6) | (last[row] << 8)
