@@ -110,7 +110,8 @@ class FusedBlocks(object):
             dev = self.opt.flat.device
             torch.cuda.synchronize(dev)               # nothing in flight refers to the buffers that are replaced
             self.cap = cap
-            self.work = torch.zeros((2, 9 * cap * 64), dtype=torch.float32, device=dev)   # zero: the invariant between blocks
+            # zero: the invariant between blocks.  One workspace unless a block's leftovers are written back beside the next block
+            self.work = torch.zeros((2 if self.split_end else 1, 9 * cap * 64), dtype=torch.float32, device=dev)
             self.meta, self.slot_block, self.slot_fin = (torch.empty((2, cap), dtype=torch.int32, device=dev) for _ in range(3))
             self.n_slots = torch.zeros((2, 1), dtype=torch.int32, device=dev)
             self._used = [False, False]
@@ -170,7 +171,7 @@ class FusedBlocks(object):
             if split:
                 cur.wait_event(self._ev_plan[q ^ 1])                 # the next block's tags decide what is written back where
             ptag = self.tags[q ^ 1].data_ptr() if split else None
-            pw = self.work[q].data_ptr()
+            pw = self.work[q if self.split_end else 0].data_ptr()
             rc = L.skr_bpr_fused_block(pp, pm, pv, n_par, pw, cap, pu + o, pi + o, pj + o, self.meta[q].data_ptr(), bsz, u0, i0, b0, lr,
                                        b1, b2, eps, t0, k, reg, ploss + blk * k * loss_stride_bytes, loss_stride_bytes // 4,
                                        self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(), self.n_slots[q].data_ptr(),
