@@ -181,6 +181,79 @@ def test_blocked_adam_full_size_is_bit_identical(big):
     assert 0.01 < float(moved) < 0.9          # rows at rest did not move, touched and lively rows did
 
 
+def test_fused_step_full_size(big):
+    """the shipped training step at full table size: 64 steps of 1024 real interactions (exact-stream negatives) through
+    skr_bpr_fused_plan / _step / _end (k = 32, two blocks, the cold pass beside them) against one skr_bpr_step + dense
+    skr_adam_step per batch, from aged moments.  Rows shared inside a batch (popular items, bias blocks) sum their float
+    atomics in a launch-dependent order in BOTH paths, and every row a batch names is scored against them: named rows are
+    compared to rounding; the rows no batch names (their k zero-gradient updates per block in one cold pass) BIT FOR BIT.
+    (Bit-identity of the named rows, with gradients that do not depend on the order of atomics: test_fused_step_is_bit_identical.)"""
+    import torch
+    from skrec import _hip
+    from skrec.recommender.base import DenseAdam
+    from skrec.recommender.fused import FusedBlocks
+    from skrec.utils.py.random import DeviceSampler
+    L, st = _hip.lib(), _hip.stream
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    n_par = (U + I) * 64 + I
+    b, k, n_steps = 1024, 32, 64
+    init = torch.randn(n_par, generator=g, device=dev) * 0.05
+    age = torch.empty(U + I, device=dev).exponential_(1.0 / 977.0, generator=g)
+    age = torch.cat([age.repeat_interleave(64), torch.zeros(I, device=dev)])
+    m0 = torch.randn(n_par, generator=g, device=dev) * 1e-3 * torch.exp(age * float(np.log(0.9)))
+    v0 = torch.rand(n_par, generator=g, device=dev) * 1e-6 * torch.exp(age * float(np.log(0.999)))
+    del age
+    n_pref = 40_000
+    nnz = int(big["rowptr"][n_pref])
+    neg = torch.empty(nnz, dtype=torch.int32, device=dev)
+    DeviceSampler(2020).sample_epoch_exact(I, n_pref, big["rowptr"][:n_pref + 1].contiguous(), big["items"][:nnz], nnz, 1, neg)
+    perm = torch.randperm(nnz, generator=g, device=dev)[:n_steps * b]
+    u = big["users"][:nnz][perm].contiguous()
+    i = big["items"][:nnz][perm].contiguous()
+    j = neg[perm].contiguous()
+    t_start = 20_000
+
+    def views(t):
+        return t[:U * 64].view(U, 64), t[U * 64:(U + I) * 64].view(I, 64), t[(U + I) * 64:]
+    a = DenseAdam(init.clone(), lr=1e-3)
+    a.m.copy_(m0)
+    a.v.copy_(v0)
+    a.t = t_start
+    la = torch.zeros((n_steps, 2), device=dev)
+    (P, Q, Bi), (gP, gQ, gB) = views(a.flat), views(a.grad)
+    for s in range(n_steps):
+        sl = slice(s * b, (s + 1) * b)
+        _hip.check(L.skr_bpr_step(_hip.ptr(P), _hip.ptr(Q), _hip.ptr(Bi), _hip.ptr(P), _hip.ptr(Q), _hip.ptr(u[sl]), _hip.ptr(i[sl]),
+                                  _hip.ptr(j[sl]), b, 1.0, 1e-3, 1.0, _hip.ptr(gP), _hip.ptr(gQ), _hip.ptr(gB), _hip.ptr(gP),
+                                  _hip.ptr(gQ), _hip.ptr(la[s]), None, None, st()))
+        a.step()
+    c = DenseAdam(init.clone(), lr=1e-3)
+    c.m.copy_(m0)
+    c.v.copy_(v0)
+    c.t = t_start
+    S = _hip.SKR_LOSS_SLOTS
+    lc = torch.zeros((n_steps, S, 2), device=dev)
+    fb = FusedBlocks(c, 0, U, U + I, 1e-3)
+    fb.run_blocks(u.data_ptr(), i.data_ptr(), j.data_ptr(), n_steps // k, k, b, lc.data_ptr(), 8 * S)
+    c.end_blocks()
+    torch.cuda.synchronize()
+    assert c.t == a.t == t_start + n_steps
+    np.testing.assert_allclose(lc.sum(1).cpu().numpy(), la.cpu().numpy(), rtol=1e-5)
+    # rows no batch names take only zero-gradient updates: the same bits in both runs
+    uu = u.view(n_steps, b).long()
+    cnt = torch.zeros(U, dtype=torch.int64, device=dev).index_add_(0, uu.reshape(-1), torch.ones(n_steps * b, dtype=torch.int64, device=dev))
+    cold = cnt == 0
+    for x, y in ((a.flat, c.flat), (a.m, c.m), (a.v, c.v)):
+        xu, yu = x[:U * 64].view(U, 64)[cold], y[:U * 64].view(U, 64)[cold]
+        assert int((xu.view(torch.int32) != yu.view(torch.int32)).sum()) == 0
+    assert int(cold.sum()) > 900_000 and int((cnt > 0).sum()) > 20_000
+    # everything else to rounding
+    for x, y, atol in ((a.flat, c.flat, 2e-6), (a.m, c.m, 1e-7), (a.v, c.v, 1e-9)):
+        assert bool(((x - y).abs() <= atol + 1e-5 * y.abs()).all()), float((x - y).abs().max())
+    assert float(fb.work[:, 6 * fb.cap * 64:].abs().max()) == 0.0
+
+
 def test_lightgcn_full_size_propagation_and_step(big):
     """BASELINE configs[2] at size: LightGCN, 3 layers, 'pre' adjacency of the 1 M-user / 100 k-item / 48 M-interaction
     graph (1.1 M rows, 97 M non-zeros), reference LightGCN.py:89-100,180-199.
