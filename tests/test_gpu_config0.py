@@ -148,3 +148,97 @@ def test_bprmf_config0_shape_fit_replays_the_oracle(tmp_path, monkeypatch):
     np.testing.assert_allclose(got_losses[:, 0], want_losses[:, 0], rtol=1e-5)
     np.testing.assert_allclose(got_losses[:, 1], want_losses[:, 1], rtol=1e-5)
     assert list(m.evaluator.metrics_list) == names
+
+
+@pytest.mark.parametrize("model_name", ["LightGCN", "LayerGCN"])
+def test_graph_models_config0_shape_fit_replays_the_oracle(model_name, tmp_path, monkeypatch):
+    """LightGCN (3 layers, `pre` adjacency) and LayerGCN (4 layers) on the same ml-100k-shaped set through the API, against the
+    oracle's replay (exact-stream negatives, numpy permutations, oracle.lightgcn_step / layergcn_step -- float32 scipy
+    propagation with explicit backward -- and oracle.Adam): per-step losses 1e-5, the ego table after every epoch 3e-6.
+    The graph has 139 k non-zeros, so the propagation goes through skr_spmm_plan_* with the step's row / column masks live
+    (the 64-user golden set needs SKR_SPMM_PLAN=1 for that)."""
+    import random
+    import scipy.sparse as sp
+    import torch
+    from oracle import oracle as O
+    from skrec import RunConfig
+    from skrec.utils.py.random import reset_global_sampler
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("SKR_SPMM_PLAN", raising=False)
+    train, test = _ml100k_shaped(np.random.default_rng(100))
+    root = tmp_path / "ml100k_shaped"
+    root.mkdir()
+    for name, rows in (("train", train), ("test", test)):
+        with open(root / f"ml100k_shaped.{name}", "w") as f:
+            for u, i, t in rows:
+                f.write(f"{u}\t{i}\t1.0\t{t}\n")
+    np.random.seed(SEED)
+    random.seed(SEED)
+    torch.manual_seed(SEED)
+    reset_global_sampler(2020)
+    rc = RunConfig(recommender=model_name, data_dir=str(root), file_column="UIRT", sep="\t", hyperopt=False, gpu_id=0,
+                   metric=("Recall", "NDCG"), top_k=(10, 20), test_batch_size=64, test_thread=4, seed=SEED)
+    lr, bsz, epochs = 1e-3, 1024, 2
+    if model_name == "LightGCN":
+        from skrec.recommender.LightGCN import LightGCN as Model
+        reg, n_layers = 1e-3, 3
+        m = Model(rc, dict(lr=lr, reg=reg, embed_size=64, n_layers=n_layers, adj_type="pre", batch_size=bsz, epochs=epochs))
+    else:
+        from skrec.recommender.LayerGCN import LayerGCN as Model
+        reg, n_layers = 1e-2, 4
+        m = Model(rc, dict(lr=lr, reg=reg, embed_dim=64, n_layers=n_layers, dropout=0.0, batch_size=bsz, epochs=epochs))
+    assert (m.num_users, m.num_items) == (N_USERS, N_ITEMS) and m.engine is None
+    E0 = np.concatenate([m.user_embeddings.cpu().numpy(), m.item_embeddings.cpu().numpy()], 0).copy()
+    np_state = np.random.get_state()
+    losses, snaps = [], []
+    te = m.train_epoch
+
+    def train_epoch(it):
+        te(it)
+        losses.append(m.step_losses.cpu().numpy().copy())
+        snaps.append(np.concatenate([m.user_embeddings.cpu().numpy(), m.item_embeddings.cpu().numpy()], 0).copy())
+    m.train_epoch = train_epoch
+    m.fit()
+    got_losses = np.concatenate(losses, 0)
+    # the oracle's replay
+    order = np.lexsort((train[:, 2], train[:, 0]))
+    users_ary, pos_items = train[order, 0].astype(np.int32), train[order, 1].astype(np.int32)
+    rowptr = np.zeros(N_USERS + 1, np.int64)
+    rowptr[1:] = np.cumsum(np.bincount(users_ary, minlength=N_USERS))
+    N = N_USERS + N_ITEMS
+    R = sp.csr_matrix((np.ones(len(users_ary), np.float32), (users_ary, pos_items + N_USERS)), shape=(N, N))
+    A = (R + R.T).tocsr()
+    deg = np.asarray(A.sum(1)).reshape(-1).astype(np.float64)
+    if model_name == "LightGCN":       # D^-1/2 A D^-1/2, zero degree -> 0 (utils/common.py:27-40)
+        with np.errstate(divide="ignore"):
+            dinv = np.where(deg > 0, np.power(deg, -0.5), 0.0)
+    else:                              # +1e-7 on the degrees (LayerGCN.py:186)
+        dinv = np.power(deg + 1e-7, -0.5)
+    A = (sp.diags(dinv) @ A @ sp.diags(dinv)).astype(np.float32).tocsr()
+    sampler = O.Sampler(2020)
+    opt = O.Adam([E0], lr=lr)
+    np.random.set_state(np_state)
+    want = []
+    for ep in range(epochs):
+        neg = sampler.sample_epoch(N_ITEMS, rowptr, pos_items, 1)
+        perm = np.random.permutation(len(users_ary))
+        for bu, bi, bj in O.pairwise_epoch(users_ary, pos_items, neg, bsz, perm):
+            if model_name == "LightGCN":
+                loss, l2, G = O.lightgcn_step(A, E0, N_USERS, bu, bi, bj, n_layers, reg, bsz)
+                want.append((loss, l2))
+            else:
+                loss, l2, G = O.layergcn_step(A, E0, N_USERS, bu, bi, bj, n_layers, reg)
+                want.append((loss, l2))
+            opt.step([G])
+        diff = np.abs(snaps[ep] - E0)
+        if model_name == "LightGCN":
+            assert diff.max() <= 3e-6
+        else:
+            # LayerGCN divides by row norms, and Adam turns the SIGN of a gradient element into a step of lr whatever its size:
+            # where a gradient element is at the level of fp32 summation noise (rows far from the batch), two correct
+            # evaluations can step in opposite directions.  Nearly all elements agree to 3e-6; the rest stay within a few lr.
+            assert (diff <= 3e-6).mean() >= 0.99 and diff.max() <= 5e-4, ((diff <= 3e-6).mean(), diff.max())
+    want = np.array(want, np.float32)
+    assert got_losses.shape == want.shape
+    np.testing.assert_allclose(got_losses[:, 0], want[:, 0], rtol=1e-5)
+    np.testing.assert_allclose(got_losses[:, 1], want[:, 1], rtol=1e-5)
