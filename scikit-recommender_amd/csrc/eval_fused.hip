@@ -951,6 +951,178 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v4(FusedAr
     }
 }
 
+constexpr int F5_RING = 3;              // half tiles resident per WORKGROUP (the counted waits and the two bias rows assume 3)
+
+// ================================================================================================
+// The same bf16x3 sweep with the item tile SHARED by the four wavefronts of a workgroup (the default up to top-32): in
+// fused_topk_kernel_v4 every wavefront streams the whole split item table through a ring of its own -- 8 wavefronts per CU
+// each write 12 KB per tile into LDS and read it back (the LDS-DMA stream costs 5 of the kernel's 19 ms, by ablation).
+// Here a half tile's six 1 KB blocks are brought by the four wavefronts together (2 + 2 + 1 + 1) into ONE ring, and a
+// workgroup barrier per half-tile step orders "all blocks of half hs+1 have landed" and "everybody holds half hs in
+// registers, its slot is free".  A quarter of the DMA instructions and of the LDS write traffic (a ring of six half tiles, the
+// DMA 2.5 tile times ahead of its use, was no faster: 17.6 ms); the wavefronts of a
+// workgroup advance in lock-step, so one that compacts a candidate list holds the other three at the next barrier.
+// ================================================================================================
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v5(FusedArgs a, const uint4* __restrict__ frags) {
+    __shared__ uint4 s_tile[F5_RING * F4_HALF_U4];             // ONE ring of F5_RING half tiles for the workgroup's four wavefronts
+    __shared__ float4 s_bias[2][16];                           // the bias DMA writes 4 B for each of the 64 lanes
+    __shared__ int s_cnt[FE_WAVES][FE_UW];
+    __shared__ int64_t s_row_beg[FE_WAVES][FE_UW];
+    __shared__ int s_row_len[FE_WAVES][FE_UW];
+    __shared__ int s_rowbuf[FE_WAVES][F4_ROWBUF];
+    WaveCtx w;
+    w.lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: it selects DMA blocks (scalar operands)
+    w.c = w.lane & 31;
+    w.h = w.lane >> 5;
+    const int lane = w.lane, c = w.c, h = w.h;
+    w.ubase = (static_cast<int64_t>(blockIdx.x) * FE_WAVES + wv) * FE_UW;
+    // a wavefront whose users lie beyond B stays: it carries its share of the tile DMA and of the workgroup barriers
+    // (its thresholds are +inf and it writes nothing)
+    w.cnt = s_cnt[wv];
+    w.cnt[lane] = 0;
+    w.my_cand = a.cand + w.ubase * a.cap;
+    w.row_beg = s_row_beg[wv];
+    w.row_len = s_row_len[wv];
+    w.rowbuf = s_rowbuf[wv];
+    w.rowbuf_len = F4_ROWBUF;
+    {
+        const int64_t row = w.ubase + lane;
+        int64_t rb = 0;
+        int len = 0;
+        if (a.train_rowptr && row < a.B) {
+            const int u = a.users[row];
+            rb = a.train_rowptr[u];
+            len = static_cast<int>(a.train_rowptr[u + 1] - rb);
+        }
+        w.row_beg[lane] = rb;
+        w.row_len[lane] = len;
+    }
+    // user fragments: B[k = 8h + j][col c] of chunk q, three pieces each
+    uint4 bh[2][4], bm[2][4], bl[2][4];
+    float thr[2];
+    int uid[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int64_t row = w.ubase + 32 * f + c;
+        const bool ok = row < a.B;
+        uid[f] = a.users[ok ? row : (a.B - 1)];
+        thr[f] = (ok && a.ablate != 1 && a.ablate != 7) ? -INFINITY : INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid[f]) * FE_D + q * 16 + 8 * h);
+            const float4 v0 = up[0], v1 = up[1];
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            split3x8(v, bh[f][q], bm[f][q], bl[f][q]);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // retire the loads here (see the fp32 kernel: hidden DMA vs counted vmcnt)
+            asm volatile("" : "+v"(bh[f][q].x), "+v"(bh[f][q].y), "+v"(bh[f][q].z), "+v"(bh[f][q].w));
+            asm volatile("" : "+v"(bm[f][q].x), "+v"(bm[f][q].y), "+v"(bm[f][q].z), "+v"(bm[f][q].w));
+            asm volatile("" : "+v"(bl[f][q].x), "+v"(bl[f][q].y), "+v"(bl[f][q].z), "+v"(bl[f][q].w));
+        }
+    const int n_tiles = (a.n_items + FE_TI - 1) / FE_TI;
+    const int n_half = 2 * n_tiles;
+    const uint32_t lt = lds_addr_of(&s_tile[0]);
+    const uint32_t lb0 = lds_addr_of(&s_bias[0][0]), lb1 = lds_addr_of(&s_bias[1][0]);
+    // half tile `hs` (tile hs>>1, chunks 2*(hs&1) and 2*(hs&1)+1) -> ring slot `slot`; with the first half of a
+    // tile travels its bias row.  7 (6) DMA instructions per even (odd) half with a bias, 6 without.
+    const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+    auto issue_half = [&](int hs, int slot) {
+        const char* sbase = reinterpret_cast<const char*>(frags) + static_cast<int64_t>(hs) * (F4_HALF_U4 * 16);   // wave-uniform
+        const uint32_t dst = lt + slot * (F4_HALF_U4 * 16);
+        // the half tile's six 1 KB blocks are shared out: wavefronts 0 and 1 bring two each, 2 and 3 one each (3 also the bias)
+        glds_b128_s(lane16, sbase + wv * 1024, dst + wv * 1024);
+        if (wv < 2) glds_b128_s(lane16, sbase + (4 + wv) * 1024, dst + (4 + wv) * 1024);
+        if (HAS_BIAS && !(hs & 1) && wv == 3) {
+            int bi = (hs >> 1) * FE_TI + (lane & 31);
+            bi = bi < a.n_items ? bi : a.n_items - 1;
+            glds_b32(a.item_bias + bi, ((hs >> 1) & 1) ? lb1 : lb0);
+        }
+    };
+#pragma unroll
+    for (int h0 = 0; h0 < F5_RING; ++h0)
+        if (h0 < n_half) issue_half(h0, h0);        // n_half >= 2 always
+    FE2_WAIT();
+    __syncthreads();                                // every wavefront's blocks have landed
+    uint4 afA[6], afB[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) afA[i] = s_tile[i * 64 + lane];
+    f32x16 acc0, acc1;
+    CandRegs cr{{0, 0}};
+    int slot = 0;                                   // ring slot of the half held in afA at an even step
+    // one step = one half tile.  At its start the fragments of half hs are in registers, so its ring slot
+    // is free: the DMA of half hs+3 goes there, then the fragments of half hs+1 are fetched (its DMA was
+    // issued two steps ago: a counted wait leaves the two younger DMAs in flight) while the 24 MFMAs run.
+#define F5_STEP(CUR, NXT, HS, EVEN)                                                                           \
+    {                                                                                                         \
+        const int hs_ = (HS);                                                                                 \
+        /* pinned: left to itself hipcc hoists this wait above the previous step's MFMAs (an asm volatile is  \
+           only ordered against memory operations), i.e. right behind the reads it waits for */               \
+        FE3_PIN();                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* CUR has landed in registers */                \
+        FE3_PIN();                                                                                            \
+        const bool more3_ = hs_ + F5_RING < n_half && a.ablate != 7;                                          \
+        const int nslot_ = slot == F5_RING - 1 ? 0 : slot + 1;                                                \
+        if (hs_ + 1 < n_half) {                                                                               \
+            /* my blocks of half hs+1 have landed once at most my blocks of half hs+2 are in flight (those of */  \
+            /* half hs+3 are issued below): two for wavefronts 0, 1 (and 3 with a bias row), else one         */  \
+            if (hs_ + 2 >= n_half) FE2_WAIT();                                                                \
+            else if (wv < 2 || (HAS_BIAS && (EVEN) && wv == 3)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); \
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                             \
+        }                                                                                                     \
+        /* ONE workgroup barrier per half-tile step: behind it every wavefront's blocks of half hs+1 have     */  \
+        /* landed, and every wavefront holds half hs in registers -- its ring slot is free for half hs+3     */  \
+        __syncthreads();                                                                                      \
+        FE3_PIN();                                                                                            \
+        if (more3_) issue_half(a.ablate == 8 ? ((hs_ + F5_RING) & 31) : hs_ + F5_RING, slot);                 \
+        if (hs_ + 1 < n_half) {                                                                               \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i) NXT[i] = s_tile[nslot_ * F4_HALF_U4 + i * 64 + lane]; \
+        }                                                                                                     \
+        FE3_PIN();                                                                                            \
+        if (EVEN) {                                                                                           \
+            if (HAS_BIAS) {                                                                                   \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
+                    const float4 b4 = s_bias[(hs_ >> 1) & 1][2 * g + h];                                  \
+                    acc0[4 * g + 0] = b4.x; acc0[4 * g + 1] = b4.y; acc0[4 * g + 2] = b4.z; acc0[4 * g + 3] = b4.w; \
+                }                                                                                             \
+            } else {                                                                                          \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;                                \
+            }                                                                                                 \
+            acc1 = acc0;                                                                                      \
+        }                                                                                                     \
+        _Pragma("unroll") for (int qq = 0; qq < 2; ++qq) {   /* small terms first */                          \
+            const int q = ((EVEN) ? 0 : 2) + qq;                                                              \
+            const uint4 &ah = CUR[3 * qq], &am = CUR[3 * qq + 1], &al = CUR[3 * qq + 2];                      \
+            acc0 = F4_MFMA(al, bh[0][q], acc0);  acc1 = F4_MFMA(al, bh[1][q], acc1);                          \
+            acc0 = F4_MFMA(ah, bl[0][q], acc0);  acc1 = F4_MFMA(ah, bl[1][q], acc1);                          \
+            acc0 = F4_MFMA(am, bm[0][q], acc0);  acc1 = F4_MFMA(am, bm[1][q], acc1);                          \
+            acc0 = F4_MFMA(am, bh[0][q], acc0);  acc1 = F4_MFMA(am, bh[1][q], acc1);                          \
+            acc0 = F4_MFMA(ah, bm[0][q], acc0);  acc1 = F4_MFMA(ah, bm[1][q], acc1);                          \
+            acc0 = F4_MFMA(ah, bh[0][q], acc0);  acc1 = F4_MFMA(ah, bh[1][q], acc1);                          \
+        }                                                                                                     \
+        if (!(EVEN)) {                                                                                        \
+            tile_candidates_v4(a, w, acc0, acc1, (hs_ >> 1) * FE_TI, thr, cr);                                \
+        }                                                                                                     \
+        slot = nslot_;                                                                                        \
+    }
+    for (int t = 0; t < n_tiles; ++t) {
+        F5_STEP(afA, afB, 2 * t, true)
+        F5_STEP(afB, afA, 2 * t + 1, false)
+    }
+#undef F5_STEP
+    cand_sync_to_lds(w, cr);
+    for (int ul = 0; ul < FE_UW; ++ul) {
+        const int64_t row = w.ubase + ul;
+        if (row >= a.B) break;
+        compact_user(a, w, ul, row);
+    }
+}
+
 // list capacity per user.  Measured on MI355X (K = 10..100, 262 144 users): 512-entry lists with a
 // trigger of 480 were no faster than 256 / 224 once the mid-sweep compaction selects instead of sorting
 // (profiles/r01_eval_history.txt), so the smaller scratch footprint stays.
@@ -1000,9 +1172,14 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     hipStream_t st = skr::as_stream(stream);
     // arithmetic mode, read per call: "bf16x3" (default) or "fp32" (the FP32-MFMA kernel)
     const char* mode_env = getenv("SKR_FUSED_MODE");
-    const bool mode_bf16x3 = !(mode_env && std::string(mode_env) == "fp32");
-    SKR_REQUIRE(!mode_env || std::string(mode_env) == "fp32" || std::string(mode_env) == "bf16x3",
-                "SKR_FUSED_MODE must be 'bf16x3' or 'fp32' (got '%s')", mode_env);
+    const std::string mode = mode_env ? mode_env : "bf16x3";
+    SKR_REQUIRE(mode == "fp32" || mode == "bf16x3" || mode == "bf16x3s" || mode == "bf16x3w",
+                "SKR_FUSED_MODE must be 'bf16x3', 'bf16x3s', 'bf16x3w' or 'fp32' (got '%s')", mode_env);
+    const bool mode_bf16x3 = mode != "fp32";
+    // bf16x3: the workgroup-shared tile ring (v5) for short lists, the ring per wavefront (v4) for long ones -- measured on
+    // 262 144 users x 100 k items: top-10 17.3 vs 18.1 ms, top-50 21.2 vs 21.4, top-100 25.3 vs 25.1 (a wavefront that compacts
+    // a list holds its three neighbours at the next barrier, and long lists are compacted more often); "s" / "w" force one
+    const bool shared_ring = mode == "bf16x3s" || (mode == "bf16x3" && top_k <= 32);
     if (mode_bf16x3) {
         // library-owned scratch for the split item table (38 MB at 100 k items), grown on demand
         static uint4* frag_buf = nullptr;
@@ -1024,7 +1201,12 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
                            n_items, n_tiles, frag_buf);
         SKR_LAUNCH_CHECK();
         static const unsigned dyn_lds = [] { const char* e = getenv("SKR_FUSED_DYN_LDS"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();   // occupancy experiments
-        if (d_item_bias)
+        if (shared_ring) {
+            if (d_item_bias)
+                hipLaunchKernelGGL(fused_topk_kernel_v5<true>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
+            else
+                hipLaunchKernelGGL(fused_topk_kernel_v5<false>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
+        } else if (d_item_bias)
             hipLaunchKernelGGL(fused_topk_kernel_v4<true>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
         else
             hipLaunchKernelGGL(fused_topk_kernel_v4<false>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
