@@ -15,6 +15,7 @@
 #include "skr_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -149,6 +150,134 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
                     h_new[static_cast<int64_t>(row) * H + j] = hn;
                 }
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward for MANY sessions (the inference sweep `_get_user_embeddings`, GRU4RecPlus.py:256-302, advances every user at
+// once): the two products [x, h] Wg and [x, r*h] Wc on the matrix cores, v_mfma_f32_32x32x2_f32 (fp32 operands, fp32
+// accumulation).  A workgroup takes 32 sessions: their [x, h] rows sit in LDS (row stride K + 1: the 32 rows of a column then
+// fall into 32 banks) as the A operand; a wavefront owns 32-column tiles of the output and streams the weight rows of its
+// columns from L2 (coalesced 128-byte reads, eight k-steps ahead); the gates' r*h and u pass to the candidate phase through
+// LDS.  1 M sessions, d = 128 (tools/gru_sweep_lab.py): 3.99 ms per step = 49 TFLOP/s, the vector-FMA kernel (16 sessions per
+// workgroup) 6.58 ms = 30 TFLOP/s; hardware exp2 / reciprocal in the activations would give 3.85 ms and were not taken (the
+// sweep then rounds differently from the training step).  Sums are formed pairwise in k inside an MFMA and then in k order:
+// equal to the FMA chain to rounding.
+// ------------------------------------------------------------------------------------------------
+typedef float gru_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int GM_ROWS = 32;
+
+template <int H>
+__global__ __launch_bounds__(G_T) void gru_fwd_mfma_kernel(GruIn g, const uint8_t* __restrict__ active,
+                                                           const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                           const float* __restrict__ Wc, const float* __restrict__ bc, int act,
+                                                           float* __restrict__ r_out, float* __restrict__ u_out,
+                                                           float* __restrict__ c_out, float* __restrict__ h_new) {
+    __shared__ float a[GM_ROWS][G_KMAX + 1];
+    __shared__ float rh[GM_ROWS][H + 1];
+    __shared__ float us[GM_ROWS][H + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int IN = g.in_dim, K = IN + H;
+    const int row0 = blockIdx.x * GM_ROWS;
+    // staging: a wavefront takes 8 sessions, lanes along the row (coalesced, no index arithmetic per element, all of a
+    // session's loads issued together); column K is a zero that the odd-K tail multiplies
+#pragma unroll
+    for (int rr = 0; rr < GM_ROWS / (G_T / 64); ++rr) {
+        const int r = wv * (GM_ROWS / (G_T / 64)) + rr, row = row0 + r;
+        const bool ok = row < g.B;
+        const float* __restrict__ xr = ok ? x_row(g, row) : g.x;
+        const float* __restrict__ hr = g.h + static_cast<int64_t>(ok ? row : 0) * H;
+#pragma unroll
+        for (int e = 0; e < (G_KMAX + 64) / 64; ++e) {
+            const int k = lane + 64 * e;
+            if (k <= K) a[r][k] = (ok && k < K) ? (k < IN ? xr[k] : hr[k - IN]) : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int m = lane & 31, kh = lane >> 5;            // A[row m][k + kh], B[k + kh][col m]
+    // NT 32 x 32 output tiles side by side (columns col0 + 32 t): acc[t] += A * W(:, col0 + 32 t ...).  Rows [0, n1) of W meet
+    // src's columns, rows [n1, n1 + n2) meet src2's (r*h in the candidate phase).  Two tiles share every A value and give the
+    // matrix pipe two independent accumulation chains.
+    auto tiles = [&](auto nt_c, gru_f32x16* acc, const float (*src)[G_KMAX + 1], const float (*src2)[H + 1], int n1, int n2,
+                     const float* __restrict__ W, int ld, int col0) {
+        constexpr int NT = decltype(nt_c)::value;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+        const float* __restrict__ wcol = W + col0 + m;
+        const int n = n1 + n2;
+        // the operands of the next 16 k are fetched before the MFMAs of the current 16 are issued (two register sets): without
+        // that every chunk waits out an L2 round trip with the matrix pipe idle
+        float b[2][NT][8], av[2][8];
+        auto fetch = [&](int k0, float (&bb)[NT][8], float (&aa)[8]) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + 2 * q + kh;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bb[t][q] = k < n ? wcol[static_cast<int64_t>(k) * ld + 32 * t] : 0.0f;
+                aa[q] = k < n1 ? src[m][k] : (k < n ? (src2 ? src2[m][k - n1] : src[m][k]) : 0.0f);
+            }
+        };
+        fetch(0, b[0], av[0]);
+        for (int k0 = 0; k0 < n; k0 += 32) {
+            if (k0 + 16 < n) fetch(k0 + 16, b[1], av[1]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][q], b[0][t][q], acc[t], 0, 0, 0);
+            if (k0 + 16 >= n) break;
+            if (k0 + 32 < n) fetch(k0 + 32, b[0], av[0]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][q], b[1][t][q], acc[t], 0, 0, 0);
+        }
+    };
+    // accumulator element i of a lane: row 8 * (i / 4) + 4 * kh + i % 4, column m
+    {   // gates: C / 32 column tiles over the four wavefronts, two at a time where there are eight
+        constexpr int C = 2 * H, NT = (C / 32 >= 8) ? 2 : 1;
+        for (int ct = wv * NT; ct < C / 32; ct += (G_T / 64) * NT) {
+            gru_f32x16 acc[NT];
+            tiles(std::integral_constant<int, NT>{}, acc, a, nullptr, K, 0, Wg, C, ct * 32);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int j = (ct + t) * 32 + m;
+                const float b = bg[j];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = 8 * (i >> 2) + 4 * kh + (i & 3), row = row0 + r;
+                    const float sgm = sigmoidf_(acc[t][i] + b);
+                    if (j < H) {
+                        rh[r][j] = sgm * a[r][IN + j];
+                        if (r_out && row < g.B) r_out[static_cast<int64_t>(row) * H + j] = sgm;
+                    } else {
+                        us[r][j - H] = sgm;
+                        if (u_out && row < g.B) u_out[static_cast<int64_t>(row) * H + (j - H)] = sgm;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int ct = wv; ct < H / 32; ct += G_T / 64) {     // candidate and new state
+        gru_f32x16 acc1[1];
+        tiles(std::integral_constant<int, 1>{}, acc1, a, rh, IN, H, Wc, H, ct * 32);
+        const gru_f32x16& acc = acc1[0];
+        const int j = ct * 32 + m;
+        const float b = bc[j];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = 8 * (i >> 2) + 4 * kh + (i & 3), row = row0 + r;
+            if (row < g.B) {
+                const float c = hidden_act(acc[i] + b, act);
+                const float ho = a[r][IN + j], u = us[r][j];
+                float hn = u * ho + (1.0f - u) * c;
+                if (active && !active[row]) hn = ho;        // finished history: the state is carried
+                if (c_out) c_out[static_cast<int64_t>(row) * H + j] = c;
+                h_new[static_cast<int64_t>(row) * H + j] = hn;
+            }
+        }
     }
 }
 
@@ -624,7 +753,20 @@ int skr_gru_cell_fwd(const float* d_x, const int32_t* d_x_index, const float* d_
         else if (hid == 64) by_align(rows_c, std::integral_constant<int, 64>{});
         else by_align(rows_c, std::integral_constant<int, 128>{});
     };
-    if (B <= G_SMALL_B) by_hid(std::integral_constant<int, 4>{}); else by_hid(std::integral_constant<int, G_ROWS>{});
+    // many sessions (the inference sweep): the matrix cores.  SKR_GRU_MFMA=0 keeps the vector kernel (16 sessions per workgroup).
+    static const bool use_mfma = [] { const char* e = getenv("SKR_GRU_MFMA"); return !(e && atoi(e) == 0); }();
+    if (B > G_SMALL_B && use_mfma) {
+        const dim3 grid((B + GM_ROWS - 1) / GM_ROWS), wg(G_T);
+        if (hid == 32)
+            hipLaunchKernelGGL(gru_fwd_mfma_kernel<32>, grid, wg, 0, skr::as_stream(stream), g, d_active, d_Wg, d_bg, d_Wc, d_bc,
+                               hidden_act_kind, d_r, d_u, d_c, d_h_new);
+        else if (hid == 64)
+            hipLaunchKernelGGL(gru_fwd_mfma_kernel<64>, grid, wg, 0, skr::as_stream(stream), g, d_active, d_Wg, d_bg, d_Wc, d_bc,
+                               hidden_act_kind, d_r, d_u, d_c, d_h_new);
+        else
+            hipLaunchKernelGGL(gru_fwd_mfma_kernel<128>, grid, wg, 0, skr::as_stream(stream), g, d_active, d_Wg, d_bg, d_Wc, d_bc,
+                               hidden_act_kind, d_r, d_u, d_c, d_h_new);
+    } else if (B <= G_SMALL_B) by_hid(std::integral_constant<int, 4>{}); else by_hid(std::integral_constant<int, G_ROWS>{});
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

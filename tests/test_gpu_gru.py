@@ -2,6 +2,8 @@
 torch-CPU restatement of the reference's TensorFlow-1.14 graph with autograd supplying the gradients the
 kernels derive by hand.  PARITY UNPINNED against the reference itself (TensorFlow absent, no recorded
 output in the reference).  Tolerance: 1e-5 relative (fp32 summation order) unless noted."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -70,6 +72,56 @@ def test_gru_cell_fwd_bwd(i_d, h, B, act):
                                   None, _hip.ptr(out2), st))
     want = np.where(active[:, None] == 1, out.cpu().numpy(), hprev)
     assert np.array_equal(out2.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("mfma", ["1", "0"])
+@pytest.mark.parametrize("i_d,h,B,act", [(128, 128, 5000, "tanh"), (64, 64, 2049, "tanh"), (100, 32, 3001, "relu"), (37, 64, 4100, "tanh"),
+                                         (64, 128, 2100, "tanh")])
+def test_gru_cell_forward_for_many_sessions(i_d, h, B, act, mfma, monkeypatch):
+    """the inference sweep's forward (more than 2048 sessions per call): the matrix-core kernel (v_mfma_f32_32x32x2_f32, 32
+    sessions per workgroup) and the vector kernel it replaces (SKR_GRU_MFMA=0, 16 sessions per workgroup) against the
+    torch-CPU cell; r, u, c outputs; the row mask that carries finished histories' states; a ragged last workgroup; an odd
+    input size (the k-pairs' zero tail).  The switch is read once per process, so the vector kernel runs in a child process."""
+    import subprocess
+    import sys
+    if mfma == "0":
+        code = ("import os, sys; os.environ['SKR_GRU_MFMA'] = '0'; sys.path[:0] = [%r, %r]; import test_gpu_gru as t; "
+                "t._many_sessions_case(%d, %d, %d, %r)" % (os.path.dirname(os.path.abspath(__file__)), os.path.join(
+                    os.path.dirname(os.path.abspath(__file__)), "..", "scikit-recommender_amd"), i_d, h, B, act))
+        subprocess.run([sys.executable, "-c", code], check=True, cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        return
+    _many_sessions_case(i_d, h, B, act)
+
+
+def _many_sessions_case(i_d, h, B, act):
+    rng = np.random.default_rng(i_d + h + B)
+    n_rows = 700
+    table = (0.5 * rng.standard_normal((n_rows, i_d))).astype(np.float32)
+    idx = rng.integers(0, n_rows, B).astype(np.int32)
+    hprev = (0.5 * rng.standard_normal((B, h))).astype(np.float32)
+    Wg, bg, Wc, bc = _cell(rng, i_d, h)
+    hn = G.gru_cell(torch.tensor(table)[torch.as_tensor(idx, dtype=torch.long)], torch.tensor(hprev), torch.tensor(Wg), torch.tensor(bg),
+                    torch.tensor(Wc), torch.tensor(bc), act).numpy()
+    L, st = _hip.lib(), _hip.stream()
+    d = {k: to_dev(v) for k, v in dict(table=table, idx=idx, h=hprev, Wg=Wg, bg=bg, Wc=Wc, bc=bc).items()}
+    r, u, c, out = (torch.empty((B, h), device="cuda") for _ in range(4))
+    kind = {"tanh": 0, "relu": 1}[act]
+    _hip.check(L.skr_gru_cell_fwd(_hip.ptr(d["table"]), _hip.ptr(d["idx"]), _hip.ptr(d["h"]), None, B, i_d, h, _hip.ptr(d["Wg"]),
+                                  _hip.ptr(d["bg"]), _hip.ptr(d["Wc"]), _hip.ptr(d["bc"]), kind, _hip.ptr(r), _hip.ptr(u),
+                                  _hip.ptr(c), _hip.ptr(out), st))
+    _close(out.cpu().numpy(), hn, 2e-5, 2e-6)
+    # the saved gates are consistent with the state: h' = u h + (1 - u) c
+    rr, uu, cc = (t.cpu().numpy() for t in (r, u, c))
+    _close(uu * hprev + (1.0 - uu) * cc, hn, 2e-5, 2e-6)
+    assert (rr > 0).all() and (rr < 1).all() and (uu > 0).all() and (uu < 1).all()
+    # dense input rows (no index), no saved gates, the row mask
+    active = (rng.random(B) < 0.5).astype(np.uint8)
+    x_dense = to_dev(table[idx])
+    out2 = torch.empty((B, h), device="cuda")
+    _hip.check(L.skr_gru_cell_fwd(_hip.ptr(x_dense), None, _hip.ptr(d["h"]), _hip.ptr(to_dev(active)), B, i_d, h, _hip.ptr(d["Wg"]),
+                                  _hip.ptr(d["bg"]), _hip.ptr(d["Wc"]), _hip.ptr(d["bc"]), kind, None, None, None, _hip.ptr(out2), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), np.where(active[:, None] == 1, out.cpu().numpy(), hprev))
 
 
 @pytest.mark.parametrize("loss", ["bpr_max", "top1_max"])
