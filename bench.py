@@ -1063,7 +1063,7 @@ def main():
         te2 = time.perf_counter() - t1e
         neg_ahead = box.pop("neg")
         neg_ahead.record_stream(torch.cuda.current_stream())
-        th = threading.Thread(target=draw_ahead, daemon=True)
+        th = threading.Thread(target=draw_ahead if os.environ.get("SKR_BENCH_NO_AHEAD3") != "1" else (lambda: None), daemon=True)
         t2e = time.perf_counter()
         th.start()
         run_slice(whole, n_ep, neg=neg_ahead)
@@ -1085,9 +1085,12 @@ def main():
         epoch_leg = {"interactions_per_sec": n_ep * b / te3, "seconds": te3, "steps": n_ep, "first_epoch_seconds": te,
                      "first_epoch_interactions_per_sec": n_ep * b / te,
                      "unpipelined_seconds": te, "epoch_drawing_ahead_too_seconds": te2, "host_queued_after_seconds": te3_host,
+                     "epochs_seconds": [te, te2, te3],
                      "note": "third of three consecutive full epochs (every row's moments aged by real training), pipelined as "
                              "BPRMF.fit() runs: its negatives were drawn during the previous epoch and it draws the next "
-                             "epoch's while training; includes the epoch permutation.  first_epoch = sampling in line."}
+                             "epoch's while training; includes the epoch permutation.  first_epoch = sampling in line.  (The third epoch's time "
+                             "varies from run to run on shared boxes, 1.04-1.6 s, with or without the helper thread: "
+                             "SKR_BENCH_NO_AHEAD3=1; the first two do not.)"}
 
     out = {
         "metric": "train interactions/sec + eval users/sec (HR@10/NDCG@10) at 1/2/4/8 MI355X",
