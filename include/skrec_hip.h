@@ -94,6 +94,13 @@ int skr_randint_choice(skr_sampler* s, int high, int size, int replace, const fl
  * Synchronises the stream once at the end (it must learn how many words were consumed). */
 int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
                            const int32_t* d_pos_sorted, int64_t nnz, int num_neg, int32_t* d_out, void* stream);
+/* The same epoch without the read-back at the start of the call: the row statistics of the CSR (longest row, sum of squared
+ * row lengths: h_stats2[0], [1]) are taken ONCE with skr_csr_row_stats (which waits for its own kernel) -- a data set's CSR does
+ * not change between epochs (data_iterator.py:30-42 builds it in the constructor) -- and the call only queues work.  A failure of
+ * the PREVIOUS epoch (stream exhausted) is reported from a status word that was copied to the host behind that epoch. */
+int skr_csr_row_stats(const int64_t* d_rowptr, int n_rows, int64_t* h_stats2, void* stream);
+int skr_sample_epoch_exact_stats(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr, const int32_t* d_pos_sorted,
+                                 int64_t nnz, int num_neg, int32_t* d_out, const int64_t* h_stats2, void* stream);
 
 /* The same exact-stream epoch when the number of draws of a user is NOT the size of its exclusion set:
  * the sequential iterators (data_iterator.py:237-331: one draw group per training sequence, exclusion =

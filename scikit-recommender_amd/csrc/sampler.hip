@@ -964,6 +964,9 @@ struct skr_sampler {
     std::vector<hipEvent_t> gen_events;
     hipEvent_t start_event = nullptr;
     int64_t* h_ctl = nullptr;               // pinned: the one read-back per exact-epoch call lands here
+    int64_t* h_status = nullptr;            // pinned: the status word of the LAST epoch, copied behind it (see status_event)
+    hipEvent_t status_event = nullptr;      // recorded behind that copy
+    bool status_pending = false;
     unsigned long long* d_ev_bits = nullptr;
     unsigned long long* d_rej_bits = nullptr;
     uint32_t* d_ev_mask = nullptr;
@@ -1016,6 +1019,8 @@ int skr_sampler_destroy(skr_sampler* s) {
     for (hipEvent_t e : s->gen_events) (void)hipEventDestroy(e);
     if (s->start_event) (void)hipEventDestroy(s->start_event);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    if (s->h_status) (void)hipHostFree(s->h_status);
+    if (s->status_event) (void)hipEventDestroy(s->status_event);
     (void)hipFree(s->d_ev_bits);
     (void)hipFree(s->d_rej_bits);
     (void)hipFree(s->d_ev_mask);
@@ -1246,19 +1251,37 @@ static int run_exact_epoch_slabs(skr_sampler* s, int num_items, int n_users, con
 // epoch filled every slot.  Then the path: slabs for sparse data, the serial kernel otherwise.
 static int run_exact_epoch(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr, const int32_t* d_pos_sorted,
                            const int64_t* d_drawptr, int num_neg, int64_t n_slots, int64_t nnz, int32_t* d_out, hipStream_t st,
-                           const char* who) {
-    SKR_HIP(hipMemsetAsync(s->d_ctl + SL_SCRATCH, 0, 2 * sizeof(int64_t), st));
-    int blocks = (n_users + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(max_row_len_kernel, dim3(blocks), dim3(256), 0, st, d_rowptr, n_users, reinterpret_cast<int*>(s->d_ctl + SL_SCRATCH),
-                       reinterpret_cast<unsigned long long*>(s->d_ctl + SL_SUMSQ));
-    SKR_LAUNCH_CHECK();
-    if (!s->h_ctl) SKR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctl), (SL_STATUS + 1) * sizeof(int64_t), hipHostMallocDefault));
-    int64_t* host = s->h_ctl;
-    SKR_HIP(hipMemcpyAsync(host, s->d_ctl, (SL_STATUS + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    SKR_HIP(hipStreamSynchronize(st));
-    const int max_len = static_cast<int>(host[SL_SCRATCH] & 0xffffffff);
-    if (host[SL_STATUS] == 2) {
+                           const char* who, const int64_t* h_stats = nullptr) {
+    int max_len;
+    unsigned long long sumsq;
+    bool prev_failed = false;
+    if (h_stats) {
+        // the caller took the row statistics once (skr_csr_row_stats: the CSR does not change between epochs): nothing to read
+        // back here, the call only queues work.  The previous epoch's status word was copied behind that epoch: it has
+        // normally arrived long ago.
+        max_len = static_cast<int>(h_stats[0]);
+        sumsq = static_cast<unsigned long long>(h_stats[1]);
+        if (s->status_pending) {
+            SKR_HIP(hipEventSynchronize(s->status_event));
+            prev_failed = s->h_status[0] == 2;
+        }
+    } else {
+        SKR_HIP(hipMemsetAsync(s->d_ctl + SL_SCRATCH, 0, 2 * sizeof(int64_t), st));
+        int blocks = (n_users + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(max_row_len_kernel, dim3(blocks), dim3(256), 0, st, d_rowptr, n_users, reinterpret_cast<int*>(s->d_ctl + SL_SCRATCH),
+                           reinterpret_cast<unsigned long long*>(s->d_ctl + SL_SUMSQ));
+        SKR_LAUNCH_CHECK();
+        if (!s->h_ctl) SKR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctl), (SL_STATUS + 1) * sizeof(int64_t), hipHostMallocDefault));
+        int64_t* host = s->h_ctl;
+        SKR_HIP(hipMemcpyAsync(host, s->d_ctl, (SL_STATUS + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        SKR_HIP(hipStreamSynchronize(st));
+        max_len = static_cast<int>(host[SL_SCRATCH] & 0xffffffff);
+        sumsq = static_cast<unsigned long long>(host[SL_SUMSQ]);
+        prev_failed = host[SL_STATUS] == 2;
+    }
+    s->status_pending = false;
+    if (prev_failed) {
         SKR_HIP(hipMemsetAsync(s->d_ctl + SL_STATUS, 0, sizeof(int64_t), st));
         return skr::fail(SKR_EOVERFLOW, "%s: the previous exact epoch ran out of generated words before every slot was filled", who);
     }
@@ -1266,12 +1289,22 @@ static int run_exact_epoch(skr_sampler* s, int num_items, int n_users, const int
     const char* path = getenv("SKR_EXACT_PATH");
     const bool force_slab = path && !strcmp(path, "slab"), force_serial = path && !strcmp(path, "serial");
     const bool sparse = static_cast<int64_t>(max_len) * 16 <= num_items;
+    int rc;
     if (!force_serial && sparse && (force_slab || n_slots >= 4096)) {
         const double lemire = static_cast<double>((0u - static_cast<uint32_t>(num_items)) % static_cast<uint32_t>(num_items)) / 4294967296.0;
-        const double rate = (nnz > 0 ? static_cast<double>(static_cast<unsigned long long>(host[SL_SUMSQ])) / (static_cast<double>(nnz) * num_items) : 0.0) + lemire;
-        return run_exact_epoch_slabs(s, num_items, n_users, d_rowptr, d_pos_sorted, d_drawptr, num_neg, n_slots, d_out, rate, st);
+        const double rate = (nnz > 0 ? static_cast<double>(sumsq) / (static_cast<double>(nnz) * num_items) : 0.0) + lemire;
+        rc = run_exact_epoch_slabs(s, num_items, n_users, d_rowptr, d_pos_sorted, d_drawptr, num_neg, n_slots, d_out, rate, st);
+    } else {
+        rc = run_exact_epoch_serial(s, num_items, n_users, d_rowptr, d_pos_sorted, d_drawptr, num_neg, n_slots, d_out, st);
     }
-    return run_exact_epoch_serial(s, num_items, n_users, d_rowptr, d_pos_sorted, d_drawptr, num_neg, n_slots, d_out, st);
+    if (rc != SKR_OK) return rc;
+    // this epoch's status word, copied behind it: the next call looks at it without waiting for anything
+    if (!s->h_status) SKR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_status), sizeof(int64_t), hipHostMallocDefault));
+    if (!s->status_event) SKR_HIP(hipEventCreateWithFlags(&s->status_event, hipEventDisableTiming));
+    SKR_HIP(hipMemcpyAsync(s->h_status, s->d_ctl + SL_STATUS, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    SKR_HIP(hipEventRecord(s->status_event, st));
+    s->status_pending = true;
+    return SKR_OK;
 }
 
 int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,
@@ -1286,6 +1319,43 @@ int skr_sample_epoch_exact(skr_sampler* s, int num_items, int n_users, const int
     SKR_REQUIRE(n_slots < (int64_t(1) << 31), "more than 2^31-1 samples per call (the reference's int limit)");
     return run_exact_epoch(s, num_items, n_users, d_rowptr, d_pos_sorted, nullptr, num_neg, n_slots, nnz, d_out, st,
                            "skr_sample_epoch_exact");
+}
+
+int skr_csr_row_stats(const int64_t* d_rowptr, int n_rows, int64_t* h_stats2, void* stream) {
+    SKR_REQUIRE(d_rowptr && h_stats2, "skr_csr_row_stats: NULL argument");
+    SKR_REQUIRE(n_rows >= 0, "skr_csr_row_stats: negative size");
+    hipStream_t st = skr::as_stream(stream);
+    int64_t* d = nullptr;
+    SKR_HIP(hipMalloc(&d, 2 * sizeof(int64_t)));
+    SKR_HIP(hipMemsetAsync(d, 0, 2 * sizeof(int64_t), st));
+    if (n_rows > 0) {
+        int blocks = (n_rows + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(max_row_len_kernel, dim3(blocks), dim3(256), 0, st, d_rowptr, n_rows, reinterpret_cast<int*>(d),
+                           reinterpret_cast<unsigned long long*>(d + 1));
+    }
+    int64_t h[2] = {0, 0};
+    const hipError_t e1 = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st), e2 = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    SKR_HIP(e1);
+    SKR_HIP(e2);
+    h_stats2[0] = h[0] & 0xffffffff;
+    h_stats2[1] = h[1];
+    return SKR_OK;
+}
+
+int skr_sample_epoch_exact_stats(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr, const int32_t* d_pos_sorted,
+                                 int64_t nnz, int num_neg, int32_t* d_out, const int64_t* h_stats2, void* stream) {
+    SKR_REQUIRE(s && d_rowptr && d_pos_sorted && d_out && h_stats2, "skr_sample_epoch_exact_stats: NULL argument");
+    SKR_REQUIRE(num_items > 1, "'high' must be larger than 1.");
+    SKR_REQUIRE(n_users > 0 && num_neg > 0, "skr_sample_epoch_exact_stats: n_users and num_neg must be positive");
+    SKR_REQUIRE(nnz >= 0 && h_stats2[0] >= 0 && h_stats2[1] >= 0, "skr_sample_epoch_exact_stats: negative size");
+    hipStream_t st = skr::as_stream(stream);
+    if (nnz == 0) return SKR_OK;
+    const int64_t n_slots = nnz * num_neg;
+    SKR_REQUIRE(n_slots < (int64_t(1) << 31), "more than 2^31-1 samples per call (the reference's int limit)");
+    return run_exact_epoch(s, num_items, n_users, d_rowptr, d_pos_sorted, nullptr, num_neg, n_slots, nnz, d_out, st,
+                           "skr_sample_epoch_exact_stats", h_stats2);
 }
 
 int skr_sample_epoch_exact_counts(skr_sampler* s, int num_items, int n_users, const int64_t* d_rowptr,

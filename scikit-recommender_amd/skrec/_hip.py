@@ -32,6 +32,8 @@ SIGNATURES = {
     "skr_randint_choice": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp]),
     "skr_sample_epoch_exact": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, vp]),
     "skr_sample_epoch_exact_counts": (i32, [vp, i32, i32, vp, vp, i64, vp, i64, vp, vp]),
+    "skr_csr_row_stats": (i32, [vp, i32, C.POINTER(i64), vp]),
+    "skr_sample_epoch_exact_stats": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, C.POINTER(i64), vp]),
     "skr_sample_epoch_fast": (i32, [u64, u64, i64, i32, i32, vp, vp, i64, i32, vp, vp]),
     "skr_adam_block_mark": (i32, [vp, i64, i64, i32, vp, i32, vp, i64, vp]),
     "skr_adam_block_cold": (i32, [vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, i32, vp]),

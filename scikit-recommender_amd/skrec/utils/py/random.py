@@ -69,9 +69,23 @@ class DeviceSampler(object):
         return out
 
     def sample_epoch_exact(self, num_items, n_users, d_rowptr, d_pos_sorted, nnz, num_neg, d_out):
-        _hip.check(_hip.lib().skr_sample_epoch_exact(self._h, int(num_items), int(n_users), _hip.ptr(d_rowptr),
-                                                     _hip.ptr(d_pos_sorted), int(nnz), int(num_neg), _hip.ptr(d_out),
-                                                     _hip.stream()))
+        """one epoch of negatives on the reference's stream.  The CSR's row statistics are taken on the first call with a
+        given ``d_rowptr`` (same storage, same length, not written to since: torch's version counter) and kept: every later
+        call only queues work -- no read-back, the host does not wait for the device."""
+        key = (d_rowptr.data_ptr(), int(n_users), int(nnz), d_rowptr._version)
+        cache = self.__dict__.setdefault("_stats", {})
+        hit = cache.get(key)
+        if hit is None:
+            stats = (C.c_int64 * 2)()
+            _hip.check(_hip.lib().skr_csr_row_stats(_hip.ptr(d_rowptr), int(n_users), stats, _hip.stream()))
+            if len(cache) >= 64:
+                cache.clear()
+            # the tensor is kept with its statistics: while the entry lives, the storage's address cannot go to another tensor
+            hit = cache[key] = (stats, d_rowptr)
+        stats = hit[0]
+        _hip.check(_hip.lib().skr_sample_epoch_exact_stats(self._h, int(num_items), int(n_users), _hip.ptr(d_rowptr),
+                                                           _hip.ptr(d_pos_sorted), int(nnz), int(num_neg), _hip.ptr(d_out), stats,
+                                                           _hip.stream()))
 
     def last_epoch(self):
         """how the last exact epoch ran: dict(status, handed_over, filled, consumed) -- see skr_sampler_last_epoch"""
