@@ -750,9 +750,9 @@ def main():
     timed = prefix(K * b, warm["end_user"] if warm else (pre["end_user"] if pre else 0))
     assert timed["nnz"] >= K * b, "dataset too small for --steps"
     sampler = DeviceSampler(2020)
-    def sample_slice(sl):
+    def sample_slice(sl, smp=None):
         neg = torch.empty(sl["nnz"], dtype=torch.int32, device=dev)
-        sampler.sample_epoch_exact(nI, sl["n_users"], sl["rowptr"], sl["items"], sl["nnz"], 1, neg)
+        (smp or sampler).sample_epoch_exact(nI, sl["n_users"], sl["rowptr"], sl["items"], sl["nnz"], 1, neg)
         if os.environ.get("SKR_BENCH_SYNC_AFTER_SAMPLER") == "1":     # diagnosis of shared-GPU rehearsals only
             torch.cuda.synchronize()
         return neg
@@ -1051,9 +1051,13 @@ def main():
         ahead_stream = torch.cuda.Stream(device=dev)
         box = {}
 
+        # the helper draws with a generator of its own: in the second epoch the main thread samples in line at the same time, and
+        # a sampler handle is not re-entrant (in fit() the two never overlap: the epoch in hand was drawn during the previous one)
+        sampler_ahead = DeviceSampler(2021)
+
         def draw_ahead():
             with torch.cuda.stream(ahead_stream):
-                box["neg"] = sample_slice(whole)
+                box["neg"] = sample_slice(whole, sampler_ahead)
         th = threading.Thread(target=draw_ahead, daemon=True)
         t1e = time.perf_counter()
         th.start()
