@@ -158,8 +158,8 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
 // once): the two products [x, h] Wg and [x, r*h] Wc on the matrix cores, v_mfma_f32_32x32x2_f32 (fp32 operands, fp32
 // accumulation).  A workgroup takes 32 sessions: their [x, h] rows sit in LDS (row stride K + 1: the 32 rows of a column then
 // fall into 32 banks) as the A operand; a wavefront owns 32-column tiles of the output and streams the weight rows of its
-// columns from L2 (coalesced 128-byte reads, eight k-steps ahead); the gates' r*h and u pass to the candidate phase through
-// LDS.  1 M sessions, d = 128 (tools/gru_sweep_lab.py): 3.99 ms per step = 49 TFLOP/s, the vector-FMA kernel (16 sessions per
+// columns from L2 (coalesced 128-byte reads, two 16-k chunks ahead); the gates' r*h passes to the candidate phase through LDS,
+// u in the registers of the wavefront that owns those columns in both phases (50 KB of LDS: three workgroups per CU).  1 M sessions, d = 128 (tools/gru_sweep_lab.py): 3.99 ms per step = 49 TFLOP/s, the vector-FMA kernel (16 sessions per
 // workgroup) 6.58 ms = 30 TFLOP/s; hardware exp2 / reciprocal in the activations would give 3.85 ms and were not taken (the
 // sweep then rounds differently from the training step).  Sums are formed pairwise in k inside an MFMA and then in k order:
 // equal to the FMA chain to rounding.
@@ -175,7 +175,6 @@ __global__ __launch_bounds__(G_T) void gru_fwd_mfma_kernel(GruIn g, const uint8_
                                                            float* __restrict__ c_out, float* __restrict__ h_new) {
     __shared__ float a[GM_ROWS][G_KMAX + 1];
     __shared__ float rh[GM_ROWS][H + 1];
-    __shared__ float us[GM_ROWS][H + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int IN = g.in_dim, K = IN + H;
     const int row0 = blockIdx.x * GM_ROWS;
@@ -195,11 +194,11 @@ __global__ __launch_bounds__(G_T) void gru_fwd_mfma_kernel(GruIn g, const uint8_
     }
     __syncthreads();
     const int m = lane & 31, kh = lane >> 5;            // A[row m][k + kh], B[k + kh][col m]
-    // NT 32 x 32 output tiles side by side (columns col0 + 32 t): acc[t] += A * W(:, col0 + 32 t ...).  Rows [0, n1) of W meet
+    // NT 32 x 32 output tiles (columns col0 + tstride t): acc[t] += A * W(:, col0 + tstride t ...).  Rows [0, n1) of W meet
     // src's columns, rows [n1, n1 + n2) meet src2's (r*h in the candidate phase).  Two tiles share every A value and give the
     // matrix pipe two independent accumulation chains.
     auto tiles = [&](auto nt_c, gru_f32x16* acc, const float (*src)[G_KMAX + 1], const float (*src2)[H + 1], int n1, int n2,
-                     const float* __restrict__ W, int ld, int col0) {
+                     const float* __restrict__ W, int ld, int col0, int tstride) {
         constexpr int NT = decltype(nt_c)::value;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(G_T) void gru_fwd_mfma_kernel(GruIn g, const uint8_
             for (int q = 0; q < 8; ++q) {
                 const int k = k0 + 2 * q + kh;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) bb[t][q] = k < n ? wcol[static_cast<int64_t>(k) * ld + 32 * t] : 0.0f;
+                for (int t = 0; t < NT; ++t) bb[t][q] = k < n ? wcol[static_cast<int64_t>(k) * ld + tstride * t] : 0.0f;
                 aa[q] = k < n1 ? src[m][k] : (k < n ? (src2 ? src2[m][k - n1] : src[m][k]) : 0.0f);
             }
         };
@@ -235,34 +234,31 @@ __global__ __launch_bounds__(G_T) void gru_fwd_mfma_kernel(GruIn g, const uint8_
         }
     };
     // accumulator element i of a lane: row 8 * (i / 4) + 4 * kh + i % 4, column m
-    {   // gates: C / 32 column tiles over the four wavefronts, two at a time where there are eight
-        constexpr int C = 2 * H, NT = (C / 32 >= 8) ? 2 : 1;
-        for (int ct = wv * NT; ct < C / 32; ct += (G_T / 64) * NT) {
-            gru_f32x16 acc[NT];
-            tiles(std::integral_constant<int, NT>{}, acc, a, nullptr, K, 0, Wg, C, ct * 32);
+    // A wavefront takes the r tile and the u tile of the SAME 32 hidden columns (two accumulation chains that share every A
+    // value), then -- behind the barrier that publishes r*h -- the candidate tile of those columns: u stays in its registers.
+    // (Hidden sizes below 128 leave wavefronts without a tile: 64 -> two work, 32 -> one.)
+    const int ct = wv;
+    const bool mine = ct < H / 32;
+    float ureg[16];
+    if (mine) {
+        gru_f32x16 acc[2];
+        tiles(std::integral_constant<int, 2>{}, acc, a, nullptr, K, 0, Wg, 2 * H, ct * 32, H);
+        const int j = ct * 32 + m;
+        const float b_r = bg[j], b_u = bg[H + j];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int j = (ct + t) * 32 + m;
-                const float b = bg[j];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int r = 8 * (i >> 2) + 4 * kh + (i & 3), row = row0 + r;
-                    const float sgm = sigmoidf_(acc[t][i] + b);
-                    if (j < H) {
-                        rh[r][j] = sgm * a[r][IN + j];
-                        if (r_out && row < g.B) r_out[static_cast<int64_t>(row) * H + j] = sgm;
-                    } else {
-                        us[r][j - H] = sgm;
-                        if (u_out && row < g.B) u_out[static_cast<int64_t>(row) * H + (j - H)] = sgm;
-                    }
-                }
-            }
+        for (int i = 0; i < 16; ++i) {
+            const int r = 8 * (i >> 2) + 4 * kh + (i & 3), row = row0 + r;
+            const float rg = sigmoidf_(acc[0][i] + b_r);
+            ureg[i] = sigmoidf_(acc[1][i] + b_u);
+            rh[r][j] = rg * a[r][IN + j];
+            if (r_out && row < g.B) r_out[static_cast<int64_t>(row) * H + j] = rg;
+            if (u_out && row < g.B) u_out[static_cast<int64_t>(row) * H + j] = ureg[i];
         }
     }
     __syncthreads();
-    for (int ct = wv; ct < H / 32; ct += G_T / 64) {     // candidate and new state
+    if (mine) {                                            // candidate and new state
         gru_f32x16 acc1[1];
-        tiles(std::integral_constant<int, 1>{}, acc1, a, rh, IN, H, Wc, H, ct * 32);
+        tiles(std::integral_constant<int, 1>{}, acc1, a, rh, IN, H, Wc, H, ct * 32, 0);
         const gru_f32x16& acc = acc1[0];
         const int j = ct * 32 + m;
         const float b = bc[j];
@@ -271,7 +267,7 @@ __global__ __launch_bounds__(G_T) void gru_fwd_mfma_kernel(GruIn g, const uint8_
             const int r = 8 * (i >> 2) + 4 * kh + (i & 3), row = row0 + r;
             if (row < g.B) {
                 const float c = hidden_act(acc[i] + b, act);
-                const float ho = a[r][IN + j], u = us[r][j];
+                const float ho = a[r][IN + j], u = ureg[i];
                 float hn = u * ho + (1.0f - u) * c;
                 if (active && !active[row]) hn = ho;        // finished history: the state is carried
                 if (c_out) c_out[static_cast<int64_t>(row) * H + j] = c;
