@@ -159,10 +159,11 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
 // accumulation).  A workgroup takes 32 sessions: their [x, h] rows sit in LDS (row stride K + 1: the 32 rows of a column then
 // fall into 32 banks) as the A operand; a wavefront owns 32-column tiles of the output and streams the weight rows of its
 // columns from L2 (coalesced 128-byte reads, two 16-k chunks ahead); the gates' r*h passes to the candidate phase through LDS,
-// u in the registers of the wavefront that owns those columns in both phases (50 KB of LDS: three workgroups per CU).  1 M sessions, d = 128 (tools/gru_sweep_lab.py): 3.99 ms per step = 49 TFLOP/s, the vector-FMA kernel (16 sessions per
-// workgroup) 6.58 ms = 30 TFLOP/s; hardware exp2 / reciprocal in the activations would give 3.85 ms and were not taken (the
-// sweep then rounds differently from the training step).  Sums are formed pairwise in k inside an MFMA and then in k order:
-// equal to the FMA chain to rounding.
+// u in the registers of the wavefront that owns those columns in both phases (50 KB of LDS: three workgroups per CU).
+// 1 M sessions, d = 128 (tools/gru_sweep_lab.py): 3.19 ms per step = 62 TFLOP/s, the vector-FMA kernel (16 sessions per
+// workgroup) 6.58 ms = 30 TFLOP/s.  (With u through LDS and two workgroups per CU: 3.99 ms.  Hardware exp2 / reciprocal in the
+// activations gave 3 % and were not taken: the sweep would round differently from the training step.)  Sums are formed
+// pairwise in k inside an MFMA and then in k order: equal to the FMA chain to rounding.
 // ------------------------------------------------------------------------------------------------
 typedef float gru_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GM_ROWS = 32;
