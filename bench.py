@@ -522,6 +522,7 @@ def finish(args, world, rank, dev, dist, full, V, bias, out):
                                        not args.no_cpu_baseline)
     if not args.no_gru and 128 % world == 0:
         out["gru4rec"] = gru_leg(args, world, rank, dev, dist, args.gru_steps, 10, not args.no_cpu_baseline)
+    out.update(dist_info(world, dist))
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -624,6 +625,53 @@ def bprmf_strong(args, world, rank, dev, dist, full, ds):
     finish(args, world, rank, dev, dist, full, eng.item_rows, eng.item_bias, out)
 
 
+def dist_info(world, dist):
+    """what the collectives of this run really were: rccl_ranks = the group size torch.distributed saw on backend "nccl"
+    (= RCCL on ROCm); 0 for a gloo rehearsal; 1 for a single process (no group)"""
+    if world > 1 and dist.is_initialized():
+        be = dist.get_backend()
+        return {"dist_backend": be, "rccl_ranks": dist.get_world_size() if be == "nccl" else 0,
+                "gpus_visible": torch.cuda.device_count()}
+    return {"dist_backend": None, "rccl_ranks": 1, "gpus_visible": torch.cuda.device_count()}
+
+
+def launch_command(n_ranks, argv, port, script=None):
+    """the driver's own N > 1 form: one fresh process per GPU under torch.distributed.run, rendezvous on 127.0.0.1"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n_ranks, argv, script=None, env=None):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process becomes the launcher.  It has made NO
+    HIP call (torch.cuda.device_count() counts devices without initialising one) and makes none: it starts N fresh children
+    (never an exec of a process that has touched the GPU), relays their output -- rank 0 prints the JSON line -- and returns
+    their exit status.  With fewer visible GPUs than ranks RCCL cannot form the group (one process per GPU), so unless
+    SKR_DIST_BACKEND says otherwise the ranks rehearse on gloo, sharing the card(s); the line then carries rccl_ranks = 0."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ if env is None else env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
+    n_dev = torch.cuda.device_count()
+    if "SKR_DIST_BACKEND" not in env and n_dev < n_ranks:
+        print(f"[bench] {n_ranks} ranks but {n_dev} visible GPU(s): rehearsing on gloo (SKR_DIST_BACKEND=gloo); nothing in "
+              "this run is an RCCL / xGMI measurement", file=sys.stderr)
+        env["SKR_DIST_BACKEND"] = "gloo"
+        # processes time-slicing one card: every cross-stream wait becomes milliseconds; keep each on one stream
+        env.setdefault("SKR_ADAM_OVERLAP", "0")
+        env.setdefault("SKR_SAMPLER_ONE_STREAM", "1")
+    cmd = launch_command(n_ranks, argv, port, script)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:            # relayed as it comes; stderr goes straight through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["bprmf", "lightgcn", "gru4rec"], default="bprmf")
@@ -652,6 +700,9 @@ def main():
     ap.add_argument("--lightgcn-warmup", type=int, default=2)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher (no HIP call has been made in this process)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -679,6 +730,7 @@ def main():
         out = {"metric": "train interactions/sec + eval users/sec (HR@10/NDCG@10) at 1/2/4/8 MI355X", "higher_is_better": True,
                "vs_baseline": None, "data": "synthetic"}
         out.update(leg)
+        out.update(dist_info(world, dist))
         if rank == 0:
             print(json.dumps(out))
         if world > 1:
@@ -690,6 +742,7 @@ def main():
         out = {"metric": "train interactions/sec + eval users/sec (HR@10/NDCG@10) at 1/2/4/8 MI355X", "higher_is_better": True,
                "vs_baseline": None, "data": "synthetic"}
         out.update(leg)
+        out.update(dist_info(world, dist))
         if rank == 0:
             print(json.dumps(out))
         if world > 1:

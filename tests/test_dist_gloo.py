@@ -95,3 +95,45 @@ def test_fast_sampler_twin_is_shard_invariant():
     lo = sample_fast(9, 2, 0, 25, rowptr[:cut_u + 1].copy(), pos[:cut].copy(), 2)
     hi = sample_fast(9, 2, cut * 2, 25, (rowptr[cut_u:] - cut).copy(), pos[cut:].copy(), 2)
     assert np.array_equal(np.concatenate([lo, hi]), whole)
+
+
+def test_launch_command_is_the_drivers_form():
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "20", "--warmup", "5"], 29411)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29411"
+    assert cmd[-7] == os.path.abspath(bench.__file__) and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+
+
+_STUB = """
+import json, os, sys
+import torch.distributed as dist
+dist.init_process_group("gloo")          # env:// -- what torch.distributed.run exports
+r, w = dist.get_rank(), dist.get_world_size()
+import torch
+t = torch.tensor([float(r + 1)])
+dist.all_reduce(t)
+if r == 0:
+    print(json.dumps({"world": w, "sum": float(t), "argv": sys.argv[1:], "backend_env": os.environ.get("SKR_DIST_BACKEND"),
+                      "master": os.environ["MASTER_ADDR"], "ipc": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}))
+dist.destroy_process_group()
+sys.exit(int(os.environ.get("STUB_EXIT", "0")) if r == w - 1 else 0)
+"""
+
+
+def test_launcher_starts_fresh_ranks_and_relays_rank0(tmp_path, capfd):
+    """`python bench.py --gpus 2` without WORLD_SIZE: the parent starts two children under torch.distributed.run, relays rank
+    0's line and returns the children's status (a stub script stands in for bench.py's body: no GPU here)."""
+    import json
+    stub = tmp_path / "stub.py"
+    stub.write_text(_STUB)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SKR_DIST_BACKEND")}
+    rc = bench.launch_ranks(2, ["--gpus", "2", "--steps", "3"], script=str(stub), env=env)
+    out = capfd.readouterr().out
+    assert rc == 0
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    assert line["world"] == 2 and line["sum"] == 3.0 and line["argv"] == ["--gpus", "2", "--steps", "3"]
+    assert line["master"] == "127.0.0.1" and line["ipc"] == "0"
+    assert line["backend_env"] == "gloo"          # no GPU visible here: fewer devices than ranks => rehearsal backend
+    env["STUB_EXIT"] = "3"
+    assert bench.launch_ranks(2, [], script=str(stub), env=env) != 0      # a failing rank fails the launcher

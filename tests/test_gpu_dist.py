@@ -218,6 +218,30 @@ def test_bprmf_fit_on_rccl(exchange, tiny_dir, tmp_path):
     assert np.array_equal(res[0]["V1"], res[1]["V1"])
 
 
+_TWO_GPUS = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL branch needs two GPUs (one process per GPU); the "
+                               "test boxes of this environment have one -- it runs as soon as a multi-GPU box executes the suite")
+
+
+@_TWO_GPUS
+@pytest.mark.parametrize("plan", ["auto", "1"])
+def test_lightgcn_fit_on_rccl(plan, tiny_dir, tmp_path, monkeypatch):
+    """ShardedLightGCN through the drop-in API on two RCCL ranks (the asynchronous all-reduce of the item block beside the
+    user-side product, the compact exchanges of the masked layers with the plan forced) == the reference's recorded run"""
+    monkeypatch.setenv("SKR_SPMM_PLAN", plan)
+    g = np.load(os.path.join(GOLDEN, "golden_lightgcn.npz"))
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_api_worker, args=(2, _free_port(), tiny_dir, str(tmp_path), ret, "nccl"), nprocs=2, join=True)
+        res = {k: ret[k] for k in range(2)}
+    for r in res.values():
+        np.testing.assert_allclose(r["losses"][:, 0], g["bpr_mean"], rtol=1e-5)
+        np.testing.assert_allclose(r["losses"][:, 1], g["l2"], rtol=1e-5)
+        np.testing.assert_allclose(r["reports"], g["reports"], rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(r["U1"], g["U1"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=3e-6)
+    assert np.array_equal(res[0]["V1"], res[1]["V1"]) and np.array_equal(res[0]["reports"], res[1]["reports"])
+
+
 def _layergcn_worker(rank, world, port, data_dir, workdir, dropout, ret, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world), SKR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -276,6 +300,29 @@ def test_layergcn_fit_under_torchrun_contract(world, plan, tiny_dir, tmp_path, m
         np.testing.assert_allclose(r["Uf"], g["Uf"], rtol=0, atol=6e-6)
         np.testing.assert_allclose(r["pred"], g["pred"], rtol=1e-4, atol=2e-6)
     assert np.array_equal(res[0]["V1"], res[1]["V1"]) and np.array_equal(res[0]["reports"], res[world - 1]["reports"])
+
+
+@_TWO_GPUS
+@pytest.mark.parametrize("plan,dropout", [("auto", 0.0), ("1", 0.0), ("1", 0.25)])
+def test_layergcn_fit_on_rccl(plan, dropout, tiny_dir, tmp_path, monkeypatch):
+    """ShardedLayerGCN.fit() on two RCCL ranks == the reference's recorded run (dropout 0); with edge dropout the pruning draw
+    of rank 0 is broadcast over RCCL and the replicas stay bit-identical"""
+    monkeypatch.setenv("SKR_SPMM_PLAN", plan)
+    g = np.load(os.path.join(GOLDEN, "golden_layergcn.npz"))
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_layergcn_worker, args=(2, _free_port(), tiny_dir, str(tmp_path), dropout, ret, "nccl"), nprocs=2, join=True)
+        res = {k: ret[k] for k in range(2)}
+    if dropout == 0.0:
+        for r in res.values():
+            total = r["losses"][:, 0] + np.float32(1e-2) * r["losses"][:, 1]
+            np.testing.assert_allclose(total, g["loss"], rtol=1e-5)
+            np.testing.assert_allclose(r["reports"], g["reports"], rtol=1e-5, atol=2e-4)
+            np.testing.assert_allclose(r["U1"], g["U1"], rtol=0, atol=3e-6)
+            np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=3e-6)
+    else:
+        assert np.isfinite(res[0]["losses"]).all()
+    assert np.array_equal(res[0]["V1"], res[1]["V1"]) and np.array_equal(res[0]["reports"], res[1]["reports"])
 
 
 @pytest.mark.parametrize("plan", ["auto", "1"])

@@ -285,7 +285,11 @@ def _sharded_gru_worker(rank, world, port, ret, rccl_one=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from skrec.parallel import DistContext
     from skrec.recommender.GRU4RecPlus import SessionGRU, ShardedSessionGRU
-    if world > 1:
+    if world > 1 and rccl_one == "rccl":      # one process per GPU on RCCL
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        rccl_one = False
+    elif world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     if rccl_one:      # a group of one rank on RCCL, forced through the sharded engine's collectives
         os.environ["SKR_DIST_FORCE_ACTIVE"] = "1"
@@ -356,6 +360,27 @@ def test_session_sharded_steps_equal_the_single_process_steps(world):
         np.testing.assert_allclose(many[r]["flat"], one["flat"], rtol=0, atol=3e-5)
         np.testing.assert_allclose(many[r]["state"], one["state"][many[r]["lo"]:many[r]["hi"]], rtol=0, atol=3e-5)
         assert np.array_equal(many[r]["flat"], many[0]["flat"])          # replicas: the same bits
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL branch needs two GPUs (one process per GPU); the test boxes of "
+                    "this environment have one -- it runs as soon as a multi-GPU box executes the suite")
+def test_session_sharded_steps_on_rccl():
+    """ShardedSessionGRU on two RCCL ranks (all_gather_into_tensor of the compact block between two GPUs) == the
+    single-process steps; replicas bit-identical"""
+    import torch.multiprocessing as mp
+    from test_gpu_dist import _free_port
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_sharded_gru_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+        one = ret[0]
+        ret2 = mgr.dict()
+        mp.spawn(_sharded_gru_worker, args=(2, _free_port(), ret2, "rccl"), nprocs=2, join=True)
+        many = {k: ret2[k] for k in range(2)}
+    for r in range(2):
+        np.testing.assert_allclose(many[r]["losses"], one["losses"], rtol=2e-5)
+        np.testing.assert_allclose(many[r]["flat"], one["flat"], rtol=0, atol=3e-5)
+        np.testing.assert_allclose(many[r]["state"], one["state"][many[r]["lo"]:many[r]["hi"]], rtol=0, atol=3e-5)
+    assert np.array_equal(many[0]["flat"], many[1]["flat"])
 
 
 def test_config4_shape_steps_match_oracle():
