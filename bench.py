@@ -129,6 +129,8 @@ def lightgcn_leg(args, world, rank, dev, dist, full, K, W, cpu_baseline):
     eng = ShardedLightGCN.from_device_edges(ctx, full["users"], full["items"], nU, nI, user0, item0, 3, 1e-3, 1e-3, b)
     # the epoch slice these steps consume: a user prefix, sampled with the exact stream on every rank
     need = (W + K + 8) * gb
+    if world == 1 and args.large_batches:
+        need = max(need, 4 * max(int(x) for x in args.large_batches.split(",") if x))
     end_user = min(int(torch.searchsorted(full["rowptr"], torch.tensor(need, device=dev))) + 1, nU)
     nnz = int(full["rowptr"][end_user])
     assert nnz >= need, "dataset too small for the LightGCN leg"
@@ -212,6 +214,29 @@ def lightgcn_leg(args, world, rank, dev, dist, full, K, W, cpu_baseline):
         del adj
         leg["cpu_baseline"] = {"value": b / t_step, "unit": "train interactions/s", "cores": cores, "kind": "port", "sample": sample}
         leg["speedup_vs_cpu_baseline"] = leg["value"] / leg["cpu_baseline"]["value"]
+    # separately labelled large-batch variants (batch_size is a config knob, LightGCN.py:37): the same engine,
+    # the same full-graph propagation per step, more interactions per step
+    for bl in ([int(x) for x in args.large_batches.split(",") if x] if (world == 1 and args.large_batches) else []):
+        if (1 + 3) * bl > nnz:
+            continue
+        eng.batch_size_cfg, gb_l = bl, bl
+
+        def run_l(n_steps, off):
+            for s_ in range(n_steps):
+                sl = slice(off + s_ * gb_l, off + (s_ + 1) * gb_l)
+                eng.train_step(uu_l[sl], ii_l[sl], jj_l[sl])
+        sampler.sample_epoch_exact(nI, end_user, rp, cols_src[1], nnz, 1, neg)
+        uu_l, ii_l, jj_l = _hip.shuffle_gather(cols_src, None, seed=77 + bl, n_out=4 * bl)
+        run_l(1, 0)
+        barrier()
+        t0 = time.perf_counter()
+        run_l(3, bl)
+        barrier()
+        dtl = time.perf_counter() - t0
+        leg.setdefault("large_batch", {})[str(bl)] = {"value": 3 * bl / dtl, "unit": "train interactions/s", "global_batch": bl, "steps": 3,
+                                                      "warmup": 1, "ms_per_step": dtl / 3 * 1e3,
+                                                      "epoch_seconds_estimated": -(-n_inter_total // bl) * dtl / 3}
+    eng.batch_size_cfg = b
     steps_per_epoch = -(-n_inter_total // gb)
     leg["epoch"] = {"steps": steps_per_epoch, "seconds_estimated": steps_per_epoch * dt / K,
                     "note": "steps per epoch x the measured time per step (every step is the same full-graph work)"}
@@ -345,9 +370,12 @@ def pmc_lookup():
     except Exception:
         pmc, source = {}, None
 
-    def lookup(prefix):
+    def lookup(key):
+        """`kernel` or `kernel@state` (e.g. @epoch3: the launches of the third whole epoch)"""
+        base, _, state = key.partition("@")
         for name, ent in pmc.items():
-            if name.startswith(prefix) and "hbm_bytes_per_launch" in ent:
+            n_base, _, n_state = name.partition("@")
+            if n_base.startswith(base) and n_state == state and "hbm_bytes_per_launch" in ent:
                 return ent["hbm_bytes_per_launch"]
         return None
     return lookup, source
@@ -377,7 +405,7 @@ def cold_roofline(n_par, n_hot_blocks, kblk, cold_ms, alone_ms, overlapped, traf
          "achieved_by_traffic": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
          "frac_by_traffic": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
          "avg_launch_ms": ms, "launches_averaged": len(cold_ms),
-         "launches_by_phase": {ph: sum(1 for _, _, p_ in cold_ms if p_ == ph) for ph in ("pre", "warmup", "timed")},
+         "launches_by_phase": {ph: sum(1 for _, _, p_ in cold_ms if p_ == ph) for ph in sorted({p_ for _, _, p_ in cold_ms})},
          "avg_ms_full_k_launches": float(np.mean(full)) if full else None, "full_k_launches": len(full),
          "timed_region_launches": [{"ms": t, "optimizer_steps": k} for t, k, p_ in cold_ms if p_ == "timed"],
          "algorithmic_bytes_per_launch": cold_bytes, "algorithmic_bytes_per_parameter": 20.0, "cold_parameters": cold_par,
@@ -390,6 +418,117 @@ def cold_roofline(n_par, n_hot_blocks, kblk, cold_ms, alone_ms, overlapped, traf
                       "note": f"the same pass ({kblk} steps) with nothing beside it (copies of the buffers after the timed region, "
                               "same tags): `achieved` / `frac` above are the live figures, with the pass held to 4 workgroups per CU "
                               "underneath the step kernels"}
+    return r
+
+
+def bprmf_large_batch_leg(bl, dev, nU, nI, prefix, sample_slice):
+    """Separately labelled leg (b = 1 024 is the reference's default, batch_size is its config knob, BPRMF.py:28):
+    configs[1]'s job at batch `bl`, N = 1, on tables of its own.  Two forms of the same step are timed:
+      * `blocked`: what BPRMF.train_epoch runs -- one launch per step (skr_bpr_fused_step) with the dense Adam blocked over
+        k = min(32, 2^20 / (5 bl)) steps (the fused workspace has 2^20 row slots);
+      * `dense`: skr_bpr_step_spread + one dense skr_adam_step per step, each launch bracketed by HIP events: the HBM-bound
+        regime of K1 (1 564 B per interaction) and K2 (28 B per parameter and step)."""
+    from skrec import _hip
+    from skrec.recommender.base import DenseAdam
+    from skrec.recommender.fused import FusedBlocks
+    L, st, S = _hip.lib(), _hip.stream, _hip.SKR_LOSS_SLOTS
+    n_par = nU * D + nI * D + nI
+    flat = torch.zeros(n_par, device=dev)
+    flat[:(nU + nI) * D].normal_(0.0, 0.01, generator=torch.Generator(device=dev).manual_seed(99))
+    opt = DenseAdam(flat, lr=1e-3, track_touch=True)
+    k = max(1, min(32, (1 << 20) // (5 * bl)))
+    nb_w, nb_t = 2, 8
+    n_dense = 12
+    sl = prefix(((nb_w + nb_t) * k + n_dense) * bl, 0)
+    neg = sample_slice(sl)
+    uu, ii, jj = _hip.shuffle_gather([sl["users"], sl["items"], neg], None, seed=4242 + bl, n_out=((nb_w + nb_t) * k + n_dense) * bl)
+    pu, pi, pj = uu.data_ptr(), ii.data_ptr(), jj.data_ptr()
+    loss = torch.zeros(((nb_w + nb_t) * k + n_dense, S, 2), device=dev)
+    res = {"batch": bl, "unit": "train interactions/s"}
+    if k >= 2:
+        fb = FusedBlocks(opt, 0, nU, nU + nI, 1e-3)
+        fb.run_blocks(pu, pi, pj, nb_w, k, bl, loss.data_ptr(), 8 * S)
+        opt.end_blocks()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = 4 * nb_w * k * bl
+        fb.run_blocks(pu + o, pi + o, pj + o, nb_t, k, bl, loss.data_ptr() + 8 * S * nb_w * k, 8 * S)
+        opt.end_blocks()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res["blocked"] = {"value": nb_t * k * bl / dt, "ms_per_step": dt / (nb_t * k) * 1e3, "steps": nb_t * k, "adam_block": k,
+                          "step_launches": "1: skr_bpr_fused_step + one cold pass per block on the side stream"}
+        del fb
+    # dense form, launch by launch
+    P = {n_: t_.data_ptr() for n_, t_ in dict(flat=flat, grad=opt.grad, m=opt.m, v=opt.v, touch=opt.touch).items()}
+    pU, pV, pb = P["flat"], P["flat"] + 4 * nU * D, P["flat"] + 4 * (nU + nI) * D
+    gU, gV, gb = P["grad"], P["grad"] + 4 * nU * D, P["grad"] + 4 * (nU + nI) * D
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(n_dense)]
+    for t_ in ev:
+        for e_ in t_:
+            e_.record()
+    o0 = (nb_w + nb_t) * k
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(n_dense):
+        o = 4 * (o0 + s_) * bl
+        ev[s_][0].record()
+        rc = L.skr_bpr_step_spread(pU, pV, pb, pU, pV, pu + o, pi + o, pj + o, bl, 1.0, 1e-3, 1.0, gU, gV, gb, gU, gV,
+                                   loss.data_ptr() + 8 * S * (o0 + s_), P["touch"], P["grad"], st())
+        ev[s_][1].record()
+        opt.t += 1
+        rc |= L.skr_adam_step(P["flat"], P["grad"], P["m"], P["v"], n_par, 1e-3, 0.9, 0.999, 1e-8, opt.t, 1, P["touch"], st())
+        ev[s_][2].record()
+        if rc:
+            _hip.check(rc)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    bpr_ms = float(np.mean([a.elapsed_time(b_) for a, b_, _ in ev[2:]]))
+    adam_ms = float(np.mean([b_.elapsed_time(c) for _, b_, c in ev[2:]]))
+    k1 = 1564.0 * bl / (bpr_ms * 1e-3) / 1e9
+    k2 = 28.0 * n_par / (adam_ms * 1e-3) / 1e9
+    res["dense"] = {"value": n_dense * bl / dt, "ms_per_step": dt / n_dense * 1e3, "steps": n_dense,
+                    "step_launches": "2: skr_bpr_step_spread + skr_adam_step (dense, one launch per step)",
+                    "roofline_K1": {"kernel": "bpr_step_kernel", "bound": "hbm", "achieved": k1, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": k1 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": bpr_ms,
+                                    "algorithmic_bytes_per_launch": 1564.0 * bl, "launches_averaged": n_dense - 2},
+                    "roofline_K2": {"kernel": "adam_kernel (dense, touch bytes skip the reads of zero gradients)", "bound": "hbm",
+                                    "achieved": k2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2 / HBM_PEAK_GBS, "traffic": None,
+                                    "avg_launch_ms": adam_ms, "algorithmic_bytes_per_launch": 28.0 * n_par, "launches_averaged": n_dense - 2}}
+    best = max((res[k_]["value"], k_) for k_ in ("blocked", "dense") if k_ in res)
+    res["value"], res["form"] = best
+    del opt, flat
+    torch.cuda.empty_cache()
+    return res
+
+
+def step_roofline(b, kblk, under_log, alone_log, traffic, traffic_source):
+    """Roofline entry of bpr_fused_step_kernel, the launch the main stream of a BPRMF step consists of (one per step; the
+    cold pass runs beside it on the side stream).  Algorithmic bytes: 1 564 B per interaction.  Timed by
+    HIP events on the stream the launches go to: around the k step launches of a block and around its end launch
+    (bpr_fused_end_kernel: the block's hot rows back into the dense tables), for blocks of the third whole epoch (under
+    the cold pass) and for blocks with the cold pass in front of them on the same stream (alone on the chip)."""
+    def ms(log):
+        st_ = float(np.mean([e0.elapsed_time(e1) / k_ for e0, e1, _, k_ in log]))
+        en_ = float(np.mean([e1.elapsed_time(e2) for _, e1, e2, _ in log]))
+        return st_, en_
+    us, end_us = (x * 1e3 for x in ms(under_log))
+    alg = 1564.0 * b
+    ach = alg / (us * 1e-6) / 1e9
+    r = {"kernel": "bpr_fused_step_kernel (one launch per step: BPR forward / backward of the batch + the lazily evaluated Adam "
+                   "updates of the rows it names; bound by the exact catch-up arithmetic and launch latency, not by HBM)",
+         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+         "traffic_over_algorithmic": (traffic / alg) if traffic else None,
+         "avg_launch_us": us, "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_interaction": 1564.0, "interactions_per_launch": b,
+         "state": "under the cold pass (third whole epoch, blocks 257-768); start-to-start of consecutive launches on their stream",
+         "blocks_averaged": len(under_log), "launches_averaged": len(under_log) * kblk,
+         "end_launch_us_per_block": end_us, "end_launch_us_per_step": end_us / kblk}
+    if alone_log:
+        a_us, a_end = (x * 1e3 for x in ms(alone_log))
+        r["alone"] = {"avg_launch_us": a_us, "end_launch_us_per_block": a_end, "achieved": alg / (a_us * 1e-6) / 1e9,
+                      "frac": alg / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "blocks_averaged": len(alone_log),
+                      "note": "the same launches with the block's cold pass in front of them on the same stream"}
     return r
 
 
@@ -657,10 +796,11 @@ def launch_ranks(n_ranks, argv, script=None, env=None):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
     n_dev = torch.cuda.device_count()
-    if "SKR_DIST_BACKEND" not in env and n_dev < n_ranks:
-        print(f"[bench] {n_ranks} ranks but {n_dev} visible GPU(s): rehearsing on gloo (SKR_DIST_BACKEND=gloo); nothing in "
-              "this run is an RCCL / xGMI measurement", file=sys.stderr)
-        env["SKR_DIST_BACKEND"] = "gloo"
+    if n_dev < n_ranks:
+        if "SKR_DIST_BACKEND" not in env:
+            print(f"[bench] {n_ranks} ranks but {n_dev} visible GPU(s): rehearsing on gloo (SKR_DIST_BACKEND=gloo); nothing in "
+                  "this run is an RCCL / xGMI measurement", file=sys.stderr)
+            env["SKR_DIST_BACKEND"] = "gloo"
         # processes time-slicing one card: every cross-stream wait becomes milliseconds; keep each on one stream
         env.setdefault("SKR_ADAM_OVERLAP", "0")
         env.setdefault("SKR_SAMPLER_ONE_STREAM", "1")
@@ -698,6 +838,10 @@ def main():
     ap.add_argument("--no-lightgcn", action="store_true", help="skip the secondary LightGCN leg")
     ap.add_argument("--lightgcn-steps", type=int, default=10)
     ap.add_argument("--lightgcn-warmup", type=int, default=2)
+    ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are run this many times (fresh slices of the epoch each "
+                    "time, barrier + synchronize around each); `value` is the median repeat, all of them are listed")
+    ap.add_argument("--large-batches", default="16384,65536", help="batch sizes of the separately labelled large-batch legs "
+                    "(SURVEY 8d: batch_size is a config knob of the reference); empty = none")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -800,8 +944,13 @@ def main():
         n_pre = int(t_pre)
     pre = prefix(n_pre * b, 0) if n_pre > 0 else None
     warm = prefix(W * b, pre["end_user"] if pre else 0) if W > 0 else None
-    timed = prefix(K * b, warm["end_user"] if warm else (pre["end_user"] if pre else 0))
-    assert timed["nnz"] >= K * b, "dataset too small for --steps"
+    R = max(1, args.repeats)
+    timed_slices, at = [], (warm["end_user"] if warm else (pre["end_user"] if pre else 0))
+    for _ in range(R):          # every repeat trains on interactions of its own (its sampler call is inside its timed region)
+        timed_slices.append(prefix(K * b, at))
+        at = timed_slices[-1]["end_user"]
+        assert timed_slices[-1]["nnz"] >= K * b, "dataset too small for --steps x --repeats"
+    timed = timed_slices[0]
     sampler = DeviceSampler(2020)
     def sample_slice(sl, smp=None):
         neg = torch.empty(sl["nnz"], dtype=torch.int32, device=dev)
@@ -842,6 +991,11 @@ def main():
                 # on the side stream
                 f_opt.t = run_slice.t
                 f_opt.cold_timing = [] if phase is not None else None
+                if phase == "epoch3":       # blocks 256.. of the third whole epoch: the state an epoch runs in
+                    f_opt.cold_event_pool, f_opt.cold_timing_skip = epoch_cold_pool, 256
+                    fb.block_timing, fb.block_event_pool, fb.block_timing_skip = epoch_block_log, epoch_block_pool, 256
+                else:
+                    f_opt.cold_event_pool, f_opt.cold_timing_skip = cold_pool, 0
                 nfull, rem = divmod(n_steps, kblk)
                 fb.run_blocks(pu, pi, pj, nfull, kblk, b, P["loss"], 0)
                 if rem:
@@ -851,6 +1005,8 @@ def main():
                 run_slice.t = f_opt.t
                 if phase is not None:
                     cold_log.extend(((e0_, e1_), kk_, phase) for e0_, e1_, kk_ in f_opt.cold_timing)
+                if phase == "epoch3":
+                    fb.block_timing = None
                 return
             if world == 1 and not fused:   # every full block of the slice in one vectorised op
                 nfull = n_steps // kblk
@@ -1038,9 +1194,16 @@ def main():
     # building 2K timing events costs ~30 us each once a pool of ~1000 is used up (+56 ms inside the region at K = 960)
     mk_pair = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))   # noqa: E731
     event_pool = [mk_pair() for _ in range(K)] if kblk <= 1 else []
-    cold_pool = [mk_pair() for _ in range((n_pre + W + K) // max(kblk, 1) + 4)] if kblk > 1 else []
-    for pair in event_pool + cold_pool:
-        pair[0].record(); pair[1].record()       # first record creates the HIP event
+    cold_pool = [mk_pair() for _ in range((n_pre + W) // max(kblk, 1) + R * (K // max(kblk, 1) + 1) + 6)] if kblk > 1 else []
+    # the third whole epoch: 512 of its blocks (from the 257th on) get their cold pass and their step launches bracketed
+    epoch_cold_pool = [mk_pair() for _ in range(512)] if (kblk > 1 and world == 1 and not args.no_epoch) else []
+    mk_trip = lambda: tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))   # noqa: E731
+    epoch_block_pool = [mk_trip() for _ in range(512)] if epoch_cold_pool else []
+    alone_block_pool = [mk_trip() for _ in range(48)] if epoch_cold_pool else []
+    epoch_block_log, alone_block_log = [], []
+    for pair in event_pool + cold_pool + epoch_cold_pool + epoch_block_pool + alone_block_pool:
+        for e_ in pair:
+            e_.record()                          # first record creates the HIP event
     cold_log, step_events = [], []
     # SKR_BENCH_EPOCH_PROBE=1: HIP events around the cold pass and around the step launches of 200 blocks of each whole epoch
     epoch_probe = [] if os.environ.get("SKR_BENCH_EPOCH_PROBE") == "1" else None
@@ -1048,16 +1211,21 @@ def main():
         run_slice(pre, n_pre, "pre")
     if W > 0:
         run_slice(warm, W, "warmup")
-    barrier()
-    t0 = time.perf_counter()
-    run_slice(timed, K, "timed")
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+    dts = []
+    for r_ in range(R):         # EXACTLY K steps per repeat, barrier + synchronize on both sides, max over the ranks
+        barrier()
+        t0 = time.perf_counter()
+        run_slice(timed_slices[r_], K, "timed")
+        barrier()
+        dt_r = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt_r], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_r = float(tmax)
+        dts.append(dt_r)
+    dt = float(np.median(dts))
     if kblk > 1:
+        n_fresh_log = len(cold_log)              # what follows in the log belongs to the whole-epoch leg
         cold_ms = [(a.elapsed_time(z), kk, ph) for (a, z), kk, ph in cold_log]
         adam_ms = float(np.mean([t for t, _, _ in cold_ms]))
         steps_per_launch = float(np.mean([kk for _, kk, _ in cold_ms]))
@@ -1088,6 +1256,7 @@ def main():
     # sits inside the timed region); an epoch's batches spread over all users -- more distinct hot rows per block, and
     # moments of every age.  Reported beside `value`, never instead of it.
     epoch_leg = None
+    n_hot_epoch = n_hot_blocks
     if world == 1 and not args.no_epoch:
         whole = prefix(int(ds["rowptr"][-1]), 0)
         n_ep = whole["nnz"] // b
@@ -1123,7 +1292,7 @@ def main():
         th = threading.Thread(target=draw_ahead if os.environ.get("SKR_BENCH_NO_AHEAD3") != "1" else (lambda: None), daemon=True)
         t2e = time.perf_counter()
         th.start()
-        run_slice(whole, n_ep, neg=neg_ahead)
+        run_slice(whole, n_ep, phase="epoch3", neg=neg_ahead)
         te3_host = time.perf_counter() - t2e      # every launch of the epoch queued (the GPU may still be working)
         th.join()
         barrier()
@@ -1131,6 +1300,15 @@ def main():
         del neg_ahead
         box.clear()
         keep_alive.clear()
+        if fused:
+            n_hot_epoch = int((fb.tags[fb.last_q] == fb.serial).sum())        # hot blocks of the epoch's last block
+            # the step launches ALONE on the chip: the same loop with the cold pass in front of each block's steps on the same
+            # stream instead of beside them (40 blocks of a slice of their own, the last 36 bracketed)
+            side_, f_opt._side = f_opt._side, torch.cuda.current_stream()
+            fb.block_timing, fb.block_event_pool, fb.block_timing_skip = alone_block_log, alone_block_pool, 4
+            run_slice(prefix(40 * kblk * b, 0), 40 * kblk)
+            torch.cuda.synchronize()
+            fb.block_timing, f_opt._side = None, side_
         if epoch_probe:
             torch.cuda.synchronize()
             last = epoch_probe[-200:]            # the third epoch's blocks
@@ -1154,6 +1332,8 @@ def main():
         "value": value, "unit": "train interactions/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": args.scaling if world == 1 else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "repeats": {"n": R, "statistic": "value / ms_per_step are the MEDIAN of n timed regions of exactly `steps` steps each",
+                    "seconds": dts, "value_min": K * b * world / max(dts), "value_max": K * b * world / min(dts)},
         "config": {"workload": f"BASELINE configs[1]: BPRMF d=64, synthetic {args.users}-user/{args.items}-item/"
                                f"{args.interactions}-interaction (MovieLens-shaped), exact-stream sampler + fused BPR "
                                f"step + dense Adam; eval = fused MFMA top-{args.top_k}",
@@ -1179,8 +1359,25 @@ def main():
         # written (8 B) per cold parameter = 20 B; blocks not at rest also write p (4 B more -- not counted: their share
         # depends on the state of the moments).  The launch applies kblk optimiser steps.  SURVEY 8(d)'s per-step figure
         # (28 B per parameter and step) is what this pass replaces kblk times over: `dense_equivalent_GBps`, not `achieved`.
-        out["roofline"] = cold_roofline(n_par, n_hot_blocks, kblk, cold_ms, cold_alone_ms, side != torch.cuda.current_stream(),
-                                        pmc_traffic("adam_cold_rows_kernel") if args.users == 1_000_000 else None, pmc_source)
+        fresh = cold_roofline(n_par, n_hot_blocks, kblk, cold_ms, cold_alone_ms, side != torch.cuda.current_stream(),
+                              pmc_traffic("adam_cold_rows_kernel") if args.users == 1_000_000 else None, pmc_source)
+        aged_ms = [(a.elapsed_time(z), kk, ph) for (a, z), kk, ph in cold_log[n_fresh_log:] if ph == "epoch3"]
+        if aged_ms:
+            # THE roofline entry: the cold passes of the third whole epoch (blocks 257..768) -- every row's moments aged by two
+            # epochs of real training, nothing skipped because a moment is still zero: the state an epoch runs in
+            out["roofline"] = cold_roofline(n_par, n_hot_epoch, kblk, aged_ms, None, True,
+                                            pmc_traffic("adam_cold_rows_kernel@epoch3") if args.users == 1_000_000 else None, pmc_source)
+            out["roofline"]["state"] = ("third consecutive whole epoch (full_epoch leg), cold passes of blocks 257-768, every one "
+                                        "bracketed by HIP events on the side stream it runs on, underneath the block's step launches")
+            fresh["state"] = ("fresh model: the passes of this run's pre-steps, warm-up and timed steps -- most rows' moments are still "
+                              "zero and are not written back, which flatters the pass; kept for comparison with rounds 1-2")
+            out["roofline_fresh_model"] = fresh
+        else:
+            fresh["state"] = "fresh model (no whole-epoch leg in this run): flattering, see DESIGN.md 5"
+            out["roofline"] = fresh
+        if epoch_block_log:
+            out["roofline_step"] = step_roofline(b, kblk, epoch_block_log, alone_block_log,
+                                                 pmc_traffic("bpr_fused_step_kernel@epoch3") if args.users == 1_000_000 else None, pmc_source)
     else:
         adam_bytes = float(n_par if world == 1 else n_par - nU * D) * 28.0
         ach = adam_bytes / (adam_ms * 1e-3) / 1e9
@@ -1190,6 +1387,9 @@ def main():
                            "traffic_source": pmc_source, "avg_launch_ms": adam_ms, "launches_averaged": len(step_events),
                            "algorithmic_bytes_per_launch": adam_bytes}
 
+    if world == 1 and args.large_batches:
+        out["large_batch"] = {str(bl): bprmf_large_batch_leg(bl, dev, nU, nI, prefix, sample_slice)
+                              for bl in (int(x) for x in args.large_batches.split(",") if x) if 64 * bl < int(ds["rowptr"][-1])}
     if not args.no_eval:
         eval_leg(args, world, rank, dev, dist, U, V, bias, ds, nU, nI, out)
     if world == 1 and not args.no_cpu_baseline:

@@ -127,6 +127,10 @@ class BPRMF(AbstractRecommender):
         pgU, pgV, pgb = gU.data_ptr(), gV.data_ptr(), gb.data_ptr()
         ploss, reg = spread.data_ptr(), self.config.reg
         kblk = self.adam_block
+        # large batches: the one-launch step's workspace has 2^20 row slots (5 * batch per step); shorter blocks keep it usable
+        k_fit = (1 << 20) // (5 * max(1, self.config.batch_size))
+        if self.fused_step and 2 <= k_fit < kblk:
+            kblk = k_fit
         if kblk <= 1 or data_iter.num_neg != 1:
             pgrad, pflat, pm, pv = (t.data_ptr() for t in (opt.grad, opt.flat, opt.m, opt.v))
             ptouch = opt.touch.data_ptr() if opt.touch is not None else None    # None: plain dense step, every gradient read

@@ -172,10 +172,33 @@ class FusedBlocks(object):
                 cur.wait_event(self._ev_plan[q ^ 1])                 # the next block's tags decide what is written back where
             ptag = self.tags[q ^ 1].data_ptr() if split else None
             pw = self.work[q if self.split_end else 0].data_ptr()
-            rc = L.skr_bpr_fused_block(pp, pm, pv, n_par, pw, cap, pu + o, pi + o, pj + o, self.meta[q].data_ptr(), bsz, u0, i0, b0, lr,
-                                       b1, b2, eps, t0, k, reg, ploss + blk * k * loss_stride_bytes, loss_stride_bytes // 4,
-                                       self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(), self.n_slots[q].data_ptr(),
-                                       ptag, serial0 + blk + 1, st)
+            # measurement hook (bench.py): `block_timing` receives (start, steps done, end done, k) -- HIP events on the current
+            # stream around the block's k step launches and around its end launch -- with event triples from `block_event_pool`
+            # (made beforehand), after `block_timing_skip` unbracketed blocks; no pool or an empty one: no bracket.  A
+            # bracketed block is issued launch by launch from here (same launches as skr_bpr_fused_block makes).
+            bt = getattr(self, "block_timing", None)
+            if bt is not None and getattr(self, "block_timing_skip", 0) > 0:
+                self.block_timing_skip -= 1
+                bt = None
+            trip = self.block_event_pool.pop() if (bt is not None and getattr(self, "block_event_pool", None)) else None
+            if trip is None:
+                rc = L.skr_bpr_fused_block(pp, pm, pv, n_par, pw, cap, pu + o, pi + o, pj + o, self.meta[q].data_ptr(), bsz, u0, i0, b0,
+                                           lr, b1, b2, eps, t0, k, reg, ploss + blk * k * loss_stride_bytes, loss_stride_bytes // 4,
+                                           self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(), self.n_slots[q].data_ptr(),
+                                           ptag, serial0 + blk + 1, st)
+            else:
+                rc, pmeta = 0, self.meta[q].data_ptr()
+                trip[0].record(cur)
+                for s_ in range(k):
+                    os_ = o + 4 * s_ * bsz
+                    rc |= L.skr_bpr_fused_step(pp, pm, pv, n_par, pw, cap, pu + os_, pi + os_, pj + os_, pmeta + 20 * s_ * bsz, bsz, u0,
+                                               i0, b0, lr, b1, b2, eps, t0, k, s_, reg, ploss + (blk * k + s_) * loss_stride_bytes, st)
+                trip[1].record(cur)
+                rc |= L.skr_bpr_fused_end(pp, pm, pv, n_par, pw, cap, self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(),
+                                          self.n_slots[q].data_ptr(), lr, b1, b2, eps, t0, k, ptag, serial0 + blk + 1,
+                                          1 if ptag else 0, st)
+                trip[2].record(cur)
+                bt.append((trip[0], trip[1], trip[2], k))
             self._ev_block.record(cur)
             side.wait_event(self._ev_block)       # the next cold pass updates rows this block has just written back
             if split:
