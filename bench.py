@@ -1306,7 +1306,8 @@ def main():
             # stream instead of beside them (40 blocks of a slice of their own, the last 36 bracketed)
             side_, f_opt._side = f_opt._side, torch.cuda.current_stream()
             fb.block_timing, fb.block_event_pool, fb.block_timing_skip = alone_block_log, alone_block_pool, 4
-            run_slice(prefix(40 * kblk * b, 0), 40 * kblk)
+            n_alone = min(40, n_ep // kblk)
+            run_slice(prefix(n_alone * kblk * b, 0), n_alone * kblk)
             torch.cuda.synchronize()
             fb.block_timing, f_opt._side = None, side_
         if epoch_probe:
@@ -1389,7 +1390,8 @@ def main():
 
     if world == 1 and args.large_batches:
         out["large_batch"] = {str(bl): bprmf_large_batch_leg(bl, dev, nU, nI, prefix, sample_slice)
-                              for bl in (int(x) for x in args.large_batches.split(",") if x) if 64 * bl < int(ds["rowptr"][-1])}
+                              for bl in (int(x) for x in args.large_batches.split(",") if x)
+                              if (10 * max(1, min(32, (1 << 20) // (5 * bl))) + 12) * bl <= int(ds["rowptr"][-1])}
     if not args.no_eval:
         eval_leg(args, world, rank, dev, dist, U, V, bias, ds, nU, nI, out)
     if world == 1 and not args.no_cpu_baseline:

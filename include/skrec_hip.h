@@ -288,6 +288,41 @@ int skr_spmm_plan_run_masked(const skr_spmm_plan* plan, const float* d_X, int di
                              float* d_accum, float accum_scale, const uint8_t* d_row_mask, const uint8_t* d_col_mask,
                              void* stream);
 int skr_mark_ids(const int32_t* d_ids, int64_t n, int64_t offset, uint8_t* d_mask, void* stream);
+/* The general form: what happens to a finished row y = (A X)_r (+ addend_r) is described by a skr_spmm_epilogue, so that the
+ * row-local passes around a propagation ride in the product's row epilogue instead of being launches of their own (a
+ * wavefront holds the whole 64-float row there):
+ *   SKR_EPI_PLAIN       Y_r = y (Y may be NULL when only accum is wanted); accum_r = accum_r + accum_scale * y, or, with
+ *                       accum_base, accum_r = accum_scale * accum_base_r + accum_scale * y (LightGCN's layer mean including
+ *                       its E0 term: LightGCN.py:89-100), or, with accum_init, accum_r = accum_scale * y (accum is not read);
+ *   SKR_EPI_REFINE_FWD  LayerGCN.py:214-216 on the finished row: w_r = cos(y, E_r) (torch eps 1e-8) -> w[r]; Z_r = w_r * y;
+ *                       Y_r = y (the raw row the backward needs; Y may be NULL for inference); accum_r += Z_r (accum_init:
+ *                       accum_r = Z_r);
+ *   SKR_EPI_REFINE_BWD  the finished row is dZ of the layer below (hop k+1 of the backward feeds layer k's refinement):
+ *                       Y_r = dY_r = the backward of that refinement at (rawY_r, E_r, w[r]); dE_r += its E0 part
+ *                       (skr_layer_refine_bwd's arithmetic).
+ * Rows skipped by d_row_mask get no epilogue. */
+enum { SKR_EPI_PLAIN = 0, SKR_EPI_REFINE_FWD = 1, SKR_EPI_REFINE_BWD = 2 };
+typedef struct skr_spmm_epilogue {
+    int32_t mode;
+    int32_t accum_init;
+    const float* addend;
+    float* Y;
+    float* accum;
+    const float* accum_base;
+    float accum_scale;
+    float reserved_;
+    const float* E;
+    float* w;
+    float* Z;
+    const float* rawY;
+    float* dE;
+    const uint8_t* accum_mask;    /* uint8[n_rows] or NULL: accum_r is only updated where the byte is set (a training step reads
+                                     the layer mean / sum at its batch's rows only) */
+    const uint8_t* addend_mask;   /* uint8[n_rows] or NULL: addend_r IS zero where the byte is 0 and is not read there (dL/d output
+                                     is zero outside the batch's rows) */
+} skr_spmm_epilogue;
+int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, const skr_spmm_epilogue* epi,
+                         const uint8_t* d_row_mask, const uint8_t* d_col_mask, void* stream);
 int skr_spmm_plan_info(const skr_spmm_plan* plan, int64_t* h_info4);
 int skr_spmm_plan_destroy(skr_spmm_plan* plan);
 
@@ -298,6 +333,17 @@ int skr_layer_refine_fwd(const float* d_Y, const float* d_E, int64_t n_rows, int
 /* Backward of the above: given dZ -> dY (written) and dE (accumulated). */
 int skr_layer_refine_bwd(const float* d_Y, const float* d_E, const float* d_w, const float* d_dZ,
                          int64_t n_rows, int dim, float* d_dY, float* d_dE, void* stream);
+
+/* The same restricted to the rows whose byte in d_row_mask (uint8[n_rows], NULL = all) is set: where dZ_r is known to be
+ * zero (LayerGCN's first backward refinement: dL/d out is zero outside the batch's rows) dY_r = 0 and dE_r gets nothing, so
+ * the row is skipped.  zero_skipped != 0: dY_r = 0 is written for the skipped rows; 0: dY_r is left as it is (the product
+ * that follows must then skip those columns: d_col_mask). */
+int skr_layer_refine_bwd_masked(const float* d_Y, const float* d_E, const float* d_w, const float* d_dZ, int64_t n_rows,
+                                int dim, float* d_dY, float* d_dE, const uint8_t* d_row_mask, int zero_skipped, void* stream);
+/* Rows of d_table [n_rows, dim] whose byte in d_mask is set are zeroed; with clear_mask != 0 the bytes are cleared too.
+ * Restores the all-zero state of a gradient buffer of which only one batch's rows were written (instead of a fill of
+ * the whole buffer; no reference counterpart: autograd allocates a fresh zero tensor per step). */
+int skr_clear_marked_rows(uint8_t* d_mask, int64_t n_rows, int64_t clear_mask, float* d_table, int dim, void* stream);
 
 /* Row gather out[k] = table[idx[k]] (F.embedding; any row width `dim`, 64 has its own kernel) and  y = a*x + y  helpers
  * used by the host mirror so that no torch kernel sits on the hot path. */

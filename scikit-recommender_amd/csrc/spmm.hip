@@ -85,17 +85,131 @@ __device__ __forceinline__ int keep_marked(const uint8_t* __restrict__ col_mask,
     return kept;
 }
 
-__device__ __forceinline__ void finish_row(float4 y, int64_t r, int sub, const float* __restrict__ addend, float* __restrict__ Y,
-                                           float* __restrict__ accum, float accum_scale) {
-    if (addend) {
-        const float4 a = reinterpret_cast<const float4*>(addend)[r * 16 + sub];
-        y.x += a.x; y.y += a.y; y.z += a.z; y.w += a.w;
+// ---- what happens to a finished row (skr_spmm_epilogue, include/skrec_hip.h) ---------------------------------------------
+// The row is held V floats per lane: V = 4 in the row kernel (lane `idx` = sub of a 16-lane group owns floats 4 idx .. 4 idx + 3;
+// all four groups hold the same totals, `writer` = group 0 stores), V = 1 in the reduce kernel (64 lanes, one float each).
+// The LayerGCN refinements need sums over the row: V = 4 adds its four floats, then 16 lanes by xor-shuffles.
+constexpr float COS_EPS = 1e-8f;     // F.cosine_similarity default (LayerGCN.py:214)
+
+template <int V>
+__device__ __forceinline__ float row_total(const float (&p)[V]) {
+    float s = p[0];
+#pragma unroll
+    for (int j = 1; j < V; ++j) s += p[j];
+    if (V == 4) {
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+    } else {
+        s = skr::wave_sum(s);
     }
-    reinterpret_cast<float4*>(Y)[r * 16 + sub] = y;
-    if (accum) {
-        float4 c = reinterpret_cast<float4*>(accum)[r * 16 + sub];
-        c.x += accum_scale * y.x; c.y += accum_scale * y.y; c.z += accum_scale * y.z; c.w += accum_scale * y.w;
-        reinterpret_cast<float4*>(accum)[r * 16 + sub] = c;
+    return s;
+}
+template <int V>
+__device__ __forceinline__ void row_load(const float* __restrict__ t, int64_t r, int idx, float (&o)[V]) {
+    if (V == 4) {
+        const float4 a = reinterpret_cast<const float4*>(t)[r * 16 + idx];
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+    } else {
+        o[0] = t[r * D + idx];
+    }
+}
+template <int V>
+__device__ __forceinline__ void row_store(float* __restrict__ t, int64_t r, int idx, const float (&o)[V]) {
+    if (V == 4) reinterpret_cast<float4*>(t)[r * 16 + idx] = make_float4(o[0], o[1], o[2], o[3]);
+    else t[r * D + idx] = o[0];
+}
+
+template <int V>
+__device__ __forceinline__ void epilogue(const skr_spmm_epilogue& ep, float (&y)[V], int64_t r, int idx, bool writer) {
+    if (ep.addend && !(ep.addend_mask && !ep.addend_mask[r])) {     // a row of the addend known to be zero is not read
+        float a[V];
+        row_load<V>(ep.addend, r, idx, a);
+#pragma unroll
+        for (int j = 0; j < V; ++j) y[j] += a[j];
+    }
+    const bool accumulate = ep.accum && !(ep.accum_mask && !ep.accum_mask[r]);   // only the rows somebody will read
+    if (ep.mode == SKR_EPI_PLAIN) {
+        if (writer && ep.Y) row_store<V>(ep.Y, r, idx, y);
+        if (accumulate) {
+            float c[V];
+            if (ep.accum_base) {              // accum = scale * base + scale * y: the layer mean's first term folded in
+                row_load<V>(ep.accum_base, r, idx, c);
+#pragma unroll
+                for (int j = 0; j < V; ++j) c[j] = ep.accum_scale * c[j];
+            } else if (ep.accum_init) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) c[j] = 0.0f;
+            } else {
+                row_load<V>(ep.accum, r, idx, c);
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) c[j] += ep.accum_scale * y[j];
+            if (writer) row_store<V>(ep.accum, r, idx, c);
+        }
+        return;
+    }
+    float e[V], p[V];
+    row_load<V>(ep.E, r, idx, e);
+    if (ep.mode == SKR_EPI_REFINE_FWD) {
+        // LayerGCN.py:214-216: w = cos(y, e0); z = w * y feeds the next layer and the sum of the layers
+#pragma unroll
+        for (int j = 0; j < V; ++j) p[j] = y[j] * y[j];
+        const float ny = fmaxf(sqrtf(row_total<V>(p)), COS_EPS);
+#pragma unroll
+        for (int j = 0; j < V; ++j) p[j] = e[j] * e[j];
+        const float ne = fmaxf(sqrtf(row_total<V>(p)), COS_EPS);
+#pragma unroll
+        for (int j = 0; j < V; ++j) p[j] = (y[j] / ny) * (e[j] / ne);
+        const float w = row_total<V>(p);
+        float z[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) z[j] = w * y[j];
+        if (writer) {
+            if (ep.Y) row_store<V>(ep.Y, r, idx, y);
+            row_store<V>(ep.Z, r, idx, z);
+            if (idx == 0) ep.w[r] = w;
+        }
+        if (accumulate) {
+            float c[V];
+            if (ep.accum_init) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) c[j] = z[j];
+            } else {
+                row_load<V>(ep.accum, r, idx, c);
+#pragma unroll
+                for (int j = 0; j < V; ++j) c[j] += z[j];
+            }
+            if (writer) row_store<V>(ep.accum, r, idx, c);
+        }
+        return;
+    }
+    // SKR_EPI_REFINE_BWD: the finished row is dZ of the layer below; dY = backward of that layer's refinement, dE += its part
+    float yr[V];
+    row_load<V>(ep.rawY, r, idx, yr);
+    const float w = ep.w[r];
+#pragma unroll
+    for (int j = 0; j < V; ++j) p[j] = yr[j] * yr[j];
+    const float nyr = sqrtf(row_total<V>(p));
+#pragma unroll
+    for (int j = 0; j < V; ++j) p[j] = e[j] * e[j];
+    const float ner = sqrtf(row_total<V>(p));
+    const float ny = fmaxf(nyr, COS_EPS), ne = fmaxf(ner, COS_EPS);
+#pragma unroll
+    for (int j = 0; j < V; ++j) p[j] = y[j] * yr[j];
+    const float dw = row_total<V>(p);
+    float dy[V], de[V];
+    row_load<V>(ep.dE, r, idx, de);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const float yh = yr[j] / ny, eh = e[j] / ne;
+        // d(yh)/dy = (I - yh yh^T)/ny when the norm is not clamped, I/eps when it is (clamp_min has zero slope)
+        const float gy = (nyr > COS_EPS) ? (eh - w * yh) / ny : eh / ny;
+        const float ge = (ner > COS_EPS) ? (yh - w * eh) / ne : yh / ne;
+        dy[j] = w * y[j] + dw * gy;
+        de[j] += dw * ge;
+    }
+    if (writer) {
+        row_store<V>(ep.Y, r, idx, dy);
+        row_store<V>(ep.dE, r, idx, de);
     }
 }
 
@@ -103,8 +217,7 @@ __device__ __forceinline__ void finish_row(float4 y, int64_t r, int sub, const f
 template <bool COLMASK>
 __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, int long_thr, const int64_t* __restrict__ rowptr,
                                                                    const int32_t* __restrict__ col, const float* __restrict__ val,
-                                                                   const float* __restrict__ X, const float* __restrict__ addend,
-                                                                   float* __restrict__ Y, float* __restrict__ accum, float accum_scale,
+                                                                   const float* __restrict__ X, const skr_spmm_epilogue ep,
                                                                    const uint8_t* __restrict__ row_mask,
                                                                    const uint8_t* __restrict__ col_mask,
                                                                    const int64_t* __restrict__ split, int n_win, int win) {
@@ -124,7 +237,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, i
             if (win < n_win - 1) re = sp[win];
         }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n_win > 1 && win > 0 && grp == 0) acc = reinterpret_cast<const float4*>(Y)[r * 16 + sub];   // the earlier windows' sum
+        if (n_win > 1 && win > 0 && grp == 0) acc = reinterpret_cast<const float4*>(ep.Y)[r * 16 + sub];   // the earlier windows' sum
         for (int64_t e = rb; e < re; e += 64) {
             int m = static_cast<int>(re - e < 64 ? re - e : 64);
             int cl = 0;
@@ -134,9 +247,11 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, i
             gather_block(X4, cl, vl, m, grp, sub, acc);
         }
         sum_groups(acc);
-        if (grp == 0) {
-            if (win == n_win - 1) finish_row(acc, r, sub, addend, Y, accum, accum_scale);
-            else reinterpret_cast<float4*>(Y)[r * 16 + sub] = acc;
+        if (win == n_win - 1) {
+            float y[4] = {acc.x, acc.y, acc.z, acc.w};
+            epilogue<4>(ep, y, r, sub, grp == 0);
+        } else if (grp == 0) {
+            reinterpret_cast<float4*>(ep.Y)[r * 16 + sub] = acc;
         }
     }
 }
@@ -192,8 +307,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
 // a long row = the sum of its partial rows, added in slot order by one workgroup: every wavefront sums a contiguous
 // quarter of the row's slots (8 loads in flight), the four sums are combined in wave order
 __global__ __launch_bounds__(256) void spmm_reduce_kernel(const int32_t* __restrict__ long_rows, const int64_t* __restrict__ part_ptr,
-                                                          const float* __restrict__ part, const float* __restrict__ addend,
-                                                          float* __restrict__ Y, float* __restrict__ accum, float accum_scale,
+                                                          const float* __restrict__ part, const skr_spmm_epilogue ep,
                                                           const uint8_t* __restrict__ row_mask) {
     __shared__ float s[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -214,10 +328,8 @@ __global__ __launch_bounds__(256) void spmm_reduce_kernel(const int32_t* __restr
     __syncthreads();
     if (wv == 0) {
         const int64_t r = long_rows[blockIdx.x];
-        float y = ((s[0][lane] + s[1][lane]) + s[2][lane]) + s[3][lane];
-        if (addend) y += addend[r * D + lane];
-        Y[r * D + lane] = y;
-        if (accum) accum[r * D + lane] += accum_scale * y;
+        float y[1] = {((s[0][lane] + s[1][lane]) + s[2][lane]) + s[3][lane]};
+        epilogue<1>(ep, y, r, lane, true);
     }
 }
 
@@ -461,11 +573,17 @@ int skr_spmm_plan_info(const skr_spmm_plan* plan, int64_t* h_info4) {
     return SKR_OK;
 }
 
-int skr_spmm_plan_run_masked(const skr_spmm_plan* plan, const float* d_X, int dim, const float* d_addend, float* d_Y, float* d_accum,
-                             float accum_scale, const uint8_t* d_row_mask, const uint8_t* d_col_mask, void* stream) {
-    SKR_REQUIRE(plan && d_X && d_Y, "skr_spmm_plan_run: NULL argument");
+int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, const skr_spmm_epilogue* epi, const uint8_t* d_row_mask,
+                         const uint8_t* d_col_mask, void* stream) {
+    SKR_REQUIRE(plan && d_X && epi, "skr_spmm_plan_run: NULL argument");
     SKR_REQUIRE(dim == D, "skr_spmm_plan_run: dim must be 64 (got %d)", dim);
-    SKR_REQUIRE(d_Y != d_X, "skr_spmm_plan_run: in-place propagation is not supported");
+    const skr_spmm_epilogue ep = *epi;
+    SKR_REQUIRE(ep.mode == SKR_EPI_PLAIN || ep.mode == SKR_EPI_REFINE_FWD || ep.mode == SKR_EPI_REFINE_BWD, "skr_spmm_plan_run: unknown epilogue mode %d", ep.mode);
+    SKR_REQUIRE(ep.Y != d_X, "skr_spmm_plan_run: in-place propagation is not supported");
+    SKR_REQUIRE(ep.mode != SKR_EPI_PLAIN || ep.Y || ep.accum, "skr_spmm_plan_run: the plain epilogue needs Y or accum");
+    SKR_REQUIRE(ep.mode != SKR_EPI_REFINE_FWD || (ep.E && ep.w && ep.Z && ep.Z != d_X), "skr_spmm_plan_run: the forward refinement needs E, w and Z");
+    SKR_REQUIRE(ep.mode != SKR_EPI_REFINE_BWD || (ep.E && ep.w && ep.rawY && ep.dE && ep.Y), "skr_spmm_plan_run: the backward refinement needs E, w, rawY, dE and Y");
+    SKR_REQUIRE(plan->n_win == 1 || ep.Y, "skr_spmm_plan_run: column windows need Y");
     if (plan->n_rows == 0) return SKR_OK;
     hipStream_t st = skr::as_stream(stream);
     int64_t wgs = (static_cast<int64_t>(plan->n_rows) + ROW_WAVES - 1) / ROW_WAVES;
@@ -474,10 +592,10 @@ int skr_spmm_plan_run_masked(const skr_spmm_plan* plan, const float* d_X, int di
     for (int w = 0; w < plan->n_win; ++w) {
         if (d_col_mask)
             hipLaunchKernelGGL(spmm_rows_kernel<true>, rgrid, blk, 0, st, plan->n_rows, plan->long_thr, plan->rowptr, plan->col, plan->val,
-                               d_X, d_addend, d_Y, d_accum, accum_scale, d_row_mask, d_col_mask, plan->split, plan->n_win, w);
+                               d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w);
         else
             hipLaunchKernelGGL(spmm_rows_kernel<false>, rgrid, blk, 0, st, plan->n_rows, plan->long_thr, plan->rowptr, plan->col, plan->val,
-                               d_X, d_addend, d_Y, d_accum, accum_scale, d_row_mask, d_col_mask, plan->split, plan->n_win, w);
+                               d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w);
     }
     SKR_LAUNCH_CHECK();
     if (plan->n_long > 0) {
@@ -495,11 +613,20 @@ int skr_spmm_plan_run_masked(const skr_spmm_plan* plan, const float* d_X, int di
             }
             SKR_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(spmm_reduce_kernel, dim3(plan->n_long), dim3(256), 0, st, plan->long_rows, plan->part_ptr, plan->part, d_addend,
-                           d_Y, d_accum, accum_scale, d_row_mask);
+        hipLaunchKernelGGL(spmm_reduce_kernel, dim3(plan->n_long), dim3(256), 0, st, plan->long_rows, plan->part_ptr, plan->part, ep,
+                           d_row_mask);
         SKR_LAUNCH_CHECK();
     }
     return SKR_OK;
+}
+
+int skr_spmm_plan_run_masked(const skr_spmm_plan* plan, const float* d_X, int dim, const float* d_addend, float* d_Y, float* d_accum,
+                             float accum_scale, const uint8_t* d_row_mask, const uint8_t* d_col_mask, void* stream) {
+    SKR_REQUIRE(d_Y, "skr_spmm_plan_run: NULL argument");
+    skr_spmm_epilogue ep = {};
+    ep.mode = SKR_EPI_PLAIN;
+    ep.addend = d_addend; ep.Y = d_Y; ep.accum = d_accum; ep.accum_scale = accum_scale;
+    return skr_spmm_plan_run_ex(plan, d_X, dim, &ep, d_row_mask, d_col_mask, stream);
 }
 
 int skr_spmm_plan_run(const skr_spmm_plan* plan, const float* d_X, int dim, const float* d_addend, float* d_Y, float* d_accum,

@@ -347,10 +347,14 @@ __global__ void refine_fwd_kernel(const float* __restrict__ Y, const float* __re
 
 __global__ void refine_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ E, const float* __restrict__ w_in,
                                   const float* __restrict__ dZ, int64_t n_rows, float* __restrict__ dY,
-                                  float* __restrict__ dE) {
+                                  float* __restrict__ dE, const uint8_t* __restrict__ row_mask, int zero_skipped) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
     if (r >= n_rows) return;
+    if (row_mask && !row_mask[r]) {            // dZ_r is zero: dY_r is zero and nothing is added to dE_r
+        if (zero_skipped) dY[r * D + lane] = 0.0f;
+        return;
+    }
     const float y = Y[r * D + lane], e = E[r * D + lane], dz = dZ[r * D + lane];
     const float w = w_in[r];
     const float nyr = sqrtf(skr::wave_sum(y * y)), ner = sqrtf(skr::wave_sum(e * e));
@@ -362,6 +366,22 @@ __global__ void refine_bwd_kernel(const float* __restrict__ Y, const float* __re
     const float ge = (ner > COS_EPS) ? (yh - w * eh) / ne : yh / ne;
     dY[r * D + lane] = w * dz + dw * gy;
     dE[r * D + lane] += dw * ge;
+}
+
+// rows whose mask byte is set are zeroed (and the byte cleared): restores the "all zero" state of a buffer of which only a
+// batch's rows were written, without a fill of the whole buffer
+__global__ void clear_marked_rows_kernel(uint8_t* __restrict__ mask, int64_t n_rows, int clear_mask, float* __restrict__ table, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6) * 64;     // 64 rows per wavefront
+    if (r0 >= n_rows) return;
+    const bool set = r0 + lane < n_rows && mask[r0 + lane] != 0;
+    unsigned long long b = __ballot(set);
+    if (set && clear_mask) mask[r0 + lane] = 0;
+    while (b) {
+        const int j = __ffsll(static_cast<long long>(b)) - 1;
+        b &= b - 1;
+        for (int c = lane; c < dim; c += 64) table[(r0 + j) * dim + c] = 0.0f;
+    }
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx, int64_t n,
@@ -1428,13 +1448,29 @@ int skr_layer_refine_fwd(const float* d_Y, const float* d_E, int64_t n_rows, int
     return SKR_OK;
 }
 
-int skr_layer_refine_bwd(const float* d_Y, const float* d_E, const float* d_w, const float* d_dZ, int64_t n_rows, int dim,
-                         float* d_dY, float* d_dE, void* stream) {
+int skr_layer_refine_bwd_masked(const float* d_Y, const float* d_E, const float* d_w, const float* d_dZ, int64_t n_rows, int dim,
+                                float* d_dY, float* d_dE, const uint8_t* d_row_mask, int zero_skipped, void* stream) {
     SKR_REQUIRE(d_Y && d_E && d_w && d_dZ && d_dY && d_dE, "skr_layer_refine_bwd: NULL argument");
     SKR_REQUIRE(dim == D, "skr_layer_refine_bwd: dim must be 64 (got %d)", dim);
     if (n_rows <= 0) return SKR_OK;
     hipLaunchKernelGGL(refine_bwd_kernel, dim3(rows_to_blocks(n_rows)), dim3(256), 0, skr::as_stream(stream), d_Y, d_E,
-                       d_w, d_dZ, n_rows, d_dY, d_dE);
+                       d_w, d_dZ, n_rows, d_dY, d_dE, d_row_mask, zero_skipped);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_layer_refine_bwd(const float* d_Y, const float* d_E, const float* d_w, const float* d_dZ, int64_t n_rows, int dim,
+                         float* d_dY, float* d_dE, void* stream) {
+    return skr_layer_refine_bwd_masked(d_Y, d_E, d_w, d_dZ, n_rows, dim, d_dY, d_dE, nullptr, 0, stream);
+}
+
+int skr_clear_marked_rows(uint8_t* d_mask, int64_t n_rows, int64_t clear_mask, float* d_table, int dim, void* stream) {
+    SKR_REQUIRE(n_rows >= 0 && dim >= 1, "skr_clear_marked_rows: bad shape");
+    if (n_rows == 0) return SKR_OK;
+    SKR_REQUIRE(d_mask && d_table, "skr_clear_marked_rows: NULL argument");
+    const int64_t waves = (n_rows + 63) / 64;
+    hipLaunchKernelGGL(clear_marked_rows_kernel, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, skr::as_stream(stream), d_mask,
+                       n_rows, clear_mask ? 1 : 0, d_table, dim);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

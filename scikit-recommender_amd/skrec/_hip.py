@@ -74,6 +74,9 @@ SIGNATURES = {
     "skr_spmm_plan_create": (i32, [i32, i32, vp, vp, vp, i64, i32, C.POINTER(vp), vp]),
     "skr_spmm_plan_run": (i32, [vp, vp, i32, vp, vp, vp, f32, vp]),
     "skr_spmm_plan_run_masked": (i32, [vp, vp, i32, vp, vp, vp, f32, vp, vp, vp]),
+    "skr_spmm_plan_run_ex": (i32, [vp, vp, i32, vp, vp, vp, vp]),
+    "skr_clear_marked_rows": (i32, [vp, i64, i64, vp, i32, vp]),
+    "skr_layer_refine_bwd_masked": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp, i32, vp]),
     "skr_mark_ids": (i32, [vp, i64, i64, vp, vp]),
     "skr_spmm_plan_info": (i32, [vp, C.POINTER(i64)]),
     "skr_spmm_plan_destroy": (i32, [vp]),
@@ -86,6 +89,14 @@ SIGNATURES = {
     "skr_scale_copy": (i32, [f32, vp, vp, i64, vp]),
     "skr_scale": (i32, [f32, vp, i64, vp]),
 }
+
+class SpmmEpilogue(C.Structure):
+    """skr_spmm_epilogue (include/skrec_hip.h): what happens to a finished row of a propagation"""
+    _fields_ = [("mode", C.c_int32), ("accum_init", C.c_int32), ("addend", vp), ("Y", vp), ("accum", vp), ("accum_base", vp),
+                ("accum_scale", C.c_float), ("reserved_", C.c_float), ("E", vp), ("w", vp), ("Z", vp), ("rawY", vp), ("dE", vp), ("accum_mask", vp), ("addend_mask", vp)]
+
+
+EPI_PLAIN, EPI_REFINE_FWD, EPI_REFINE_BWD = 0, 1, 2
 
 SKR_MAX_TOPK = 128
 SKR_LOSS_SLOTS = 32      # skr_bpr_step_spread: pairs of loss words per batch

@@ -211,41 +211,61 @@ class ShardedLightGCN(object):
         layer's products are computed for those rows only and ``final`` is valid on those rows only."""
         K, nl = self.n_layers, self.n_local
         scale = 1.0 / (K + 1)
-        _hip.check(_hip.lib().skr_scale_copy(scale, _hip.ptr(self.ego), _hip.ptr(self.final), self.ego.numel(), _hip.stream()))
+        active = self.ctx.active
         fu, fi = self.final[:nl], self.final[nl:]
         xu, xi = self.ego[:nl], self.ego[nl:]
+        if active:      # the item half of the mean starts from its E0 term; the user half gets it in the first product's epilogue
+            _hip.check(_hip.lib().skr_scale_copy(scale, _hip.ptr(xi), _hip.ptr(fi), xi.numel(), _hip.stream()))
         for k in range(K):
             nu, ni = self._xu[k & 1], self._xi[k & 1]
             mu, mi = last_rows if (last_rows is not None and k == K - 1) else (None, None)
+            au, ai = last_rows if last_rows is not None else (None, None)    # the mean is only needed on the rows that are read
+            base_u, base_i = (self.ego[:nl], self.ego[nl:]) if k == 0 else (None, None)
+            if not active:
+                # one rank: nothing is exchanged, so the layer mean (with its E0 term) rides in both products' row epilogues
+                self.a_iu.spmm(xu, ni, accum=fi, accum_scale=scale, accum_base=base_i, row_mask=mi, accum_mask=ai)
+                self.a_ui.spmm(xi, nu, accum=fu, accum_scale=scale, accum_base=base_u, row_mask=mu, accum_mask=au)
+                xu, xi = nu, ni
+                continue
             if mi is not None:
                 ni.zero_()                                                # rows that are skipped must not carry old sums
             self.a_iu.spmm(xu, ni, row_mask=mi)                                # partial items <- local users
             # the exchange step of this layer, beside the user-side product.  In the masked last layer only the GLOBAL
             # batch's item rows carry anything: they travel as a compact [2 * batch, 64] block instead of the [I, 64] one
-            compact = self._batch_item_ids if (mi is not None and self.ctx.active) else None
+            compact = self._batch_item_ids if mi is not None else None
             if compact is not None:
                 work = self._rows_exchange_begin(ni, compact)
             else:
                 work = self.ctx.all_reduce_begin(ni)
-            self.a_ui.spmm(xi, nu, accum=fu, accum_scale=scale, row_mask=mu)   # local users <- replicated items
+            self.a_ui.spmm(xi, nu, accum=fu, accum_scale=scale, accum_base=base_u, row_mask=mu, accum_mask=au)   # local users <- replicated items
             if compact is not None:
                 self._rows_exchange_end(work, compact, ni)
             else:
                 self.ctx.all_reduce_end(work)
             self._axpy(scale, ni, fi)
             xu, xi = nu, ni
+        self._final_whole = last_rows is None
         return self.final
 
-    def _batch_rows(self, users, pos, neg):
+    def _batch_rows(self, users, pos, neg, grad_rows=None):
         """(uint8 [n_local], uint8 [I]) for a GLOBAL batch (global user ids): the rows it touches -- this rank's users,
         EVERY rank's items (the item rows are replicated and summed over the ranks, so each rank needs the same set).
         Also keeps the batch's item ids (pos ++ neg, identical on every rank) for the compact exchanges."""
+        L, st, world, rank = _hip.lib(), _hip.stream(), self.ctx.world, self.ctx.rank
         if getattr(self, "_mask_u", None) is None:
             self._mask_u = torch.zeros(self.n_local, dtype=torch.uint8, device=self.device)
             self._mask_i = torch.zeros(self.num_items, dtype=torch.uint8, device=self.device)
-        L, st, world, rank = _hip.lib(), _hip.stream(), self.ctx.world, self.ctx.rank
-        self._mask_u.zero_()
-        self._mask_i.zero_()
+            if grad_rows is not None:
+                grad_rows.zero_()
+        elif grad_rows is not None:
+            # the buffer the BPR kernel scatters dL/d(output rows) into is zero outside the PREVIOUS batch's rows: those rows
+            # are cleared, and their marks with them, instead of filling the whole [n_local + I, 64] buffer
+            nl = self.n_local
+            _hip.check(L.skr_clear_marked_rows(_hip.ptr(self._mask_u), nl, 1, _hip.ptr(grad_rows[:nl]), 64, st))
+            _hip.check(L.skr_clear_marked_rows(_hip.ptr(self._mask_i), self.num_items, 1, _hip.ptr(grad_rows[nl:]), 64, st))
+        else:
+            self._mask_u.zero_()
+            self._mask_i.zero_()
         if world > 1:   # local rows of the users this rank owns; the others become -1 (skipped)
             ul = torch.where((users % world) == rank, torch.div(users, world, rounding_mode="floor"), torch.full_like(users, -1))
         else:
@@ -276,6 +296,14 @@ class ShardedLightGCN(object):
         _hip.check(L.skr_sum_blocks(_hip.ptr(self._xall), self.ctx.world, n * 64, _hip.ptr(self._xrows), st))
         _hip.check(L.skr_scatter_rows(_hip.ptr(self._xrows), _hip.ptr(ids), n, 64, _hip.ptr(block), st))
 
+    def whole_final(self):
+        """``final`` for readers of ALL its rows (evaluation, tests): after a training step only the batch's rows are valid
+        (the last layer is computed for those only, and on several ranks the other item rows may even differ between
+        the replicas); an unmasked ``propagate()`` makes it whole again"""
+        if not getattr(self, "_final_whole", False):
+            raise ValueError("ShardedLightGCN.final holds only a batch's rows after train_step(): call propagate() first")
+        return self.final
+
     # ---- one training step on a GLOBAL batch -----------------------------------------------------------
     def train_step(self, users, pos, neg):
         """users/pos/neg: int32 device tensors of the whole global batch (identical on every rank);
@@ -287,10 +315,14 @@ class ShardedLightGCN(object):
         # skipped: rows of the last forward layer that no rank's batch reads, and -- in the first backward hop -- the
         # entries that would multiply rows of dL/dfinal that are zero (everything outside the batch).  SKR_LIGHTGCN_DENSE=1
         # computes everything.
-        masks = None if os.environ.get("SKR_LIGHTGCN_DENSE") == "1" else self._batch_rows(users, pos, neg)
-        self.propagate(last_rows=masks)
         gF, gE = self._g_final, self._g_ego
-        gF.zero_()
+        if os.environ.get("SKR_LIGHTGCN_DENSE") == "1":
+            masks = None
+            gF.zero_()
+            self._mask_u = None
+        else:
+            masks = self._batch_rows(users, pos, neg, grad_rows=gF)
+        self.propagate(last_rows=masks)
         self.loss.zero_()
         # the whole GLOBAL batch goes to the kernel, which keeps the triples of the users this rank owns: no selection on
         # the host, no count to read back
@@ -302,25 +334,35 @@ class ShardedLightGCN(object):
         self.ctx.all_reduce(self.loss)
         # gF holds H = dL/dfinal / (K+1) (the kernel applied the factor); the item half is a partial sum over ranks
         hu, hi = gF[:nl], gF[nl:]
-        if masks is not None and self.ctx.active:      # hi is zero outside the global batch's item rows: compact exchange
+        active = self.ctx.active
+        if masks is not None and active:      # hi is zero outside the global batch's item rows: compact exchange
             self._rows_exchange_end(self._rows_exchange_begin(hi, self._batch_item_ids), self._batch_item_ids, hi)
         else:
             self.ctx.all_reduce(hi)
         gu, gi = hu, hi
         gEu, gEi = gE[:nl], gE[nl:]
+        hm_u, hm_i = masks if masks is not None else (None, None)      # H is zero outside the batch's rows
         for k in range(K):
             last = (k == K - 1)
             nu, ni = self._gu[k & 1], self._gi[k & 1]
             cu, ci = masks if (masks is not None and k == 0) else (None, None)
+            if not active:
+                # one rank: g_{k+1} = A g_k + H in both epilogues; the last hop adds into the ego gradient (which holds the
+                # regulariser's part) directly
+                self.a_iu.spmm(gu, ni, addend=hi, accum=gEi if last else None, accum_scale=1.0, col_mask=cu, addend_mask=hm_i)
+                self.a_ui.spmm(gi, nu, addend=hu, accum=gEu if last else None, accum_scale=1.0, col_mask=ci, addend_mask=hm_u)
+                gu, gi = nu, ni
+                continue
             self.a_iu.spmm(gu, ni, col_mask=cu)
             if last:
                 self._axpy(1.0, gEi, ni)           # this rank's regulariser part of the item gradient
             work = self.ctx.all_reduce_begin(ni)   # summed over the ranks beside the user-side product of the same hop
-            self.a_ui.spmm(gi, nu, addend=hu, accum=gEu if last else None, accum_scale=1.0, col_mask=ci)
+            self.a_ui.spmm(gi, nu, addend=hu, accum=gEu if last else None, accum_scale=1.0, col_mask=ci, addend_mask=hm_u)
             self.ctx.all_reduce_end(work)
             self._axpy(1.0, hi, ni)
             gu, gi = nu, ni
-        gEi.copy_(gi)                              # identical on every rank -> identical Adam update
+        if active:
+            gEi.copy_(gi)                          # identical on every rank -> identical Adam update
         self.optimizer.step()
 
     def gather_user_table(self):
@@ -398,32 +440,52 @@ class ShardedLayerGCN(object):
         finite values in y / w / out; nothing reads ``out`` there and their dL/d out is zero."""
         L, st, nl = _hip.lib(), _hip.stream(), self.n_local
         a_ui, a_iu = self.train_blocks if train else self.full_blocks
-        n = self.ego.shape[0]
-        self.out.zero_()
+        active = self.ctx.active
         x = self.ego
         K = self.n_layers
         for k in range(K):
-            y = self._y[k]
+            y, zk, wk = self._y[k], self._z[k & 1], self._w[k]
             mu, mi = last_rows if (last_rows is not None and k == K - 1) else (None, None)
+            first = (k == 0)       # the first layer initialises `out` (no fill of the buffer)
+            au, ai = last_rows if last_rows is not None else (None, None)    # `out` is only needed on the rows that are read
+            if not active:
+                # one rank: the refinement (w = cos(A x, E0), z = w * A x, out += z) rides in both products' row epilogues
+                a_iu.spmm(x[:nl], y[nl:], row_mask=mi, accum=self.out[nl:], accum_init=first,
+                          refine_fwd=(self.ego[nl:], wk[nl:], zk[nl:]), accum_mask=ai)
+                a_ui.spmm(x[nl:], y[:nl], row_mask=mu, accum=self.out[:nl], accum_init=first,
+                          refine_fwd=(self.ego[:nl], wk[:nl], zk[:nl]), accum_mask=au)
+                x = zk
+                continue
             a_iu.spmm(x[:nl], y[nl:], row_mask=mi)                # partial items <- local users
-            # the exchange of this layer runs beside the user-side product
-            compact = self._batch_item_ids if (mi is not None and self.ctx.active) else None
+            # the exchange of this layer runs beside the user-side product (whose refinement rides in its row epilogue)
+            compact = self._batch_item_ids if mi is not None else None
             if compact is not None:
                 work = ShardedLightGCN._rows_exchange_begin(self, y[nl:], compact)
             else:
                 work = self.ctx.all_reduce_begin(y[nl:])
-            a_ui.spmm(x[nl:], y[:nl], row_mask=mu)                # local users <- replicated items
+            a_ui.spmm(x[nl:], y[:nl], row_mask=mu, accum=self.out[:nl], accum_init=first,
+                      refine_fwd=(self.ego[:nl], wk[:nl], zk[:nl]), accum_mask=au)
             if compact is not None:
                 ShardedLightGCN._rows_exchange_end(self, work, compact, y[nl:])
             else:
                 self.ctx.all_reduce_end(work)
-            zk = self._z[k & 1]
-            _hip.check(L.skr_layer_refine_fwd(_hip.ptr(y), _hip.ptr(self.ego), n, 64, _hip.ptr(zk), _hip.ptr(self._w[k]),
-                                              _hip.ptr(self.out), st))
+            # the item rows' refinement needs the summed rows: a launch of its own over the item block
+            if first:
+                self.out[nl:].zero_()
+            _hip.check(L.skr_layer_refine_fwd(_hip.ptr(y[nl:]), _hip.ptr(self.ego[nl:]), self.num_items, 64, _hip.ptr(zk[nl:]),
+                                              _hip.ptr(wk[nl:]), _hip.ptr(self.out[nl:]), st))
             x = zk
+        self._out_whole = last_rows is None
         return self.out
 
     _batch_rows = ShardedLightGCN._batch_rows
+
+    def whole_out(self):
+        """``out`` for readers of ALL its rows: valid after ``propagate()`` without ``last_rows`` only (see
+        ShardedLightGCN.whole_final)"""
+        if not getattr(self, "_out_whole", False):
+            raise ValueError("ShardedLayerGCN.out holds only a batch's rows after train_step(): call propagate() first")
+        return self.out
 
     def train_step(self, users, pos, neg):
         """global batch in (global user ids, identical on every rank); ``self.loss`` = global (bpr sum, l2) afterwards"""
@@ -434,10 +496,14 @@ class ShardedLayerGCN(object):
         a_ui, a_iu = self.train_blocks
         # not computed: rows of the last layer's product the batch does not read and, in the first backward hop, the
         # products with rows of dY_K that are zero (as in the one-GPU engine, recommender/LayerGCN.py train_step)
-        masks = None if os.environ.get("SKR_LIGHTGCN_DENSE") == "1" else self._batch_rows(users, pos, neg)
-        self.propagate(train=True, last_rows=masks)
         gO, gE = self._g_out, self._g_ego
-        gO.zero_()
+        if os.environ.get("SKR_LIGHTGCN_DENSE") == "1":
+            masks = None
+            gO.zero_()
+            self._mask_u = None
+        else:
+            masks = self._batch_rows(users, pos, neg, grad_rows=gO)
+        self.propagate(train=True, last_rows=masks)
         self.loss.zero_()
         # the whole GLOBAL batch goes to the kernel, which keeps the triples of the users this rank owns
         _hip.check(L.skr_bpr_step_sharded(
@@ -446,7 +512,8 @@ class ShardedLayerGCN(object):
             _hip.ptr(gO[:nl]), _hip.ptr(gO[nl:]), None, _hip.ptr(gE[:nl]), _hip.ptr(gE[nl:]), _hip.ptr(self.loss),
             None, None, world, rank, 1.0, st))
         self.ctx.all_reduce(self.loss)
-        if masks is not None and self.ctx.active:
+        active = self.ctx.active
+        if masks is not None and active:
             # both item-side blocks are zero outside the global batch's item rows: compact exchanges
             ids = self._batch_item_ids
             ShardedLightGCN._rows_exchange_end(self, ShardedLightGCN._rows_exchange_begin(self, gO[nl:], ids), ids, gO[nl:])
@@ -454,24 +521,54 @@ class ShardedLayerGCN(object):
         else:
             self.ctx.all_reduce(gO[nl:])          # dL/d out, item rows: now the full value everywhere
             self.ctx.all_reduce(gE[nl:])          # the regulariser's part of the item gradient
-        dz = gO
-        dy, tmp = self._t
+        # backward: dZ_K = gO ; dY_k, dE0 += refine_bwd(dZ_k) ; dZ_{k-1} = gO + A dY_k ; dE0 += A dY_1.  The top refinement
+        # only visits the batch's rows (dZ_K is zero elsewhere; the plan's product skips the other columns of dY_K, for
+        # the plan-free kernel the skipped rows are written as zeros); every further one rides in the row epilogue of
+        # the hop that produces its dZ -- user rows always, item rows when nothing has to be summed over ranks first.
+        dy, nxt = self._t
+        mk_u, mk_i = masks if masks is not None else (None, None)
+        zs = 0 if (a_ui.uses_plan() and a_iu.uses_plan()) else 1
+        yK, wK = self._y[K - 1], self._w[K - 1]
+        _hip.check(L.skr_layer_refine_bwd_masked(_hip.ptr(yK[:nl]), _hip.ptr(self.ego[:nl]), _hip.ptr(wK[:nl]), _hip.ptr(gO[:nl]), nl, 64,
+                                                 _hip.ptr(dy[:nl]), _hip.ptr(gE[:nl]), _hip.ptr(mk_u), zs, st))
+        _hip.check(L.skr_layer_refine_bwd_masked(_hip.ptr(yK[nl:]), _hip.ptr(self.ego[nl:]), _hip.ptr(wK[nl:]), _hip.ptr(gO[nl:]),
+                                                 self.num_items, 64, _hip.ptr(dy[nl:]), _hip.ptr(gE[nl:]), _hip.ptr(mk_i), zs, st))
         for k in range(K - 1, -1, -1):
-            _hip.check(L.skr_layer_refine_bwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), _hip.ptr(self._w[k]),
-                                              _hip.ptr(dz), n, 64, _hip.ptr(dy), _hip.ptr(gE), st))
             cu, ci = masks if (masks is not None and k == K - 1) else (None, None)
-            a_iu.spmm(dy[:nl], tmp[nl:], col_mask=cu)            # item side first, its exchange beside the user side
-            work = self.ctx.all_reduce_begin(tmp[nl:])
             if k > 0:
-                a_ui.spmm(dy[nl:], tmp[:nl], addend=gO[:nl], col_mask=ci)
-                self.ctx.all_reduce_end(work)
-                self._axpy(1.0, gO[nl:], tmp[nl:])
-                dz = tmp
+                yb, wb = self._y[k - 1], self._w[k - 1]
+                rb_u = (self.ego[:nl], wb[:nl], yb[:nl], gE[:nl])
+                rb_i = (self.ego[nl:], wb[nl:], yb[nl:], gE[nl:])
+                if not active:
+                    a_iu.spmm(dy[:nl], nxt[nl:], addend=gO[nl:], col_mask=cu, refine_bwd=rb_i, addend_mask=mk_i)
+                    a_ui.spmm(dy[nl:], nxt[:nl], addend=gO[:nl], col_mask=ci, refine_bwd=rb_u, addend_mask=mk_u)
+                else:
+                    tmp_i = self._tmp_items()
+                    a_iu.spmm(dy[:nl], tmp_i, col_mask=cu)         # item side first, its exchange beside the user side
+                    work = self.ctx.all_reduce_begin(tmp_i)
+                    a_ui.spmm(dy[nl:], nxt[:nl], addend=gO[:nl], col_mask=ci, refine_bwd=rb_u, addend_mask=mk_u)
+                    self.ctx.all_reduce_end(work)
+                    self._axpy(1.0, gO[nl:], tmp_i)
+                    _hip.check(L.skr_layer_refine_bwd(_hip.ptr(yb[nl:]), _hip.ptr(self.ego[nl:]), _hip.ptr(wb[nl:]), _hip.ptr(tmp_i),
+                                                      self.num_items, 64, _hip.ptr(nxt[nl:]), _hip.ptr(gE[nl:]), st))
+                dy, nxt = nxt, dy
             else:
-                a_ui.spmm(dy[nl:], tmp[:nl], accum=gE[:nl], accum_scale=1.0, col_mask=ci)
-                self.ctx.all_reduce_end(work)
-                self._axpy(1.0, tmp[nl:], gE[nl:])
+                if not active:
+                    a_iu.spmm(dy[:nl], None, accum=gE[nl:], accum_scale=1.0, col_mask=cu)
+                    a_ui.spmm(dy[nl:], None, accum=gE[:nl], accum_scale=1.0, col_mask=ci)
+                else:
+                    tmp_i = self._tmp_items()
+                    a_iu.spmm(dy[:nl], tmp_i, col_mask=cu)
+                    work = self.ctx.all_reduce_begin(tmp_i)
+                    a_ui.spmm(dy[nl:], None, accum=gE[:nl], accum_scale=1.0, col_mask=ci)
+                    self.ctx.all_reduce_end(work)
+                    self._axpy(1.0, tmp_i, gE[nl:])
         self.optimizer.step()
+
+    def _tmp_items(self):
+        if getattr(self, "_tmp_i", None) is None:
+            self._tmp_i = torch.zeros((self.num_items, 64), dtype=torch.float32, device=self.device)
+        return self._tmp_i
 
     def gather_user_rows(self, local_rows):
         """[U, 64] on every rank from each rank's [U_local, 64] block"""

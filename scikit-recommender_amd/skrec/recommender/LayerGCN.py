@@ -214,14 +214,14 @@ class LayerGCN(AbstractRecommender):
         L, st = _hip.lib(), _hip.stream()
         N = self.ego.shape[0]
         adj = adj if adj is not None else self.adj
-        self.out.zero_()
         x = self.ego
         K = self.config.n_layers
         for k in range(K):
-            adj.spmm(x, self._y[k], row_mask=last_rows if k == K - 1 else None)
             zk = self._z[k & 1]
-            _hip.check(L.skr_layer_refine_fwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), N, 64, _hip.ptr(zk),
-                                              _hip.ptr(self._w[k]), _hip.ptr(self.out), st))
+            # the refinement (w = cos(A x, E0), z = w * A x, out += z) rides in the product's row epilogue; the first layer
+            # initialises `out` (no fill)
+            adj.spmm(x, self._y[k], row_mask=last_rows if k == K - 1 else None, accum=self.out, accum_init=(k == 0),
+                     refine_fwd=(self.ego, self._w[k], zk), accum_mask=last_rows)
             x = zk
         return self.out
 
@@ -233,35 +233,45 @@ class LayerGCN(AbstractRecommender):
         # not computed: rows of the last layer's product that the batch does not read, and -- in the first backward hop --
         # the products with rows of dY_K that are zero (dL/d out is zero outside the batch's rows, and the refinement's
         # backward is row-local).  SKR_LIGHTGCN_DENSE=1 computes everything.
-        rows = None if os.environ.get("SKR_LIGHTGCN_DENSE") == "1" else self._batch_rows(users, pos, neg)
-        self.forward(adj, last_rows=rows)
         gO, gE = self._g_out, self._g_ego
-        gO.zero_()
+        if os.environ.get("SKR_LIGHTGCN_DENSE") == "1":
+            rows = None
+            gO.zero_()
+            self._row_mask = None
+        else:
+            # dL/d out is zero outside the previous batch's rows: those are cleared (with their marks), not the whole buffer
+            if getattr(self, "_row_mask", None) is None:
+                self._row_mask = torch.zeros(self.num_users + self.num_items, dtype=torch.uint8, device=self.device)
+                gO.zero_()
+            else:
+                _hip.check(L.skr_clear_marked_rows(_hip.ptr(self._row_mask), N, 1, _hip.ptr(gO), 64, st))
+            rows = self._batch_rows(users, pos, neg)
+        self.forward(adj, last_rows=rows)
         _hip.check(L.skr_bpr_step(
             _hip.ptr(self.out[:nu]), _hip.ptr(self.out[nu:]), None, _hip.ptr(self.ego[:nu]), _hip.ptr(self.ego[nu:]),
             _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), 1.0, cfg.reg, 1.0,
             _hip.ptr(gO[:nu]), _hip.ptr(gO[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot),
             None, None, st))
-        # backward: dZ_K = gO ; dY_k, dE0 += refine_bwd(dZ_k) ; dZ_{k-1} = gO + A dY_k ; dE0 += A dY_1
-        dz = gO
-        dy, tmp = self._t
-        for k in range(cfg.n_layers - 1, -1, -1):
-            _hip.check(L.skr_layer_refine_bwd(_hip.ptr(self._y[k]), _hip.ptr(self.ego), _hip.ptr(self._w[k]),
-                                              _hip.ptr(dz), N, 64, _hip.ptr(dy), _hip.ptr(gE), st))
-            cm = rows if k == cfg.n_layers - 1 else None
+        # backward: dZ_K = gO ; dY_k, dE0 += refine_bwd(dZ_k) ; dZ_{k-1} = gO + A dY_k ; dE0 += A dY_1.  dZ_K is zero outside the
+        # batch's rows, so the top refinement only visits those (the plan's product then skips the other columns of dY_K;
+        # the plan-free kernel reads every column: there the skipped rows are written as zeros); every further refinement
+        # rides in the row epilogue of the hop that produces its dZ.
+        K = cfg.n_layers
+        dy, nxt = self._t
+        _hip.check(L.skr_layer_refine_bwd_masked(_hip.ptr(self._y[K - 1]), _hip.ptr(self.ego), _hip.ptr(self._w[K - 1]), _hip.ptr(gO), N, 64,
+                                                 _hip.ptr(dy), _hip.ptr(gE), _hip.ptr(rows), 0 if adj.uses_plan() else 1, st))
+        for k in range(K - 1, -1, -1):
+            cm = rows if k == K - 1 else None
             if k > 0:
-                adj.spmm(dy, tmp, addend=gO, col_mask=cm)
-                dz = tmp
+                adj.spmm(dy, nxt, addend=gO, col_mask=cm, refine_bwd=(self.ego, self._w[k - 1], self._y[k - 1], gE), addend_mask=rows)
+                dy, nxt = nxt, dy
             else:
-                adj.spmm(dy, tmp, accum=gE, accum_scale=1.0, col_mask=cm)
+                adj.spmm(dy, None, accum=gE, accum_scale=1.0, col_mask=cm)
         self.optimizer.step()
 
     def _batch_rows(self, users, pos, neg):
         """uint8 [N]: 1 on the rows of [U; V] a batch touches (the gathers of calculate_loss, LayerGCN.py:245-253)"""
-        if getattr(self, "_row_mask", None) is None:
-            self._row_mask = torch.zeros(self.num_users + self.num_items, dtype=torch.uint8, device=self.device)
         m, L, st, nu = self._row_mask, _hip.lib(), _hip.stream(), self.num_users
-        m.zero_()
         _hip.check(L.skr_mark_ids(_hip.ptr(users), users.numel(), 0, _hip.ptr(m), st))
         _hip.check(L.skr_mark_ids(_hip.ptr(pos), pos.numel(), nu, _hip.ptr(m), st))
         _hip.check(L.skr_mark_ids(_hip.ptr(neg), neg.numel(), nu, _hip.ptr(m), st))
@@ -298,7 +308,7 @@ class LayerGCN(AbstractRecommender):
         if self.engine is not None:
             e = self.engine
             e.propagate(train=False)
-            self._full_user_out = e.gather_user_rows(e.out[:e.n_local])   # every rank can rank any user
+            self._full_user_out = e.gather_user_rows(e.whole_out()[:e.n_local])   # every rank can rank any user
         else:
             self.forward()
 
@@ -311,7 +321,7 @@ class LayerGCN(AbstractRecommender):
 
     def predict_factors(self):
         if self.engine is not None:
-            return self._full_user_out, self.engine.out[self.engine.n_local:], None
+            return self._full_user_out, self.engine.whole_out()[self.engine.n_local:], None
         return self.out[:self.num_users], self.out[self.num_users:], None
 
     def predict(self, users):

@@ -120,20 +120,69 @@ class DeviceCSR(object):
                 pass
             self._plan = None
 
-    def spmm(self, X, Y, addend=None, accum=None, accum_scale=1.0, row_mask=None, col_mask=None):
+    def uses_plan(self):
+        """whether products of this matrix go through the plan (which honours the row / column masks)"""
+        mode = os.environ.get("SKR_SPMM_PLAN", "auto")
+        return mode == "1" or (mode != "0" and self.nnz >= self.PLAN_MIN_NNZ)
+
+    def spmm(self, X, Y, addend=None, accum=None, accum_scale=1.0, row_mask=None, col_mask=None, accum_base=None, accum_init=False,
+             refine_fwd=None, refine_bwd=None, accum_mask=None, addend_mask=None):
         """Y = A @ X (+ addend); accum += accum_scale * Y.
         ``row_mask`` (uint8 [n_rows]): only rows with a non-zero byte are needed (the others may be left untouched);
         ``col_mask`` (uint8 [n_cols]): rows of X with a zero byte ARE zero, their entries may be skipped.  Both are
-        hints: the plan-free kernel computes the whole product."""
-        mode = os.environ.get("SKR_SPMM_PLAN", "auto")
-        if mode == "1" or (mode != "0" and self.nnz >= self.PLAN_MIN_NNZ):
-            _hip.check(_hip.lib().skr_spmm_plan_run_masked(self._plan_handle(), _hip.ptr(X), 64, _hip.ptr(addend), _hip.ptr(Y),
-                                                           _hip.ptr(accum), float(accum_scale), _hip.ptr(row_mask),
-                                                           _hip.ptr(col_mask), _hip.stream()))
+        hints: the plan-free kernel computes the whole product.
+        Row-local passes that ride in the product's row epilogue (skr_spmm_epilogue, include/skrec_hip.h):
+        ``accum_base``: accum = accum_scale * accum_base + accum_scale * Y (accum is not read: the layer mean with its E0 term);
+        ``accum_init``: accum = accum_scale * Y, resp. accum = Z (accum is not read);
+        ``refine_fwd`` = (E, w, Z): LayerGCN's refinement of the finished rows, w = cos(Y, E), Z = w * Y, accum += Z
+        (Y keeps the raw rows; may be None);
+        ``refine_bwd`` = (E, w, rawY, dE): the finished rows are dZ of a refinement; Y receives dY, dE its E0 part.
+        ``accum_mask`` (uint8 [n_rows]): accum is only needed on the rows with a non-zero byte; ``addend_mask`` (uint8
+        [n_rows]): addend IS zero on the rows with a zero byte (hints again: the plan-free path reads / updates every row)."""
+        L, st = _hip.lib(), _hip.stream()
+        n = self.shape[0]
+        if self.uses_plan():
+            if Y is not None and accum_base is None and not accum_init and refine_fwd is None and refine_bwd is None \
+                    and accum_mask is None and addend_mask is None:
+                _hip.check(L.skr_spmm_plan_run_masked(self._plan_handle(), _hip.ptr(X), 64, _hip.ptr(addend), _hip.ptr(Y),
+                                                      _hip.ptr(accum), float(accum_scale), _hip.ptr(row_mask),
+                                                      _hip.ptr(col_mask), st))
+                return Y
+            import ctypes
+            ep = _hip.SpmmEpilogue()
+            ep.mode, ep.accum_init = _hip.EPI_PLAIN, int(bool(accum_init))
+            ep.addend, ep.Y, ep.accum, ep.accum_base = _hip.ptr(addend), _hip.ptr(Y), _hip.ptr(accum), _hip.ptr(accum_base)
+            ep.accum_scale = float(accum_scale)
+            ep.accum_mask, ep.addend_mask = _hip.ptr(accum_mask), _hip.ptr(addend_mask)
+            if refine_fwd is not None:
+                ep.mode = _hip.EPI_REFINE_FWD
+                ep.E, ep.w, ep.Z = (_hip.ptr(t) for t in refine_fwd)
+            elif refine_bwd is not None:
+                ep.mode = _hip.EPI_REFINE_BWD
+                ep.E, ep.w, ep.rawY, ep.dE = (_hip.ptr(t) for t in refine_bwd)
+            _hip.check(L.skr_spmm_plan_run_ex(self._plan_handle(), _hip.ptr(X), 64, ctypes.byref(ep), _hip.ptr(row_mask),
+                                              _hip.ptr(col_mask), st))
             return Y
-        _hip.check(_hip.lib().skr_csr_spmm(self.shape[0], _hip.ptr(self.rowptr), _hip.ptr(self.col), _hip.ptr(self.val),
-                                           _hip.ptr(X), 64, self.nnz, _hip.ptr(addend), _hip.ptr(Y), _hip.ptr(accum),
-                                           float(accum_scale), _hip.stream()))
+        # small graphs: the plan-free kernel computes whole products; the row-local passes are launches of their own
+        raw = Y
+        if Y is None or refine_bwd is not None:
+            if getattr(self, "_tmp", None) is None:
+                self._tmp = torch.empty((n, 64), dtype=torch.float32, device=X.device)
+            raw = self._tmp
+        plain = refine_fwd is None and refine_bwd is None
+        if plain and accum is not None and accum_base is not None:
+            _hip.check(L.skr_scale_copy(float(accum_scale), _hip.ptr(accum_base), _hip.ptr(accum), n * 64, st))
+        elif accum is not None and accum_init:
+            accum.zero_()
+        _hip.check(L.skr_csr_spmm(n, _hip.ptr(self.rowptr), _hip.ptr(self.col), _hip.ptr(self.val), _hip.ptr(X), 64, self.nnz,
+                                  _hip.ptr(addend), _hip.ptr(raw), _hip.ptr(accum) if plain else None, float(accum_scale), st))
+        if refine_fwd is not None:
+            E, w, Z = refine_fwd
+            _hip.check(L.skr_layer_refine_fwd(_hip.ptr(raw), _hip.ptr(E), n, 64, _hip.ptr(Z), _hip.ptr(w), _hip.ptr(accum), st))
+        elif refine_bwd is not None:
+            E, w, rawY, dE = refine_bwd
+            _hip.check(L.skr_layer_refine_bwd(_hip.ptr(rawY), _hip.ptr(E), _hip.ptr(w), _hip.ptr(raw), n, 64, _hip.ptr(Y), _hip.ptr(dE),
+                                              st))
         return Y
 
 
@@ -286,21 +335,19 @@ class LightGCN(AbstractRecommender):
         those rows only."""
         K = self.config.n_layers
         scale = 1.0 / (K + 1)
-        _hip.check(_hip.lib().skr_scale_copy(scale, _hip.ptr(self.ego), _hip.ptr(self.final), self.ego.numel(), _hip.stream()))
         x = self.ego
         for k in range(K):
             y = self._x[k & 1]
-            self.adj.spmm(x, y, accum=self.final, accum_scale=scale, row_mask=last_rows if k == K - 1 else None)
+            # the mean's E0 term rides in the first product's row epilogue: E-bar = scale * E0 + scale * A E0, then += per layer
+            self.adj.spmm(x, y, accum=self.final, accum_scale=scale, accum_base=self.ego if k == 0 else None,
+                          row_mask=last_rows if k == K - 1 else None, accum_mask=last_rows)
             x = y
         return self.final
 
     def _batch_rows(self, users, pos, neg):
         """uint8 [N]: 1 on the rows of [U; V] a batch touches -- the only rows of E-bar its loss reads, and the only
         non-zero rows of dL/dE-bar (reference: the gathers of _LightGCN.forward, LightGCN.py:82-87)"""
-        if self._row_mask is None:
-            self._row_mask = torch.zeros(self.num_users + self.num_items, dtype=torch.uint8, device=self.device)
         m, L, st, nu = self._row_mask, _hip.lib(), _hip.stream(), self.num_users
-        m.zero_()
         _hip.check(L.skr_mark_ids(_hip.ptr(users), users.numel(), 0, _hip.ptr(m), st))
         _hip.check(L.skr_mark_ids(_hip.ptr(pos), pos.numel(), nu, _hip.ptr(m), st))
         _hip.check(L.skr_mark_ids(_hip.ptr(neg), neg.numel(), nu, _hip.ptr(m), st))
@@ -313,11 +360,23 @@ class LightGCN(AbstractRecommender):
         # the product A x dense is the reference's; what is skipped is arithmetic whose result is never read (rows of the
         # last forward layer outside the batch) or is a sum of zeros (the first backward hop reads dL/dE-bar, which is zero
         # outside the batch's rows).  SKR_LIGHTGCN_DENSE=1 computes everything.
-        rows = None if os.environ.get("SKR_LIGHTGCN_DENSE") == "1" else self._batch_rows(users, pos, neg)
+        gF, gE = self._g_final, self._g_ego
+        if os.environ.get("SKR_LIGHTGCN_DENSE") == "1":
+            rows = None
+            gF.zero_()
+            self._row_mask = None
+        else:
+            # dL/dE-bar is zero outside the previous batch's rows: those rows are cleared (and their marks with them)
+            # instead of filling the whole [N, 64] buffer
+            if self._row_mask is None:
+                self._row_mask = torch.zeros(self.num_users + self.num_items, dtype=torch.uint8, device=self.device)
+                gF.zero_()
+            else:
+                _hip.check(_hip.lib().skr_clear_marked_rows(_hip.ptr(self._row_mask), self._row_mask.numel(), 1, _hip.ptr(gF), 64,
+                                                            _hip.stream()))
+            rows = self._batch_rows(users, pos, neg)
         self.propagate(last_rows=rows)
         self._final_is_current = False
-        gF, gE = self._g_final, self._g_ego
-        gF.zero_()
         # the score part of the gradient is written already divided by K + 1: gF holds H = dL/dE-bar / (K + 1)
         _hip.check(_hip.lib().skr_bpr_step_sharded(
             _hip.ptr(self.final[:nu]), _hip.ptr(self.final[nu:]), None, _hip.ptr(self.ego[:nu]), _hip.ptr(self.ego[nu:]),
@@ -329,7 +388,8 @@ class LightGCN(AbstractRecommender):
         for k in range(K):
             y = self._g[k & 1]
             last = (k == K - 1)
-            self.adj_t.spmm(x, y, addend=gF, accum=gE if last else None, accum_scale=1.0, col_mask=rows if k == 0 else None)
+            self.adj_t.spmm(x, y, addend=gF, accum=gE if last else None, accum_scale=1.0, col_mask=rows if k == 0 else None,
+                            addend_mask=rows)
             x = y
         self.optimizer.step()
 
@@ -364,7 +424,7 @@ class LightGCN(AbstractRecommender):
             e = self.engine
             e.propagate()
             full = torch.zeros((self.num_users, 64), dtype=torch.float32, device=self.device)
-            full[torch.from_numpy(e.mine).to(self.device)] = e.final[:e.n_local]
+            full[torch.from_numpy(e.mine).to(self.device)] = e.whole_final()[:e.n_local]
             self._full_user_final = self.dist.all_reduce(full)    # every rank can rank any user
         else:
             self.propagate()
@@ -381,7 +441,7 @@ class LightGCN(AbstractRecommender):
         if not self._final_is_current:
             raise ValueError("Please first switch to 'eval' mode.")
         if self.engine is not None:
-            return self._full_user_final, self.engine.final[self.engine.n_local:], None
+            return self._full_user_final, self.engine.whole_final()[self.engine.n_local:], None
         return self.final[:self.num_users], self.final[self.num_users:], None
 
     def predict(self, users):

@@ -58,12 +58,18 @@ def _worker(rank, world, port, ret):
     for u, i, j in _batches():
         eng.train_step(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev), torch.from_numpy(j).to(dev))
         losses.append(eng.loss.cpu().numpy().copy())
+    try:                      # after a training step only the batch's rows of `final` are valid
+        eng.whole_final()
+        guarded = False
+    except ValueError:
+        guarded = True
+    assert guarded
     eng.propagate()
     uf = torch.zeros((U, 64), device=dev)
-    uf[torch.from_numpy(eng.mine).to(dev)] = eng.final[:eng.n_local]
+    uf[torch.from_numpy(eng.mine).to(dev)] = eng.whole_final()[:eng.n_local]
     eng.ctx.all_reduce(uf)
     ret[rank] = dict(losses=np.stack(losses), U1=eng.gather_user_table().cpu().numpy(), V1=eng.item_rows.cpu().numpy(),
-                     Uf=uf.cpu().numpy(), Vf=eng.final[eng.n_local:].cpu().numpy(), n_local=eng.n_local)
+                     Uf=uf.cpu().numpy(), Vf=eng.whole_final()[eng.n_local:].cpu().numpy(), n_local=eng.n_local)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -272,7 +278,7 @@ def _layergcn_worker(rank, world, port, data_dir, workdir, dropout, ret, backend
     m.fit()
     e = m.engine
     ret[rank] = dict(reports=np.stack(reports), losses=np.concatenate(losses, 0), U1=m.user_embeddings.cpu().numpy(),
-                     V1=m.item_embeddings.cpu().numpy(), Uf=e.gather_user_rows(e.out[:e.n_local]).cpu().numpy(),
+                     V1=m.item_embeddings.cpu().numpy(), Uf=e.gather_user_rows(e.whole_out()[:e.n_local]).cpu().numpy(),
                      pred=m.predict([0, 3, 9, 63]), n_test=len(m.evaluator.user_pos_test), nnz=nnz,
                      full_nnz=e.full_blocks[0].nnz)
     import torch.distributed as dist

@@ -280,6 +280,97 @@ def test_layer_refine_fwd_bwd_vs_torch_autograd():
     _close(gE.cpu().numpy(), 2.0 + te.grad.numpy(), rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("plan", ["0", "1"])
+def test_spmm_row_epilogues_equal_the_separate_passes(plan, monkeypatch):
+    """skr_spmm_plan_run_ex: the row-local passes in the product's row epilogue (layer mean with its E0 term, buffer
+    initialisation, LayerGCN's refinement forward and backward, with row masks) == the plain product followed by the
+    stand-alone kernels -- short rows (the row kernel's 16-lane layout) and long rows (the reduce kernel's 64-lane layout);
+    plan "0": the plan-free composition DeviceCSR.spmm falls back to on small graphs.  skr_layer_refine_bwd_masked,
+    skr_clear_marked_rows."""
+    import torch
+    from gpu_utils import dev, to_dev
+    from skrec import _hip
+    from skrec.recommender.LightGCN import DeviceCSR
+    monkeypatch.setenv("SKR_SPMM_PLAN", plan)
+    L, st = _hip.lib(), _hip.stream()
+    rng = np.random.default_rng(31)
+    n = 2500
+    A = sp.random(n, n, density=0.004, format="lil", random_state=rng, dtype=np.float32)
+    for h in range(3):
+        cols = rng.choice(n, 1200 + 300 * h, replace=False)
+        A[h * 11 + 1, cols] = rng.standard_normal(len(cols)).astype(np.float32)
+    A = sp.csr_matrix(A)
+    A[n // 3, :] = 0
+    A.eliminate_zeros()
+    csr = DeviceCSR(A, dev())
+    X, E, add, acc0, dE0 = (to_dev(rng.standard_normal((n, 64)).astype(np.float32)) for _ in range(5))
+    mask_np = (rng.random(n) < 0.3).astype(np.uint8)
+    mask_np[[1, 12, 23]] = [1, 0, 1]
+    mask = to_dev(mask_np)
+    z = lambda: torch.zeros((n, 64), device=dev())  # noqa: E731
+    raw = z()
+    csr.spmm(X, raw)
+    rawa = raw + add
+
+    def close(a, b, tol=2e-6):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert np.all(np.abs(a - b) <= tol * (1.0 + np.abs(b))), np.abs(a - b).max()
+    # layer mean with its E0 term, and initialisation without reading
+    Y, acc = z(), torch.full((n, 64), 9.0, device=dev())
+    csr.spmm(X, Y, accum=acc, accum_scale=0.25, accum_base=E)
+    close(Y, raw)
+    close(acc, 0.25 * E + 0.25 * raw)
+    acc = torch.full((n, 64), 9.0, device=dev())
+    csr.spmm(X, None, addend=add, accum=acc, accum_scale=0.5, accum_init=True)
+    close(acc, 0.5 * rawa)
+    # forward refinement
+    Zs, Ws, accs = z(), torch.zeros(n, device=dev()), acc0.clone()
+    _hip.check(L.skr_layer_refine_fwd(_hip.ptr(raw), _hip.ptr(E), n, 64, _hip.ptr(Zs), _hip.ptr(Ws), _hip.ptr(accs), st))
+    Y, Zf, Wf, accf = z(), z(), torch.zeros(n, device=dev()), acc0.clone()
+    csr.spmm(X, Y, accum=accf, refine_fwd=(E, Wf, Zf))
+    close(Y, raw); close(Zf, Zs); close(Wf, Ws); close(accf, accs)
+    accf = torch.full((n, 64), 9.0, device=dev())
+    csr.spmm(X, None, accum=accf, accum_init=True, refine_fwd=(E, Wf, Zf))
+    close(accf, Zs)
+    # ... with a row mask: rows outside it are left as they were (plan) or computed anyway (plan-free)
+    Zm, Wm = torch.full((n, 64), 5.0, device=dev()), torch.full((n,), 5.0, device=dev())
+    csr.spmm(X, None, row_mask=mask, refine_fwd=(E, Wm, Zm))
+    sel = torch.from_numpy(mask_np.astype(bool)).to(dev())
+    close(Zm[sel], Zs[sel]); close(Wm[sel], Ws[sel])
+    if plan == "1":
+        assert bool((Zm[~sel] == 5.0).all()) and bool((Wm[~sel] == 5.0).all())
+    # backward refinement: the finished row (product + addend) is dZ
+    dYs, dEs = z(), dE0.clone()
+    _hip.check(L.skr_layer_refine_bwd(_hip.ptr(Y), _hip.ptr(E), _hip.ptr(Ws), _hip.ptr(rawa), n, 64, _hip.ptr(dYs), _hip.ptr(dEs), st))
+    dYf, dEf = z(), dE0.clone()
+    csr.spmm(X, dYf, addend=add, refine_bwd=(E, Ws, Y, dEf))
+    close(dYf, dYs, 4e-6); close(dEf, dEs, 4e-6)
+    # the masked stand-alone backward refinement, both treatments of the skipped rows
+    for zs in (0, 1):
+        dYm, dEm = torch.full((n, 64), 3.0, device=dev()), dE0.clone()
+        _hip.check(L.skr_layer_refine_bwd_masked(_hip.ptr(Y), _hip.ptr(E), _hip.ptr(Ws), _hip.ptr(rawa), n, 64, _hip.ptr(dYm), _hip.ptr(dEm),
+                                                 _hip.ptr(mask), zs, st))
+        assert torch.equal(dYm[sel], dYs[sel]) and torch.equal(dEm[sel], dEs[sel])
+        assert bool((dYm[~sel] == (0.0 if zs else 3.0)).all()) and torch.equal(dEm[~sel], dE0[~sel])
+    # accum only where somebody reads it; an addend that is zero outside the marked rows is not read there
+    acc = torch.full((n, 64), 9.0, device=dev())
+    csr.spmm(X, Y, accum=acc, accum_scale=0.25, accum_base=E, accum_mask=mask)
+    close(acc[sel], (0.25 * E + 0.25 * raw)[sel])
+    if plan == "1":
+        assert bool((acc[~sel] == 9.0).all())
+    add_sparse = add * torch.from_numpy(mask_np).to(dev()).float().unsqueeze(1)
+    poisoned = torch.where(sel.unsqueeze(1), add, torch.full_like(add, float("nan"))) if plan == "1" else add_sparse
+    Y2 = z()
+    csr.spmm(X, Y2, addend=poisoned, addend_mask=mask)       # (plan: the rows outside the mask must not even be read)
+    close(Y2, raw + add_sparse)
+    # skr_clear_marked_rows
+    T, m2 = torch.ones((n, 64), device=dev()), mask.clone()
+    _hip.check(L.skr_clear_marked_rows(_hip.ptr(m2), n, 1, _hip.ptr(T), 64, st))
+    assert bool((T[sel] == 0).all()) and bool((T[~sel] == 1).all()) and int(m2.sum()) == 0
+    _hip.check(L.skr_clear_marked_rows(_hip.ptr(mask), n, 0, _hip.ptr(T), 64, st))
+    assert int(mask.sum()) == int(mask_np.sum())
+
+
 def test_gather_axpy_scale():
     import torch
     from gpu_utils import to_dev, dev
