@@ -406,6 +406,17 @@ int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr,
 int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
                        float eps, int64_t step_t0, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
                        int stride_floats, int32_t* d_claim, void* stream);
+/* The same three entry points with tf.train.AdamOptimizer's arithmetic (GRU4RecPlus.py:192): p -= lr_t * m / (sqrt(v) + eps)
+ * with lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) -- the second bias correction sits in the step size, eps is added to
+ * the raw sqrt(v).  |lr_t| falls and then rises again with t, so the at-rest test of a run of zero-gradient updates uses
+ * the largest |lr_t| of the run.  Blocked == one skr_adam_step_tf per step, bit for bit. */
+int skr_adam_step_tf(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     int64_t step_t, int zero_grad, uint8_t* d_touch, void* stream);
+int skr_adam_block_cold_tf(float* d_p, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                           int64_t step_t0, int k, const int32_t* d_tag, int32_t hot_value, void* stream);
+int skr_adam_block_hot_tf(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, int64_t step_t0, int64_t step_t, const int32_t* d_ids, int64_t n_ids,
+                          int64_t offset_floats, int stride_floats, int32_t* d_claim, void* stream);
 
 /* One training step of BPRMF in ONE launch: skr_bpr_step (score rows == regulariser rows, loss_scale 1) and the hot rows'
  * part of the blocked dense Adam together, for a k-step block whose batches are known (replaces, per step, the pair

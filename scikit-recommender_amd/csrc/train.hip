@@ -460,6 +460,9 @@ constexpr int AB_KMAX = 64;
 struct AdamBlockArgs {
     float one_minus_b1, b2, one_minus_b2, eps;
     float neg_step_size[AB_KMAX], bc2_sqrt[AB_KMAX];
+    float nss_bound[AB_KMAX];   // max |neg_step_size[s']| over s' >= s: the bound the at-rest test of a run starting at s needs
+                                // (torch's -lr / bc1 only shrinks with the step: then this IS |neg_step_size[s]|; TF's
+                                //  -lr * sqrt(bc2) / bc1 falls, then rises again towards lr)
     int k;
     // thresholds of the "parameter at rest" test of adam_cold_rows_kernel (0 switches the test off)
     float rest_eps;   // 2^-28 * eps
@@ -640,8 +643,8 @@ __global__ __launch_bounds__(256) void selftest_cold_math_kernel(uint32_t lo, ui
     if (b2) atomicAdd(&bad[3], b2);
 }
 
-// the two per-lane tests of the cold pass (and of the hot step's catch-up): see the comment below.  nss0 = |neg_step_size|
-// of the FIRST of the zero-gradient updates in question (the largest in magnitude of them)
+// the two per-lane tests of the cold pass (and of the hot step's catch-up): see the comment below.  nss0 = the largest
+// |neg_step_size| among the zero-gradient updates in question (AdamBlockArgs::nss_bound of the first of them)
 __device__ __forceinline__ bool lane_at_rest(float pp, float mm, float vv, float nss0, const AdamBlockArgs& a) {
     const float ap = fabsf(pp), n0 = nss0 * fabsf(mm);
     const float r = ap * 0x1p-29f;
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(256) void adam_cold_rows_kernel(float* __restrict__
         bool rest[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            rest[u] = cold[u] && __builtin_amdgcn_ballot_w64(!lane_at_rest(pp[u], mm[u], vv[u], fabsf(a.neg_step_size[0]), a)) == 0;
+            rest[u] = cold[u] && __builtin_amdgcn_ballot_w64(!lane_at_rest(pp[u], mm[u], vv[u], a.nss_bound[0], a)) == 0;
         auto store_rest = [&](int64_t i, float m0, float v0, float m1, float v1) {
             if (__builtin_amdgcn_ballot_w64(__float_as_uint(m1) != __float_as_uint(m0)) != 0) __builtin_nontemporal_store(m1, &m[i]);
             if (__builtin_amdgcn_ballot_w64(__float_as_uint(v1) != __float_as_uint(v0)) != 0) __builtin_nontemporal_store(v1, &v[i]);
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(256) void adam_hot_kernel(float* __restrict__ p, fl
     const int s_grad = t - t0 - 1;                 // the step that takes the gradient
     int s = old - t0;
     if (s < s_grad) {
-        if (__builtin_amdgcn_ballot_w64(!lane_at_rest(pp, mm, vv, fabsf(a.neg_step_size[s]), a)) == 0) {
+        if (__builtin_amdgcn_ballot_w64(!lane_at_rest(pp, mm, vv, a.nss_bound[s], a)) == 0) {
             for (; s < s_grad; ++s) {
                 mm = mm + a.one_minus_b1 * (0.0f - mm);
                 vv = vv * a.b2;
@@ -938,7 +941,7 @@ __device__ __forceinline__ void fused_advance(FusedRow& r, int g_idx, int s_from
     }
     int s = s_from;
     if (s < s_to) {
-        if (__builtin_amdgcn_ballot_w64(!lane_at_rest(r.p, r.m, r.v, fabsf(a.neg_step_size[s]), a)) == 0) {
+        if (__builtin_amdgcn_ballot_w64(!lane_at_rest(r.p, r.m, r.v, a.nss_bound[s], a)) == 0) {
             for (; s < s_to; ++s) {
                 r.m = r.m + a.one_minus_b1 * (0.0f - r.m);
                 r.v = r.v * a.b2;
@@ -1361,8 +1364,18 @@ int skr_bpr_step_spread(const float* d_P, const float* d_Q, const float* d_bias,
                            d_gRQ, d_loss64, d_touch, d_touch_base, SKR_LOSS_SLOTS, stream);
 }
 
+static int adam_step_impl(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, int64_t step_t, int zero_grad, uint8_t* d_touch, bool tf, void* stream);
 int skr_adam_step(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int64_t step_t, int zero_grad, uint8_t* d_touch, void* stream) {
+    return adam_step_impl(d_p, d_g, d_m, d_v, n, lr, beta1, beta2, eps, step_t, zero_grad, d_touch, false, stream);
+}
+int skr_adam_step_tf(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, int64_t step_t, int zero_grad, uint8_t* d_touch, void* stream) {
+    return adam_step_impl(d_p, d_g, d_m, d_v, n, lr, beta1, beta2, eps, step_t, zero_grad, d_touch, true, stream);
+}
+static int adam_step_impl(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, int64_t step_t, int zero_grad, uint8_t* d_touch, bool tf, void* stream) {
     SKR_REQUIRE(d_p && d_g && d_m && d_v, "skr_adam_step: NULL argument");
     SKR_REQUIRE(n >= 0 && step_t >= 1, "skr_adam_step: n must be >= 0 and step_t >= 1");
     SKR_REQUIRE(((reinterpret_cast<uintptr_t>(d_p) | reinterpret_cast<uintptr_t>(d_g) | reinterpret_cast<uintptr_t>(d_m) |
@@ -1378,6 +1391,10 @@ int skr_adam_step(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, flo
     a.one_minus_b2 = static_cast<float>(1.0 - b2);
     a.neg_step_size = static_cast<float>(-(static_cast<double>(lr) / bc1));
     a.bc2_sqrt = static_cast<float>(std::sqrt(bc2));
+    if (tf) {      // tf.train.AdamOptimizer's placement of the second bias correction (adam_scalars)
+        a.neg_step_size = static_cast<float>(-(static_cast<double>(lr) * std::sqrt(bc2) / bc1));
+        a.bc2_sqrt = 1.0f;
+    }
     a.eps = eps;
     // Launch shape measured on MI355X (tools/tune_adam.sh, profiles/r01_adam_tuning.txt): 2 workgroups
     // per CU, 4 float4 per lane in flight, non-temporal accesses.  SKR_ADAM_CFG="<blocks_per_cu>,
@@ -1587,13 +1604,30 @@ int skr_unpack_grad_rows_sorted(const float* d_in, int n_per_rank, int n_ranks, 
     return SKR_OK;
 }
 
-static void adam_scalars(float lr, float beta1, float beta2, int64_t step_t, float* neg_step_size, float* bc2_sqrt) {
+static void adam_scalars(float lr, float beta1, float beta2, int64_t step_t, float* neg_step_size, float* bc2_sqrt, bool tf = false) {
     // torch/optim/adam.py _single_tensor_adam: python-double scalars, cast to fp32 at the tensor ops (as skr_adam_step)
     const double b1 = static_cast<double>(beta1), b2 = static_cast<double>(beta2);
     const double bc1 = 1.0 - std::pow(b1, static_cast<double>(step_t));
     const double bc2 = 1.0 - std::pow(b2, static_cast<double>(step_t));
+    if (tf) {
+        // tf.train.AdamOptimizer (GRU4RecPlus.py:192): p -= lr_t * m / (sqrt(v) + eps), lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t):
+        // the second bias correction sits in the step size, the denominator has none
+        *neg_step_size = static_cast<float>(-(static_cast<double>(lr) * std::sqrt(bc2) / bc1));
+        *bc2_sqrt = 1.0f;
+        return;
+    }
     *neg_step_size = static_cast<float>(-(static_cast<double>(lr) / bc1));
     *bc2_sqrt = static_cast<float>(std::sqrt(bc2));
+}
+
+// the k steps' scalars of a block that starts after step_t0, and the running maximum the at-rest tests use
+static void adam_block_scalars(AdamBlockArgs& a, float lr, float beta1, float beta2, int64_t step_t0, int k, bool tf) {
+    for (int s = 0; s < k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s], tf);
+    float mx = 0.0f;
+    for (int s = k - 1; s >= 0; --s) {
+        mx = std::fmax(mx, std::fabs(a.neg_step_size[s]));
+        a.nss_bound[s] = mx;
+    }
 }
 
 int skr_adam_block_mark(const int32_t* d_ids, int64_t n_ids, int64_t offset_floats, int stride_floats, int32_t* d_tag,
@@ -1631,8 +1665,12 @@ static void adam_block_thresholds(AdamBlockArgs& a, float lr, float beta1, float
     a.rest_b2k = sane ? static_cast<float>(std::pow(static_cast<double>(beta2), k) * (1.0 - 1e-4)) : 0.0f;
     // ordinary magnitudes for all k updates (ranges of sqrt_ordinary / div_ordinary with room to spare): v in
     // [2^-90, 2^20] throughout, |nss*m| in [2^-100, 2^40] throughout, eps <= 2^20, sqrt(1 - beta2^t) >= 2^-10
-    const double nss_first = std::fabs(static_cast<double>(a.neg_step_size[0])), nss_last = std::fabs(static_cast<double>(a.neg_step_size[k - 1]));
-    const double m_lo = 0x1p-100 / (nss_last * std::pow(static_cast<double>(beta1), k) * 0.99), m_hi = 0x1p40 / nss_first;
+    double nss_max = 0.0, nss_min = INFINITY;      // torch's scalars: the first and the last step's; TF's are not monotone
+    for (int s_ = 0; s_ < k; ++s_) {
+        nss_max = std::fmax(nss_max, std::fabs(static_cast<double>(a.neg_step_size[s_])));
+        nss_min = std::fmin(nss_min, std::fabs(static_cast<double>(a.neg_step_size[s_])));
+    }
+    const double m_lo = 0x1p-100 / (nss_min * std::pow(static_cast<double>(beta1), k) * 0.99), m_hi = 0x1p40 / nss_max;
     const bool ord = sane && eps <= 0x1p20f && a.bc2_sqrt[0] >= 0x1p-10f && a.rest_b2k > 0.0f && m_lo < 1e30 && m_hi > 1e-30 &&
                      std::isfinite(m_lo) && std::isfinite(m_hi);
     a.fast_vlo = ord ? static_cast<float>(0x1p-90 / static_cast<double>(a.rest_b2k)) : 0.0f;
@@ -1653,8 +1691,8 @@ int skr_cold_pass_census(uint64_t* h_counts3, int reset) {
     return SKR_OK;
 }
 
-int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
-                        int64_t step_t0, int k, const int32_t* d_tag, int32_t hot_value, void* stream) {
+static int adam_block_cold_impl(float* d_p, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               int64_t step_t0, int k, const int32_t* d_tag, int32_t hot_value, bool tf, void* stream) {
     SKR_REQUIRE(d_p && d_m && d_v && d_tag, "skr_adam_block_cold: NULL argument");
     SKR_REQUIRE(n >= 0 && step_t0 >= 0 && k >= 1 && k <= AB_KMAX, "skr_adam_block_cold: need 1 <= k <= %d", AB_KMAX);
     SKR_REQUIRE(((reinterpret_cast<uintptr_t>(d_p) | reinterpret_cast<uintptr_t>(d_m) | reinterpret_cast<uintptr_t>(d_v)) & 15) == 0,
@@ -1666,7 +1704,7 @@ int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr,
     a.one_minus_b2 = static_cast<float>(1.0 - static_cast<double>(beta2));
     a.eps = eps;
     a.k = k;
-    for (int s = 0; s < k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s]);
+    adam_block_scalars(a, lr, beta1, beta2, step_t0, k, tf);
     static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // workgroups per CU.  The pass is off the critical path (it runs beside the k-step block's small launches): 4 leaves them more of the chip than 8 and is still done in time (tools/cold_bpc_sweep.sh, 960 timed steps: 24.9 / 31.3 / 30.3 / 28.1 M interactions/s at 2 / 3 / 4 / 8; at 200 timed steps 3 and 4 are level, and 3 makes the pass itself 15 % slower)
     // SKR_COLD_REST=0 keeps every cold block on the full update (the float4 kernel): the A/B switch of tools/microbench.py
     static const bool rest = [] { const char* e = getenv("SKR_COLD_REST"); return !(e && atoi(e) == 0); }();
@@ -1689,9 +1727,18 @@ int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr,
     return SKR_OK;
 }
 
-int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
-                       float eps, int64_t step_t0, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
-                       int stride_floats, int32_t* d_claim, void* stream) {
+int skr_adam_block_cold(float* d_p, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        int64_t step_t0, int k, const int32_t* d_tag, int32_t hot_value, void* stream) {
+    return adam_block_cold_impl(d_p, d_m, d_v, n, lr, beta1, beta2, eps, step_t0, k, d_tag, hot_value, false, stream);
+}
+int skr_adam_block_cold_tf(float* d_p, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                           int64_t step_t0, int k, const int32_t* d_tag, int32_t hot_value, void* stream) {
+    return adam_block_cold_impl(d_p, d_m, d_v, n, lr, beta1, beta2, eps, step_t0, k, d_tag, hot_value, true, stream);
+}
+
+static int adam_block_hot_impl(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, int64_t step_t0, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
+                               int stride_floats, int32_t* d_claim, bool tf, void* stream) {
     SKR_REQUIRE(d_p && d_g && d_m && d_v && d_ids && d_claim, "skr_adam_block_hot: NULL argument");
     SKR_REQUIRE(n >= 0 && step_t0 >= 0 && step_t > step_t0 && step_t - step_t0 <= AB_KMAX && step_t < INT32_MAX,
                 "skr_adam_block_hot: need step_t0 < step_t <= step_t0 + %d", AB_KMAX);
@@ -1703,13 +1750,25 @@ int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n
     a.one_minus_b2 = static_cast<float>(1.0 - static_cast<double>(beta2));
     a.eps = eps;
     a.k = static_cast<int>(step_t - step_t0);
-    for (int s = 0; s < a.k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s]);
+    adam_block_scalars(a, lr, beta1, beta2, step_t0, a.k, tf);
     adam_block_thresholds(a, lr, beta1, beta2, eps, a.k);   // for the zero-gradient steps a block may be behind
     hipLaunchKernelGGL(adam_hot_kernel, dim3(static_cast<unsigned>((n_ids + 3) / 4)), dim3(256), 0, skr::as_stream(stream), d_p,
                        d_g, d_m, d_v, n, a, static_cast<int32_t>(step_t0), static_cast<int32_t>(step_t), d_ids, n_ids,
                        offset_floats, stride_floats, d_claim);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
+}
+int skr_adam_block_hot(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, int64_t step_t0, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
+                       int stride_floats, int32_t* d_claim, void* stream) {
+    return adam_block_hot_impl(d_p, d_g, d_m, d_v, n, lr, beta1, beta2, eps, step_t0, step_t, d_ids, n_ids, offset_floats, stride_floats,
+                               d_claim, false, stream);
+}
+int skr_adam_block_hot_tf(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, int64_t step_t0, int64_t step_t, const int32_t* d_ids, int64_t n_ids, int64_t offset_floats,
+                          int stride_floats, int32_t* d_claim, void* stream) {
+    return adam_block_hot_impl(d_p, d_g, d_m, d_v, n, lr, beta1, beta2, eps, step_t0, step_t, d_ids, n_ids, offset_floats, stride_floats,
+                               d_claim, true, stream);
 }
 
 // scalars and thresholds of a k-step block, kept between the k + 1 launches of the block (2k pow() calls otherwise)
@@ -1728,7 +1787,7 @@ static const AdamBlockArgs& fused_block_args(float lr, float beta1, float beta2,
         a.one_minus_b2 = static_cast<float>(1.0 - static_cast<double>(beta2));
         a.eps = eps;
         a.k = k;
-        for (int s = 0; s < k; ++s) adam_scalars(lr, beta1, beta2, step_t0 + 1 + s, &a.neg_step_size[s], &a.bc2_sqrt[s]);
+        adam_block_scalars(a, lr, beta1, beta2, step_t0, k, false);
         adam_block_thresholds(a, lr, beta1, beta2, eps, k);
         key = Key{lr, beta1, beta2, eps, step_t0, k};
     }

@@ -38,6 +38,9 @@ SIGNATURES = {
     "skr_adam_block_mark": (i32, [vp, i64, i64, i32, vp, i32, vp, i64, vp]),
     "skr_adam_block_cold": (i32, [vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, i32, vp]),
     "skr_adam_block_hot": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i64, vp, i64, i64, i32, vp, vp]),
+    "skr_adam_step_tf": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, vp]),
+    "skr_adam_block_cold_tf": (i32, [vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, i32, vp]),
+    "skr_adam_block_hot_tf": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i64, vp, i64, i64, i32, vp, vp]),
     "skr_bpr_fused_plan": (i32, [vp, vp, vp, i32, i32, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]),
     "skr_bpr_fused_step": (i32, [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i32, i64, i64, i64, f32, f32, f32, f32, i64, i32, i32,
                                  f32, vp, vp]),

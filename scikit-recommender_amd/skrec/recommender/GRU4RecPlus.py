@@ -21,6 +21,8 @@ What differs, and why:
 """
 from typing import Dict, List
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -107,7 +109,9 @@ class SessionGRU(object):
             v = self.flat[o:o + s.numel()].view(s.shape)
             v.copy_(s)
             views.append(v)
+        self._offs = offs
         self.opt = DenseAdam(self.flat, lr=lr, track_touch=True, tf_epsilon=True)
+        self._blk_left = 0
         self.opt.touch[offs[3] // 64:] = 2                # the recurrent weights get a gradient every step
         gviews = [self.opt.grad[o:o + s.numel()].view(s.shape) for s, o in zip(sections, offs)]
         self.E_in, self.E_out, self.b_out = views[:3]
@@ -126,6 +130,47 @@ class SessionGRU(object):
 
     def zero_states(self, b):
         return [torch.zeros((b, h), dtype=torch.float32, device=self.device) for h in self.hids]
+
+    # ---- the dense Adam blocked in time (csrc/train.hip K2b, TF arithmetic): the inputs and targets of the next k steps are
+    # known (the session-parallel schedule is host logic on the data, the negatives' uniforms can be drawn ahead in the
+    # reference's order), so the 64-float blocks of the flat buffer that none of the k steps names get their k
+    # zero-gradient updates in ONE pass on a side stream and only the named rows -- at most b + (b + n_sample) item rows,
+    # their bias words and the GRU kernels -- are stepped batch by batch.  Every parameter receives every update in
+    # skr_adam_step_tf's arithmetic: bit-identical to a dense launch per step (tests/test_gpu_gru.py).
+    def block_ids(self, xs, ys):
+        """int32 [k, per]: the 64-float blocks of the flat buffer that step s of the block touches -- E_in rows of xs[s],
+        E_out rows and b_out words of ys[s], every block of the GRU kernels"""
+        k = xs.shape[0]
+        dev = self.device
+        o_in, o_out, o_b, o_cells = (o // 64 for o in self._offs[:4])
+        hn = self.hids[-1]
+
+        def rows(o, idx, d):
+            first = o + ((idx.long() * d) >> 6)
+            c = max(1, d // 64)
+            return (first.unsqueeze(2) + torch.arange(c, device=dev)).reshape(k, -1)
+        cells = torch.arange(o_cells, (self.flat.numel() + 63) // 64, device=dev).expand(k, -1)
+        return torch.cat([rows(o_in, xs, self.in_dim), rows(o_out, ys, hn), o_b + (ys.long() >> 6), cells], dim=1).int().contiguous()
+
+    def begin_block(self, xs, ys):
+        """xs int32 [k, b], ys int32 [k, b + n_sample] (device): the next k calls of train_step will be given exactly
+        these inputs / targets, in this order"""
+        assert self._blk_left == 0 and 1 <= xs.shape[0] <= 64
+        ids = self.block_ids(xs, ys)
+        self.opt.begin_block(ids.reshape(-1), xs.shape[0], per_step=ids.shape[1])
+        self._blk_left = xs.shape[0]
+
+    def end_blocks(self):
+        """join the cold passes' stream (before anything else reads the parameters)"""
+        assert self._blk_left == 0
+        self.opt.end_blocks()
+
+    def _optimizer_step(self):
+        if self._blk_left > 0:
+            self.opt.hot_step()
+            self._blk_left -= 1
+        else:
+            self.opt.step()
 
     def forward(self, x_index, states, active=None, save=False, tag="f"):
         """one step of the stack: -> new states (fresh buffers per `tag`), optionally keeping r, u, c"""
@@ -159,12 +204,14 @@ class SessionGRU(object):
         dlog, dout = self._buf("dlogits", (b, n_y)), self._buf("dout", (b, hn))
         self.loss.zero_()
         g = self.opt
+        # inside a block the hot step knows the rows by the block's id list: no touch bytes
+        p_touch, p_base = (None, None) if self._blk_left > 0 else (_hip.ptr(g.touch), _hip.ptr(g.grad))
         _hip.check(L.skr_session_loss(_hip.ptr(out), b, hn, _hip.ptr(self.E_out), _hip.ptr(self.b_out), _hip.ptr(y_index),
                                       n_y, self.final_act, self.loss_kind, self.bpr_reg, _hip.ptr(dlog), _hip.ptr(dout),
                                       _hip.ptr(self.loss), st))
         _hip.check(L.skr_session_out_grads(_hip.ptr(dlog), _hip.ptr(out), b, hn, _hip.ptr(y_index), n_y,
                                            _hip.ptr(self.E_out), _hip.ptr(self.b_out), self.reg, _hip.ptr(self.gE_out),
-                                           _hip.ptr(self.gb_out), _hip.ptr(g.touch), _hip.ptr(g.grad), st))
+                                           _hip.ptr(self.gb_out), p_touch, p_base, st))
         dh = dout
         for l in range(len(self.cells) - 1, -1, -1):
             (Wg, bg, Wc, bc), (gWg, gbg, gWc, gbc) = self.cells[l], self.gcells[l]
@@ -177,8 +224,8 @@ class SessionGRU(object):
                                           _hip.ptr(work), st))
             dh = dx
         _hip.check(L.skr_scatter_add_rows(_hip.ptr(dh), _hip.ptr(x_index), b, self.in_dim, _hip.ptr(self.E_in), self.reg,
-                                          _hip.ptr(self.gE_in), _hip.ptr(g.touch), _hip.ptr(g.grad), st))
-        g.step()
+                                          _hip.ptr(self.gE_in), p_touch, p_base, st))
+        self._optimizer_step()
         return new_states
 
     def user_embeddings(self, d_rowptr, d_items_by_time, max_len):
@@ -277,7 +324,7 @@ class ShardedSessionGRU(SessionGRU):
         _hip.check(L.skr_scatter_rows(_hip.ptr(buf[o1:o2]), _hip.ptr(x_index), b, self.in_dim, _hip.ptr(self.gE_in), st))
         g.grad[self._cells_lo:].copy_(buf[o2:o3])
         self.loss.copy_(buf[o3:])
-        g.step()
+        self._optimizer_step()
         return new_states
 
 
@@ -339,32 +386,23 @@ class GRU4RecPlus(AbstractRecommender):
                                              _hip.ptr(out), _hip.stream()))
         return out
 
-    def train_epoch(self):
-        """the session-parallel loop of GRU4RecPlus.fit (:210-247), control flow on the host as there"""
-        cfg, net, dev = self.config, self.net, self.device
-        offset_idx, d_items = self.offset_idx, self._d_items
-        b = cfg.batch_size
-        lo, hi = net.slots(b) if self.dist.active else (0, b)     # this rank's share of the b parallel sessions
-        state = net.zero_states(hi - lo)
+    def _schedule(self):
+        """The session-parallel schedule of one epoch (GRU4RecPlus.fit, :208-247) as a generator: per training step the b
+        positions in the time-ordered pair list that the step reads (inputs at pos, targets at pos + 1) and the slots whose
+        state is zeroed before it.  Host logic on the data only -- it can run any number of steps ahead of the device; the
+        epoch's permutation is drawn from numpy's global generator when the first step is asked for, as in the reference."""
+        offset_idx, b = self.offset_idx, self.config.batch_size
         user_idx = np.random.permutation(len(offset_idx) - 1)
         iters = np.arange(b, dtype=np.int32)
         maxiter = iters.max()
         start = offset_idx[user_idx[iters]].astype(np.int64)
         end = offset_idx[user_idx[iters] + 1].astype(np.int64)
-        losses = []
-        finished = False
+        finished, reset = False, None
         while not finished:
             min_len = int((end - start).min())
-            d_start = torch.from_numpy(start).to(dev)
-            out_idx = d_items[d_start]
             for i in range(min_len - 1):
-                in_idx = out_idx
-                out_idx = d_items[d_start + (i + 1)]
-                out_items = out_idx
-                if cfg.n_sample:
-                    out_items = torch.cat([out_idx, self._sample_neg_items(cfg.n_sample)])
-                state = net.train_step(in_idx.contiguous(), out_items.contiguous(), state)
-                losses.append(net.loss.clone())
+                yield start + i, reset
+                reset = None
             start = start + min_len - 1
             mask = np.arange(len(iters))[(end - start) <= 1]
             for idx in mask:
@@ -375,10 +413,48 @@ class GRU4RecPlus(AbstractRecommender):
                 iters[idx] = maxiter
                 start[idx] = offset_idx[user_idx[maxiter]]
                 end[idx] = offset_idx[user_idx[maxiter] + 1]
-            mask = mask[(mask >= lo) & (mask < hi)] - lo           # the finished sessions among this rank's slots
             if len(mask):
-                d_mask = torch.from_numpy(mask).to(dev)
-                state = [s.index_fill(0, d_mask, 0.0) for s in state]
+                reset = mask if reset is None else np.union1d(reset, mask)
+
+    def train_epoch(self):
+        """The session-parallel loop of GRU4RecPlus.fit (:210-247).  The schedule is host logic (``_schedule``), so the steps
+        are prepared SKR_ADAM_BLOCK (default 32) at a time: one upload of the positions, one gather of the inputs / targets,
+        the negatives' uniforms drawn in the reference's order (np.random.rand(n_sample) per step == one draw of k * n_sample)
+        and searched on the device, and the dense Adam blocked over those k steps (SessionGRU.begin_block)."""
+        import itertools
+        cfg, net, dev = self.config, self.net, self.device
+        d_items = self._d_items
+        b = cfg.batch_size
+        lo, hi = net.slots(b) if self.dist.active else (0, b)     # this rank's share of the b parallel sessions
+        state = net.zero_states(hi - lo)
+        kblk = max(1, min(64, int(os.environ.get("SKR_ADAM_BLOCK", "32"))))
+        sched = self._schedule()
+        losses = []
+        while True:
+            chunk = list(itertools.islice(sched, kblk))
+            if not chunk:
+                break
+            k = len(chunk)
+            pos = torch.from_numpy(np.stack([c[0] for c in chunk])).to(dev)            # [k, b]
+            xs, ys = d_items[pos], d_items[pos + 1]
+            if cfg.n_sample:
+                ys = torch.cat([ys, self._sample_neg_items(k * cfg.n_sample).view(k, cfg.n_sample)], dim=1)
+            xs, ys = xs.contiguous(), ys.contiguous()
+            resets = None
+            if any(c[1] is not None for c in chunk):
+                r = np.zeros((k, b), dtype=bool)
+                for s_, c in enumerate(chunk):
+                    if c[1] is not None:
+                        r[s_, c[1]] = True
+                resets = torch.from_numpy(r[:, lo:hi].copy()).to(dev)
+            if kblk > 1:
+                net.begin_block(xs, ys)
+            for s_ in range(k):
+                if chunk[s_][1] is not None:
+                    state = [st_.masked_fill(resets[s_].unsqueeze(1), 0.0) for st_ in state]
+                state = net.train_step(xs[s_], ys[s_], state)
+                losses.append(net.loss.clone())
+        net.end_blocks()
         self.step_losses = torch.cat(losses).cpu().numpy() if losses else np.zeros(0, np.float32)
 
     def fit(self):
@@ -396,10 +472,32 @@ class GRU4RecPlus(AbstractRecommender):
         self.logger.info("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
         return early_stopping.best_result
 
-    def _get_user_embeddings(self):
-        return self.net.user_embeddings(self._d_rowptr, self._d_hist, self._max_len)
+    def _get_user_embeddings(self, mine_only=False):
+        """top-layer state after each user's whole history.  ``mine_only`` (one process per GPU): the sweep is SHARDED like the
+        evaluation that reads it -- this rank advances the users u % world == rank only; the other rows stay zero"""
+        if not (mine_only and self.dist.active):
+            return self.net.user_embeddings(self._d_rowptr, self._d_hist, self._max_len)
+        if getattr(self, "_mine", None) is None:
+            mine = torch.arange(self.dist.rank, self.users_num, self.dist.world, device=self.device)
+            lens = (self._d_rowptr[1:] - self._d_rowptr[:-1])[mine]
+            rp = torch.zeros(mine.numel() + 1, dtype=torch.int64, device=self.device)
+            rp[1:] = torch.cumsum(lens, 0)
+            # the owned users' histories, packed: entry e of local row r is entry (e - rp[r]) of the user's global row
+            row_of = torch.repeat_interleave(torch.arange(mine.numel(), device=self.device), lens)
+            src = self._d_rowptr[:-1][mine][row_of] + (torch.arange(int(rp[-1]), device=self.device) - rp[row_of])
+            hist = self._d_hist[src].contiguous() if src.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._mine = (mine, rp, hist, int(lens.max()) if lens.numel() else 0)
+        mine, rp, hist, max_len = self._mine
+        full = torch.zeros((self.users_num, self.config.layers[-1]), dtype=torch.float32, device=self.device)
+        full[mine] = self.net.user_embeddings(rp, hist, max_len)
+        return full
 
     def evaluate(self, test_users=None):
+        if self.dist.active:
+            # every rank sweeps and ranks its own share of the users; only the fp64 metric sums are all-reduced
+            from ..parallel import sharded_evaluate
+            self.cur_user_embeddings = self._get_user_embeddings(mine_only=True)
+            return sharded_evaluate(self.dist, self.evaluator, self, test_users, self.device)
         self.cur_user_embeddings = self._get_user_embeddings().clone()
         return self.evaluator.evaluate(self, test_users)
 

@@ -73,7 +73,7 @@ class DenseAdam(object):
         self.touch = torch.zeros((flat.numel() + 63) // 64, dtype=torch.uint8, device=flat.device) if track_touch else None
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         # tf.train.AdamOptimizer puts epsilon outside the bias correction: p -= lr_t * m / (sqrt(v) + eps) with
-        # lr_t = lr * sqrt(1-b2^t) / (1-b1^t), i.e. torch's form with eps / sqrt(1-b2^t)   (GRU4RecPlus.py:192)
+        # lr_t = lr * sqrt(1-b2^t) / (1-b1^t)   (GRU4RecPlus.py:192): the skr_adam_*_tf entry points
         self.tf_epsilon = bool(tf_epsilon)
         self.t = 0
 
@@ -107,7 +107,7 @@ class DenseAdam(object):
         self._ev_marked.record(cur)
         self._side.wait_event(self._ev_marked)
         self.launch_cold(self._blk_tag, self._blk_serial, int(k))
-        self._hot = (L.skr_adam_block_hot, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+        self._hot = (L.skr_adam_block_hot_tf if self.tf_epsilon else L.skr_adam_block_hot, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                      self.flat.numel(), block_ids.data_ptr(), block_ids.numel(), self._blk_claim.data_ptr(), st,
                      self.t, int(k), None if per_step is None else int(per_step))
 
@@ -137,9 +137,10 @@ class DenseAdam(object):
         if timing is not None:
             e0, e1 = pool.pop() if pool is not None else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             e0.record(self._side)
-        _hip.check(_hip.lib().skr_adam_block_cold(_hip.ptr(self.flat), _hip.ptr(self.m), _hip.ptr(self.v), self.flat.numel(), self.lr,
-                                                  self.betas[0], self.betas[1], self.eps, self.t, int(k), _hip.ptr(tag),
-                                                  int(serial), self._side.cuda_stream))
+        L = _hip.lib()
+        _hip.check((L.skr_adam_block_cold_tf if self.tf_epsilon else L.skr_adam_block_cold)(
+            _hip.ptr(self.flat), _hip.ptr(self.m), _hip.ptr(self.v), self.flat.numel(), self.lr,
+            self.betas[0], self.betas[1], self.eps, self.t, int(k), _hip.ptr(tag), int(serial), self._side.cuda_stream))
         if timing is not None:
             e1.record(self._side)
             timing.append((e0, e1, int(k)))
@@ -172,7 +173,7 @@ class DenseAdam(object):
     def step(self):
         from .. import _hip
         self.t += 1
-        eps = self.eps / (1.0 - self.betas[1] ** self.t) ** 0.5 if self.tf_epsilon else self.eps
-        _hip.check(_hip.lib().skr_adam_step(_hip.ptr(self.flat), _hip.ptr(self.grad), _hip.ptr(self.m), _hip.ptr(self.v),
-                                            self.flat.numel(), self.lr, self.betas[0], self.betas[1], eps, self.t, 1,
-                                            _hip.ptr(self.touch), _hip.stream()))
+        L = _hip.lib()
+        _hip.check((L.skr_adam_step_tf if self.tf_epsilon else L.skr_adam_step)(
+            _hip.ptr(self.flat), _hip.ptr(self.grad), _hip.ptr(self.m), _hip.ptr(self.v), self.flat.numel(), self.lr, self.betas[0],
+            self.betas[1], self.eps, self.t, 1, _hip.ptr(self.touch), _hip.stream()))

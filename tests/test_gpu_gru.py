@@ -201,6 +201,54 @@ def test_training_trajectory_matches_oracle(layers, loss, fact, act, reg):
             _close(a.cpu().numpy(), w.detach().numpy(), 2e-4, 2e-6)
 
 
+@pytest.mark.parametrize("layers,in_dim", [([128], 128), ([64, 32], 32)])
+def test_blocked_adam_steps_are_bit_identical_to_dense_steps(layers, in_dim):
+    """SessionGRU.begin_block: the TF-arithmetic dense Adam blocked over k steps (cold rows in one pass on a side stream,
+    the step's rows by the hot launch) == one dense skr_adam_step_tf per step, BIT FOR BIT -- every parameter, both
+    moments, the recurrent states, the losses; blocks of 5, 32 and 3 steps with state resets in between; item rows that
+    repeat across the steps of a block and rows shared by input and target lists"""
+    from skrec.recommender.GRU4RecPlus import SessionGRU
+    rng = np.random.default_rng(77)
+    n_items, b, n_s = 3000, 16, 40
+    E_in = rng.normal(0, 0.1, (n_items, in_dim)).astype(np.float32)
+    E_out = rng.normal(0, 0.1, (n_items, layers[-1])).astype(np.float32)
+    cells, i_d = [], in_dim
+    for h in layers:
+        cells.append(_cell(rng, i_d, h))
+        i_d = h
+    args = (E_in, cells, E_out, np.zeros(n_items, np.float32), "tanh", "linear", "bpr_max", 1.0, 1e-4, 1e-2)
+    dense, blocked = SessionGRU(*args), SessionGRU(*args)
+    steps = 40
+    # a small id range: rows repeat ACROSS steps; distinct within a step, so that no float atomic meets another and the
+    # gradients are deterministic (the comparison isolates the optimiser)
+    X = np.stack([rng.permutation(200)[:b] for _ in range(steps)]).astype(np.int32)
+    Y = np.stack([np.concatenate([rng.permutation(200)[:b], 200 + rng.permutation(n_items - 200)[:n_s]]) for _ in range(steps)]).astype(np.int32)
+    dX, dY = to_dev(X), to_dev(Y)
+    sd, sb = dense.zero_states(b), blocked.zero_states(b)
+    ld, lb = [], []
+    for s_ in range(steps):
+        if s_ == 7:
+            sd = [t.index_fill(0, torch.tensor([2, 9], device="cuda"), 0.0) for t in sd]
+        sd = dense.train_step(dX[s_], dY[s_], sd)
+        ld.append(float(dense.loss.cpu()))
+    s_ = 0
+    for k in (5, 32, 3):
+        blocked.begin_block(dX[s_:s_ + k], dY[s_:s_ + k])
+        for _ in range(k):
+            if s_ == 7:
+                sb = [t.index_fill(0, torch.tensor([2, 9], device="cuda"), 0.0) for t in sb]
+            sb = blocked.train_step(dX[s_], dY[s_], sb)
+            lb.append(float(blocked.loss.cpu()))
+            s_ += 1
+    blocked.end_blocks()
+    torch.cuda.synchronize()
+    assert blocked.opt.t == dense.opt.t == steps
+    np.testing.assert_allclose(lb, ld, rtol=2e-6)        # (the step's loss is a sum of float atomics over the sessions)
+    assert torch.equal(blocked.flat, dense.flat) and torch.equal(blocked.opt.m, dense.opt.m) and torch.equal(blocked.opt.v, dense.opt.v)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(sd, sb))
+    assert float(blocked.opt.grad.abs().max()) == 0.0
+
+
 def test_user_embeddings_sweep_matches_oracle():
     from skrec.recommender.GRU4RecPlus import SessionGRU
     rng = np.random.default_rng(11)
@@ -252,6 +300,73 @@ def test_gru4recplus_fit_through_the_api(tiny_dir, monkeypatch, tmp_path):
     ue = m.cur_user_embeddings.cpu().numpy()
     want = ue[[0, 5, 9]] @ m.net.E_out.cpu().numpy().T + m.net.b_out.cpu().numpy()
     np.testing.assert_allclose(p, want, rtol=1e-4, atol=1e-5)
+
+
+def _gru_fit(tiny_dir, workdir, epochs=2):
+    import random
+    from skrec import RunConfig
+    from skrec.recommender.GRU4RecPlus import GRU4RecPlus
+    os.chdir(workdir)
+    np.random.seed(2021); random.seed(2021); torch.manual_seed(2021)
+    rc = RunConfig(recommender="GRU4RecPlus", data_dir=tiny_dir, file_column="UIRT", sep="\t",
+                   metric=("Precision", "Recall", "MAP", "NDCG", "MRR"), top_k=(5, 10, 20), test_batch_size=16, seed=2021)
+    m = GRU4RecPlus(rc, dict(lr=0.01, layers=[64], batch_size=16, n_sample=64, epochs=epochs, early_stop=10))
+    losses, reports = [], []
+    te, ev = m.train_epoch, m.evaluate
+
+    def train_epoch():
+        te()
+        losses.append(m.step_losses.copy())
+
+    def evaluate(test_users=None):
+        r = ev(test_users)
+        reports.append(np.array(list(r.values()), np.float32))
+        return r
+    m.train_epoch, m.evaluate = train_epoch, evaluate
+    m.fit()
+    return m, np.concatenate(losses), np.stack(reports)
+
+
+def test_fit_with_the_blocked_optimiser_equals_a_dense_launch_per_step(tiny_dir, tmp_path, monkeypatch):
+    """GRU4RecPlus.fit(): steps prepared 32 at a time with the TF-Adam blocked over them (the default) == SKR_ADAM_BLOCK=1
+    (one step at a time, one dense launch per step): the same sessions in the same order with the same negatives (numpy's
+    stream is consumed identically), per-step losses, reports"""
+    monkeypatch.setenv("SKR_ADAM_BLOCK", "1")
+    m1, l1, r1 = _gru_fit(tiny_dir, str(tmp_path))
+    monkeypatch.setenv("SKR_ADAM_BLOCK", "32")
+    m2, l2, r2 = _gru_fit(tiny_dir, str(tmp_path))
+    assert len(l1) == len(l2) and len(l1) > 40
+    # (float atomics inside a step -- an item drawn twice -- may add in another order from run to run)
+    np.testing.assert_allclose(l2, l1, rtol=2e-5)
+    np.testing.assert_allclose(r2, r1, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(m2.net.flat.cpu().numpy(), m1.net.flat.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def _gru_api_worker(rank, world, port, tiny_dir, workdir, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      SKR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    m, losses, reports = _gru_fit(tiny_dir, workdir)
+    ret[rank] = dict(losses=losses, reports=reports, flat=m.net.flat.cpu().numpy())
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gru4recplus_fit_on_two_ranks(tiny_dir, tmp_path):
+    """`torchrun ... run_skrec.py --recommender GRU4RecPlus` on two ranks: the parallel sessions split over the ranks, the
+    optimiser blocked on every rank alike, the inference sweep and the evaluation sharded (users u % 2; fp64 metric sums
+    all-reduced) == the single-process fit; replicas bit-identical"""
+    import torch.multiprocessing as mp
+    from test_gpu_dist import _free_port
+    _, l1, r1 = _gru_fit(tiny_dir, str(tmp_path))
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_gru_api_worker, args=(2, _free_port(), tiny_dir, str(tmp_path), ret), nprocs=2, join=True)
+        res = {k: ret[k] for k in range(2)}
+    for r in res.values():
+        np.testing.assert_allclose(r["losses"], l1, rtol=5e-5)
+        np.testing.assert_allclose(r["reports"], r1, rtol=1e-4, atol=2e-4)
+    assert np.array_equal(res[0]["flat"], res[1]["flat"]) and np.array_equal(res[0]["reports"], res[1]["reports"])
 
 
 def test_pop_sampler_is_numpys_searchsorted():

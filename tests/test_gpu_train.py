@@ -391,9 +391,14 @@ def test_gather_axpy_scale():
 
 
 @pytest.mark.parametrize("lazy", [True, False])
-@pytest.mark.parametrize("k,n_steps,t0", [(8, 37, 0), (1, 5, 0), (16, 16, 0), (3, 10, 0), (8, 20, 16595), (8, 16, 40000),
-                                          (32, 70, 0), (32, 64, 16580), (32, 32, 300), (64, 130, 0), (64, 64, 16570)])
-def test_blocked_adam_is_bit_identical(k, n_steps, t0, lazy):
+@pytest.mark.parametrize("k,n_steps,t0,tf", [(8, 37, 0, False), (1, 5, 0, False), (16, 16, 0, False), (3, 10, 0, False), (8, 20, 16595, False),
+                                             (8, 16, 40000, False), (32, 70, 0, False), (32, 64, 16580, False), (32, 32, 300, False),
+                                             (64, 130, 0, False), (64, 64, 16570, False),
+                                             # tf.train.AdamOptimizer's arithmetic (skr_adam_*_tf): |lr_t| falls until step ~20 and
+                                             # rises afterwards -- blocks on both sides of the minimum and across it
+                                             (8, 37, 0, True), (32, 70, 0, True), (32, 64, 10, True), (64, 130, 0, True),
+                                             (32, 64, 16580, True), (16, 48, 700, True)])
+def test_blocked_adam_is_bit_identical(k, n_steps, t0, tf, lazy):
     """temporally blocked dense Adam (cold blocks: k zero-gradient updates in one pass; hot blocks: the ordinary
     update every step -- or, `lazy`, when a batch is about to read them / has written their gradient, catching up
     on the zero-gradient steps in between) == skr_adam_step after every batch, BIT FOR BIT: parameters and both moments"""
@@ -426,14 +431,14 @@ def test_blocked_adam_is_bit_identical(k, n_steps, t0, lazy):
     # classic: one dense launch per step
     # t0: optimiser steps already taken (around 16 600 the second bias correction becomes exactly 1.0f and both forms
     # drop its division; the block starting at 16 595 straddles that point)
-    a = DenseAdam(init.clone(), lr=1e-2, track_touch=True)
+    a = DenseAdam(init.clone(), lr=1e-2, track_touch=True, tf_epsilon=tf)
     a.t = t0
     la = torch.zeros(2, device="cuda")
     for s in range(n_steps):
         bpr(a, s, la, a.touch)
         a.step()
     # blocked
-    c = DenseAdam(init.clone(), lr=1e-2)
+    c = DenseAdam(init.clone(), lr=1e-2, tf_epsilon=tf)
     c.t = t0
     lc = torch.zeros(2, device="cuda")
     for s0 in range(0, n_steps, k):
