@@ -148,6 +148,9 @@ int skr_sample_epoch_fast(uint64_t seed, uint64_t epoch, int64_t slot_offset, in
  *   d_sums      double[n_metric*top_k]           += column sums over users (may be NULL)
  * Requires 1 <= top_k <= min(n_items, SKR_MAX_TOPK). */
 #define SKR_MAX_TOPK 128
+/* skr_eval_scores and skr_rank_metrics (the score-matrix path) rank deeper: the reference's top_k is a free integer
+ * (run_config.py:16; its default (10, ..., 100) fits the fused kernel too) */
+#define SKR_MAX_TOPK_SCORES 512
 int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
                     const int64_t* d_test_rowptr, const int32_t* d_test_items,
                     const int* metric, int n_metric, int top_k,
@@ -241,6 +244,15 @@ int skr_bpr_step_spread(const float* d_P, const float* d_Q, const float* d_bias,
                  float loss_scale, float reg, float reg_scale,
                  float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ,
                  float* d_loss64, uint8_t* d_touch, const float* d_touch_base, void* stream);
+/* The general form: rows of `dim` floats (64, 128, 192 or 256; an embedding width that is not a multiple of 64 -- n_dim /
+ * embed_size are free integers in the reference, BPRMF.py:27,51, LightGCN.py:34 -- is zero-padded by the caller: padded
+ * columns have zero gradients and stay zero under Adam), loss_slots 1 (d_loss[2]) or SKR_LOSS_SLOTS (d_loss[2 * slots]),
+ * grad_scale as in skr_bpr_step_sharded. */
+int skr_bpr_step_dim(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
+                     const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n, int dim, float loss_scale,
+                     float reg, float reg_scale, float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ,
+                     float* d_loss, int loss_slots, uint8_t* d_touch, const float* d_touch_base, float grad_scale,
+                     void* stream);
 
 /* torch.optim.Adam.step for one dense parameter (single-tensor path): for every element
  *   m = m + (g-m)*(1-b1);  v = v*b2 + (1-b2)*g*g;
@@ -260,6 +272,12 @@ int skr_adam_step(float* d_p, float* d_g, float* d_m, float* d_v, int64_t n,
 int skr_csr_spmm(int n_rows, const int64_t* d_rowptr, const int32_t* d_col, const float* d_val,
                  const float* d_X, int dim, int64_t nnz, const float* d_addend, float* d_Y,
                  float* d_accum, float accum_scale, void* stream);
+
+/* The same with a row stride: X, addend, Y and accum are 64-column slices of [*, ld] tables (ld >= 64 floats) -- a wider
+ * embedding is multiplied slice by slice (pointers advanced by 64 c), the product being separable in the columns. */
+int skr_csr_spmm_strided(int n_rows, const int64_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                         const float* d_X, int dim, int ld, int64_t nnz, const float* d_addend, float* d_Y,
+                         float* d_accum, float accum_scale, void* stream);
 
 /* The same product through a per-matrix PLAN (csrc/spmm.hip): rows shorter than `long_rows_from` entries are gathered
  * one wavefront per row with 16 bytes per lane; longer rows are cut into tasks of <= 256 entries inside one block of
@@ -310,7 +328,10 @@ typedef struct skr_spmm_epilogue {
     float* accum;
     const float* accum_base;
     float accum_scale;
-    float reserved_;
+    int32_t ld;                   /* row stride, in floats, of X and of every dense operand named here; 0 = 64.  With ld = 64 C
+                                     and the pointers advanced by 64 c the call multiplies the c-th 64-column slice of [n, 64 C]
+                                     tables (embedding widths beyond 64: the product is separable in the columns);
+                                     SKR_EPI_PLAIN only */
     const float* E;
     float* w;
     float* Z;

@@ -11,12 +11,9 @@ struct MetricArgs {
     int ids[8];  // metric ids 1..5 (evaluator.py:57), at most 8 per call
 };
 
-// 1.0/log2(i+2) for i < SKR_MAX_TOPK, evaluated on the HOST with the same libm the reference's
-// C++ uses (metric.h:76,80), so that the device never depends on a device log2.
-struct InvLog2Table {
-    double v[SKR_MAX_TOPK];
-};
-const InvLog2Table& inv_log2_table();
+// 1.0/log2(i+2) for i < SKR_MAX_TOPK_SCORES, evaluated on the HOST with the same libm the reference's
+// C++ uses (metric.h:76,80), so that the device never depends on a device log2 (eval_select.hip keeps the table in HBM).
+const double* inv_log2_table_device();
 
 // One metric for one user; `rank` = arg-top-K list (any address space), truth sorted ascending.
 // Accumulators are `float`, the `+= 1.0/log2(i+2)` and `1.0/(i+1)` terms are double and rounded to

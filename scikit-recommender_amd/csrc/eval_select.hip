@@ -13,13 +13,21 @@
 #include <cmath>
 
 namespace skr {
-const InvLog2Table& inv_log2_table() {
-    static InvLog2Table t = [] {
-        InvLog2Table x;
-        for (int i = 0; i < SKR_MAX_TOPK; ++i) x.v[i] = 1.0 / std::log2(static_cast<double>(static_cast<unsigned>(i + 2)));
-        return x;
-    }();
-    return t;
+// 1 / log2(i + 2) for i < SKR_MAX_TOPK_SCORES, evaluated on the HOST with the libm the reference's metric.h uses, kept in a
+// device buffer per GPU (512 doubles are too many for a kernel argument)
+const double* inv_log2_table_device() {
+    static const double* tables[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!tables[dev]) {
+        double h[SKR_MAX_TOPK_SCORES];
+        for (int i = 0; i < SKR_MAX_TOPK_SCORES; ++i) h[i] = 1.0 / std::log2(static_cast<double>(static_cast<unsigned>(i + 2)));
+        double* d = nullptr;
+        if (hipMalloc(&d, sizeof(h)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        tables[dev] = d;
+    }
+    return tables[dev];
 }
 }  // namespace skr
 
@@ -37,13 +45,13 @@ struct RowOut {
 __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict__ scores, int n_items, int64_t ld,
                                                          const int64_t* __restrict__ test_rowptr,
                                                          const int32_t* __restrict__ test_items, skr::MetricArgs margs,
-                                                         skr::InvLog2Table tbl, int top_k, RowOut o) {
+                                                         const double* __restrict__ tbl, int top_k, RowOut o) {
     __shared__ uint64_t keys[TK_CAP];
     __shared__ int s_cnt;
     __shared__ int s_over;     // index of the last tile whose appends took s_cnt past the compaction mark
     __shared__ uint64_t s_thr;
-    __shared__ int s_rank[SKR_MAX_TOPK];
-    __shared__ double s_inv[SKR_MAX_TOPK];
+    __shared__ int s_rank[SKR_MAX_TOPK_SCORES];
+    __shared__ double s_inv[SKR_MAX_TOPK_SCORES];
     __shared__ int s_wsum[TK_T / 64];
     __shared__ int s_tie;
     const int tid = threadIdx.x;
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
         s_over = -2;
         s_thr = SKR_KEY_MIN;
     }
-    for (int i = tid; i < SKR_MAX_TOPK; i += TK_T) s_inv[i] = tbl.v[i];
+    for (int i = tid; i < SKR_MAX_TOPK_SCORES; i += TK_T) s_inv[i] = tbl[i];
     __syncthreads();
 
     auto compact = [&]() {  // all threads; keeps the best top_k keys at the front, updates threshold
@@ -121,9 +129,9 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
         // the key buffer is free from here on: its 16 KB hold the heap and the per-tile candidate list, so that
         // the tie path costs the common (tie-free) case no LDS and no occupancy
         int* s_hid = reinterpret_cast<int*>(keys);
-        float* s_hval = reinterpret_cast<float*>(s_hid + 2 * SKR_MAX_TOPK);
-        int* s_cand = s_hid + 4 * SKR_MAX_TOPK;
-        static_assert((4 * SKR_MAX_TOPK + TK_TILE) * 4 <= TK_CAP * 8, "tie-path scratch must fit the key buffer");
+        float* s_hval = reinterpret_cast<float*>(s_hid + 2 * SKR_MAX_TOPK_SCORES);
+        int* s_cand = s_hid + 4 * SKR_MAX_TOPK_SCORES;
+        static_assert((4 * SKR_MAX_TOPK_SCORES + TK_TILE) * 4 <= TK_CAP * 8, "tie-path scratch must fit the key buffer");
         skr::RefHeap h{s_hid, s_hval, sort_len};
         for (int i = tid; i < sort_len; i += TK_T) {
             s_hid[i] = i;
@@ -181,10 +189,10 @@ __global__ __launch_bounds__(TK_T) void topk_rows_kernel(const float* __restrict
 
 __global__ void rank_metrics_kernel(const int32_t* __restrict__ topk_ids, int B, int top_k,
                                     const int32_t* __restrict__ truth_rows, const int64_t* __restrict__ test_rowptr,
-                                    const int32_t* __restrict__ test_items, skr::MetricArgs margs, skr::InvLog2Table tbl,
+                                    const int32_t* __restrict__ test_items, skr::MetricArgs margs, const double* __restrict__ tbl,
                                     float* __restrict__ rows) {
-    __shared__ double s_inv[SKR_MAX_TOPK];
-    for (int i = threadIdx.x; i < SKR_MAX_TOPK; i += blockDim.x) s_inv[i] = tbl.v[i];
+    __shared__ double s_inv[SKR_MAX_TOPK_SCORES];
+    for (int i = threadIdx.x; i < SKR_MAX_TOPK_SCORES; i += blockDim.x) s_inv[i] = tbl[i];
     __syncthreads();
     const int64_t g = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (g >= static_cast<int64_t>(B) * margs.n_metric) return;
@@ -227,19 +235,19 @@ __global__ void mask_train_kernel(float* __restrict__ scores, int B, int n_items
 __global__ __launch_bounds__(256) void score_matrix_kernel(const float* __restrict__ user_table,
                                                            const int32_t* __restrict__ users, int B,
                                                            const float* __restrict__ item_table,
-                                                           const float* __restrict__ bias, int n_items,
+                                                           const float* __restrict__ bias, int n_items, int dim,
                                                            float* __restrict__ scores, int64_t ld) {
-    __shared__ float s_u[4][64];
+    __shared__ float s_u[4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.y * 4 + wv;
     const int item = blockIdx.x * 64 + lane;
-    if (b < B) s_u[wv][lane] = user_table[static_cast<int64_t>(users[b]) * 64 + lane];
+    if (b < B)
+        for (int c = lane; c < dim; c += 64) s_u[wv][c] = user_table[static_cast<int64_t>(users[b]) * dim + c];
     __syncthreads();
     if (b >= B || item >= n_items) return;
-    const float4* row = reinterpret_cast<const float4*>(item_table + static_cast<int64_t>(item) * 64);
+    const float4* row = reinterpret_cast<const float4*>(item_table + static_cast<int64_t>(item) * dim);
     float acc = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < dim / 4; ++q) {     // dim = 64: 16 trips, the same sums in the same order as before
         const float4 v = row[q];
         acc = fmaf(s_u[wv][4 * q + 0], v.x, acc);
         acc = fmaf(s_u[wv][4 * q + 1], v.y, acc);
@@ -280,7 +288,7 @@ int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
                     int32_t* d_topk_ids, double* d_sums, void* stream) {
     SKR_REQUIRE(d_scores, "skr_eval_scores: d_scores is NULL");
     SKR_REQUIRE(n_users >= 0 && n_items > 0 && ld >= n_items, "skr_eval_scores: bad shape");
-    SKR_REQUIRE(top_k >= 1 && top_k <= SKR_MAX_TOPK, "top_k %d outside [1, %d]", top_k, SKR_MAX_TOPK);
+    SKR_REQUIRE(top_k >= 1 && top_k <= SKR_MAX_TOPK_SCORES, "top_k %d outside [1, %d]", top_k, SKR_MAX_TOPK_SCORES);
     SKR_REQUIRE(top_k <= n_items, "top_k %d larger than the catalogue (%d items)", top_k, n_items);
     SKR_REQUIRE(!d_sums || d_rows, "skr_eval_scores: d_sums needs d_rows");
     skr::MetricArgs margs{};
@@ -292,8 +300,10 @@ int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
     if (n_users == 0) return SKR_OK;
     hipStream_t st = skr::as_stream(stream);
     RowOut o{d_rows, d_topk_ids};
+    const double* inv_tbl = skr::inv_log2_table_device();
+    SKR_REQUIRE(inv_tbl, "skr_eval_scores: no device memory for the 1 / log2 table");
     hipLaunchKernelGGL(topk_rows_kernel, dim3(n_users), dim3(TK_T), 0, st, d_scores, n_items, ld, d_test_rowptr,
-                       d_test_items, margs, skr::inv_log2_table(), top_k, o);
+                       d_test_items, margs, inv_tbl, top_k, o);
     SKR_LAUNCH_CHECK();
     if (d_sums) return skr::launch_colsum(d_rows, n_users, margs.n_metric * top_k, d_sums, st);
     return SKR_OK;
@@ -302,13 +312,13 @@ int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
 int skr_score_matrix(const float* d_user_table, const int32_t* d_users, int B, const float* d_item_table,
                      const float* d_item_bias, int n_items, int dim, float* d_scores, int64_t ld, void* stream) {
     SKR_REQUIRE(d_user_table && d_users && d_item_table && d_scores, "skr_score_matrix: NULL argument");
-    SKR_REQUIRE(dim == 64, "skr_score_matrix: dim must be 64 (got %d)", dim);
+    SKR_REQUIRE(dim >= 4 && dim <= 256 && dim % 4 == 0, "skr_score_matrix: dim must be a multiple of 4 in [4, 256] (got %d)", dim);
     SKR_REQUIRE(B >= 0 && n_items > 0 && ld >= n_items, "skr_score_matrix: bad shape");
     if (B == 0) return SKR_OK;
     dim3 grid(static_cast<unsigned>((n_items + 63) / 64), static_cast<unsigned>((B + 3) / 4));
     SKR_REQUIRE(grid.y <= 65535, "skr_score_matrix: at most 262140 users per call");
     hipLaunchKernelGGL(score_matrix_kernel, grid, dim3(256), 0, skr::as_stream(stream), d_user_table, d_users, B,
-                       d_item_table, d_item_bias, n_items, d_scores, ld);
+                       d_item_table, d_item_bias, n_items, dim, d_scores, ld);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
@@ -329,15 +339,17 @@ int skr_rank_metrics(const int32_t* d_topk_ids, int B, int top_k, const int32_t*
                      float* d_rows, double* d_sums, void* stream) {
     SKR_REQUIRE(d_topk_ids && d_test_rowptr && d_test_items && d_rows, "skr_rank_metrics: NULL argument");
     SKR_REQUIRE(B >= 0, "skr_rank_metrics: negative B");
-    SKR_REQUIRE(top_k >= 1 && top_k <= SKR_MAX_TOPK, "top_k %d outside [1, %d]", top_k, SKR_MAX_TOPK);
+    SKR_REQUIRE(top_k >= 1 && top_k <= SKR_MAX_TOPK_SCORES, "top_k %d outside [1, %d]", top_k, SKR_MAX_TOPK_SCORES);
     skr::MetricArgs margs{};
     int rc = make_metric_args(metric, n_metric, &margs);
     if (rc) return rc;
     if (B == 0) return SKR_OK;
     hipStream_t st = skr::as_stream(stream);
     const int64_t work = static_cast<int64_t>(B) * n_metric;
+    const double* inv_tbl = skr::inv_log2_table_device();
+    SKR_REQUIRE(inv_tbl, "skr_rank_metrics: no device memory for the 1 / log2 table");
     hipLaunchKernelGGL(rank_metrics_kernel, dim3(static_cast<unsigned>((work + 127) / 128)), dim3(128), 0, st,
-                       d_topk_ids, B, top_k, d_truth_rows, d_test_rowptr, d_test_items, margs, skr::inv_log2_table(),
+                       d_topk_ids, B, top_k, d_truth_rows, d_test_rowptr, d_test_items, margs, inv_tbl,
                        d_rows);
     SKR_LAUNCH_CHECK();
     if (d_sums) return skr::launch_colsum(d_rows, B, n_metric * top_k, d_sums, st);

@@ -42,14 +42,14 @@ struct Task {
 static_assert(SPMM_TASK <= 256, "a task's length - 1 is packed into 8 bits");
 
 // accumulate entries [e, e + m) (m <= 64, held one per lane in cl / vl; lanes >= m hold a valid column and value 0)
-__device__ __forceinline__ void gather_block(const float4* __restrict__ X4, int cl, float vl, int m, int grp, int sub, float4& acc) {
+__device__ __forceinline__ void gather_block(const float4* __restrict__ X4, int cl, float vl, int m, int grp, int sub, float4& acc, int ld4 = 16) {
     int k = 0;
     for (; k + 4 * ROW_NF <= m; k += 4 * ROW_NF) {
         float4 x[ROW_NF];
         float v[ROW_NF];
 #pragma unroll
         for (int q = 0; q < ROW_NF; ++q) {
-            x[q] = X4[static_cast<int64_t>(__shfl(cl, k + 4 * q + grp)) * 16 + sub];
+            x[q] = X4[static_cast<int64_t>(__shfl(cl, k + 4 * q + grp)) * ld4 + sub];
             v[q] = __shfl(vl, k + 4 * q + grp);
         }
 #pragma unroll
@@ -59,7 +59,7 @@ __device__ __forceinline__ void gather_block(const float4* __restrict__ X4, int 
         }
     }
     for (; k < m; k += 4) {   // every lane takes part in both shuffles (a bpermute reads 0 from a masked-off lane)
-        const float4 x = X4[static_cast<int64_t>(__shfl(cl, k + grp)) * 16 + sub];
+        const float4 x = X4[static_cast<int64_t>(__shfl(cl, k + grp)) * ld4 + sub];
         const float v = __shfl(vl, k + grp);
         acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y); acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
     }
@@ -103,47 +103,50 @@ __device__ __forceinline__ float row_total(const float (&p)[V]) {
     }
     return s;
 }
+// (ld: the row stride of every dense operand in floats -- 64 for a [n, 64] table, 64 C for one 64-column slice of a
+//  [n, 64 C] table: a wider embedding is multiplied slice by slice, the product being separable in the columns)
 template <int V>
-__device__ __forceinline__ void row_load(const float* __restrict__ t, int64_t r, int idx, float (&o)[V]) {
+__device__ __forceinline__ void row_load(const float* __restrict__ t, int64_t r, int idx, float (&o)[V], int ld = D) {
     if (V == 4) {
-        const float4 a = reinterpret_cast<const float4*>(t)[r * 16 + idx];
+        const float4 a = reinterpret_cast<const float4*>(t + r * ld)[idx];
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
     } else {
-        o[0] = t[r * D + idx];
+        o[0] = t[r * ld + idx];
     }
 }
 template <int V>
-__device__ __forceinline__ void row_store(float* __restrict__ t, int64_t r, int idx, const float (&o)[V]) {
-    if (V == 4) reinterpret_cast<float4*>(t)[r * 16 + idx] = make_float4(o[0], o[1], o[2], o[3]);
-    else t[r * D + idx] = o[0];
+__device__ __forceinline__ void row_store(float* __restrict__ t, int64_t r, int idx, const float (&o)[V], int ld = D) {
+    if (V == 4) reinterpret_cast<float4*>(t + r * ld)[idx] = make_float4(o[0], o[1], o[2], o[3]);
+    else t[r * ld + idx] = o[0];
 }
 
 template <int V>
 __device__ __forceinline__ void epilogue(const skr_spmm_epilogue& ep, float (&y)[V], int64_t r, int idx, bool writer) {
+    const int ld = ep.ld ? ep.ld : D;        // the refinements (whole-row reductions) are only run with ld == 64
     if (ep.addend && !(ep.addend_mask && !ep.addend_mask[r])) {     // a row of the addend known to be zero is not read
         float a[V];
-        row_load<V>(ep.addend, r, idx, a);
+        row_load<V>(ep.addend, r, idx, a, ld);
 #pragma unroll
         for (int j = 0; j < V; ++j) y[j] += a[j];
     }
     const bool accumulate = ep.accum && !(ep.accum_mask && !ep.accum_mask[r]);   // only the rows somebody will read
     if (ep.mode == SKR_EPI_PLAIN) {
-        if (writer && ep.Y) row_store<V>(ep.Y, r, idx, y);
+        if (writer && ep.Y) row_store<V>(ep.Y, r, idx, y, ld);
         if (accumulate) {
             float c[V];
             if (ep.accum_base) {              // accum = scale * base + scale * y: the layer mean's first term folded in
-                row_load<V>(ep.accum_base, r, idx, c);
+                row_load<V>(ep.accum_base, r, idx, c, ld);
 #pragma unroll
                 for (int j = 0; j < V; ++j) c[j] = ep.accum_scale * c[j];
             } else if (ep.accum_init) {
 #pragma unroll
                 for (int j = 0; j < V; ++j) c[j] = 0.0f;
             } else {
-                row_load<V>(ep.accum, r, idx, c);
+                row_load<V>(ep.accum, r, idx, c, ld);
             }
 #pragma unroll
             for (int j = 0; j < V; ++j) c[j] += ep.accum_scale * y[j];
-            if (writer) row_store<V>(ep.accum, r, idx, c);
+            if (writer) row_store<V>(ep.accum, r, idx, c, ld);
         }
         return;
     }
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, i
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
     const float4* X4 = reinterpret_cast<const float4*>(X);
+    const int ld = ep.ld ? ep.ld : D, ld4 = ld >> 2;
     for (int64_t r = blockIdx.x * ROW_WAVES + wv; r < n_rows; r += static_cast<int64_t>(gridDim.x) * ROW_WAVES) {
         if (row_mask && !row_mask[r]) continue;
         int64_t rb = rowptr[r], re = rowptr[r + 1];
@@ -237,21 +241,21 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, i
             if (win < n_win - 1) re = sp[win];
         }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n_win > 1 && win > 0 && grp == 0) acc = reinterpret_cast<const float4*>(ep.Y)[r * 16 + sub];   // the earlier windows' sum
+        if (n_win > 1 && win > 0 && grp == 0) acc = reinterpret_cast<const float4*>(ep.Y + r * ld)[sub];   // the earlier windows' sum
         for (int64_t e = rb; e < re; e += 64) {
             int m = static_cast<int>(re - e < 64 ? re - e : 64);
             int cl = 0;
             float vl = 0.0f;
             if (lane < m) { cl = col[e + lane]; vl = val[e + lane]; }
             if (COLMASK) m = keep_marked(col_mask, lane, m, cl, vl);
-            gather_block(X4, cl, vl, m, grp, sub, acc);
+            gather_block(X4, cl, vl, m, grp, sub, acc, ld4);
         }
         sum_groups(acc);
         if (win == n_win - 1) {
             float y[4] = {acc.x, acc.y, acc.z, acc.w};
             epilogue<4>(ep, y, r, sub, grp == 0);
         } else if (grp == 0) {
-            reinterpret_cast<float4*>(ep.Y)[r * 16 + sub] = acc;
+            reinterpret_cast<float4*>(ep.Y + r * ld)[sub] = acc;
         }
     }
 }
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
                                                                     const float* __restrict__ val, const float* __restrict__ X,
                                                                     float* __restrict__ part, const int32_t* __restrict__ long_rows,
                                                                     const uint8_t* __restrict__ row_mask,
-                                                                    const uint8_t* __restrict__ col_mask) {
+                                                                    const uint8_t* __restrict__ col_mask, int ld4) {
     const int b = group * 8 + (blockIdx.x & 7);
     if (b >= n_blocks) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
             float vl = 0.0f;
             if (lane < m) { cl = col[tk.beg + e0 + lane]; vl = val[tk.beg + e0 + lane]; }
             if (COLMASK) m = keep_marked(col_mask, lane, m, cl, vl);
-            gather_block(X4, cl, vl, m, grp, sub, acc);
+            gather_block(X4, cl, vl, m, grp, sub, acc, ld4);
         }
         sum_groups(acc);
         if (grp == 0) reinterpret_cast<float4*>(part)[static_cast<int64_t>(tk.part) * 16 + sub] = acc;
@@ -578,6 +582,9 @@ int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, c
     SKR_REQUIRE(plan && d_X && epi, "skr_spmm_plan_run: NULL argument");
     SKR_REQUIRE(dim == D, "skr_spmm_plan_run: dim must be 64 (got %d)", dim);
     const skr_spmm_epilogue ep = *epi;
+    const int ld = ep.ld ? ep.ld : D;
+    SKR_REQUIRE(ld >= D && ld % 4 == 0, "skr_spmm_plan_run: the row stride must be a multiple of 4 floats and at least 64 (got %d)", ld);
+    SKR_REQUIRE(ep.mode == SKR_EPI_PLAIN || ld == D, "skr_spmm_plan_run: the refinements need whole 64-float rows (row stride 64)");
     SKR_REQUIRE(ep.mode == SKR_EPI_PLAIN || ep.mode == SKR_EPI_REFINE_FWD || ep.mode == SKR_EPI_REFINE_BWD, "skr_spmm_plan_run: unknown epilogue mode %d", ep.mode);
     SKR_REQUIRE(ep.Y != d_X, "skr_spmm_plan_run: in-place propagation is not supported");
     SKR_REQUIRE(ep.mode != SKR_EPI_PLAIN || ep.Y || ep.accum, "skr_spmm_plan_run: the plain epilogue needs Y or accum");
@@ -606,10 +613,10 @@ int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, c
             for (int g = 0; g < groups; ++g) {
                 if (d_col_mask)
                     hipLaunchKernelGGL(spmm_tasks_kernel<true>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
-                                       plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask);
+                                       plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask, ld >> 2);
                 else
                     hipLaunchKernelGGL(spmm_tasks_kernel<false>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
-                                       plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask);
+                                       plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask, ld >> 2);
             }
             SKR_LAUNCH_CHECK();
         }

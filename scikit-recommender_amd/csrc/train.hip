@@ -25,6 +25,9 @@ constexpr int D = 64;
 // ------------------------------------------------------------------------------------------------
 constexpr int BPR_WAVES = 4;
 
+// C: the row is 64 C floats wide (embedding widths beyond 64, zero-padded to a multiple of 64 by the caller); lane l owns
+// floats l, l + 64, ...: every access is still a coalesced 256-byte one
+template <int C>
 __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
     const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ bias,
     const float* __restrict__ RP, const float* __restrict__ RQ, const int32_t* __restrict__ u_ids,
@@ -50,9 +53,17 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
             if (u % shard_world != shard_rank) continue;
             u /= shard_world;       // row of the local user table
         }
-        const float pu = P[u * D + lane], qi = Q[i * D + lane], qj = Q[j * D + lane];
+        constexpr int DW = D * C;
+        float pu[C], qi[C], qj[C];
+        float di = 0.0f, dj = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            pu[c] = P[u * DW + c * D + lane]; qi[c] = Q[i * DW + c * D + lane]; qj[c] = Q[j * DW + c * D + lane];
+            di += pu[c] * qi[c];
+            dj += pu[c] * qj[c];
+        }
         // x_ui - x_uj; the two inner products are reduced separately like inner_product() does
-        float xi = skr::wave_sum(pu * qi), xj = skr::wave_sum(pu * qj);
+        float xi = skr::wave_sum(di), xj = skr::wave_sum(dj);
         float bi = 0.0f, bj = 0.0f;
         if (bias) {
             bi = bias[i];
@@ -72,23 +83,33 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
         float sq;
         if (same_tables) {
             // BPRMF: the regulariser rows ARE the score rows -- no second read, one atomic per row for both gradient parts
-            sq = skr::wave_sum(pu * pu + qi * qi + qj * qj);
-            atomicAdd(&gP[u * D + lane], c * (qi - qj) + rs * pu);
-            atomicAdd(&gQ[i * D + lane], c * pu + rs * qi);
-            atomicAdd(&gQ[j * D + lane], -c * pu + rs * qj);
+            float sl = 0.0f;
+#pragma unroll
+            for (int c_ = 0; c_ < C; ++c_) {
+                sl += pu[c_] * pu[c_] + qi[c_] * qi[c_] + qj[c_] * qj[c_];
+                atomicAdd(&gP[u * DW + c_ * D + lane], c * (qi[c_] - qj[c_]) + rs * pu[c_]);
+                atomicAdd(&gQ[i * DW + c_ * D + lane], c * pu[c_] + rs * qi[c_]);
+                atomicAdd(&gQ[j * DW + c_ * D + lane], -c * pu[c_] + rs * qj[c_]);
+            }
+            sq = skr::wave_sum(sl);
         } else {
             // score-part gradients
-            atomicAdd(&gP[u * D + lane], c * (qi - qj));
-            atomicAdd(&gQ[i * D + lane], c * pu);
-            atomicAdd(&gQ[j * D + lane], -c * pu);
-            // regulariser rows (other tables than the score tables: LightGCN's ego embeddings)
-            const float ru = RP[u * D + lane], ri = RQ[i * D + lane], rj = RQ[j * D + lane];
-            sq = skr::wave_sum(ru * ru + ri * ri + rj * rj);
-            if (rs != 0.0f) {
-                atomicAdd(&gRP[u * D + lane], rs * ru);
-                atomicAdd(&gRQ[i * D + lane], rs * ri);
-                atomicAdd(&gRQ[j * D + lane], rs * rj);
+            float sl = 0.0f;
+#pragma unroll
+            for (int c_ = 0; c_ < C; ++c_) {
+                atomicAdd(&gP[u * DW + c_ * D + lane], c * (qi[c_] - qj[c_]));
+                atomicAdd(&gQ[i * DW + c_ * D + lane], c * pu[c_]);
+                atomicAdd(&gQ[j * DW + c_ * D + lane], -c * pu[c_]);
+                // regulariser rows (other tables than the score tables: LightGCN's ego embeddings)
+                const float ru = RP[u * DW + c_ * D + lane], ri = RQ[i * DW + c_ * D + lane], rj = RQ[j * DW + c_ * D + lane];
+                sl += ru * ru + ri * ri + rj * rj;
+                if (rs != 0.0f) {
+                    atomicAdd(&gRP[u * DW + c_ * D + lane], rs * ru);
+                    atomicAdd(&gRQ[i * DW + c_ * D + lane], rs * ri);
+                    atomicAdd(&gRQ[j * DW + c_ * D + lane], rs * rj);
+                }
             }
+            sq = skr::wave_sum(sl);
         }
         if (bias) {
             sq += bi * bi + bj * bj;
@@ -97,9 +118,11 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_step_kernel(
                 atomicAdd(&gb[j], -c + rs * bj);
             }
         }
+        if (touch && lane < C) {      // lane c marks the c-th 64-float block of each row
+            mark(&gP[u * DW + lane * D]); mark(&gQ[i * DW + lane * D]); mark(&gQ[j * DW + lane * D]);
+            if (rs != 0.0f) { mark(&gRP[u * DW + lane * D]); mark(&gRQ[i * DW + lane * D]); mark(&gRQ[j * DW + lane * D]); }
+        }
         if (touch && lane == 0) {
-            mark(&gP[u * D]); mark(&gQ[i * D]); mark(&gQ[j * D]);
-            if (rs != 0.0f) { mark(&gRP[u * D]); mark(&gRQ[i * D]); mark(&gRQ[j * D]); }
             if (bias && gb) { mark(&gb[i]); mark(&gb[j]); }
         }
         acc_loss += l;
@@ -241,17 +264,17 @@ __device__ __forceinline__ bool row_is_split(int64_t rb, int64_t re) { return (r
 
 // rows no chunk completes: empty rows get their final value here, split rows are zeroed for atomics
 __global__ void spmm_prep_kernel(int n_rows, const int64_t* __restrict__ rowptr, const float* __restrict__ addend,
-                                 float* __restrict__ Y, float* __restrict__ accum, float accum_scale) {
+                                 float* __restrict__ Y, float* __restrict__ accum, float accum_scale, int ld) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
     if (r >= n_rows) return;
     const int64_t rb = rowptr[r], re = rowptr[r + 1];
     if (re == rb) {
-        const float y = addend ? addend[r * D + lane] : 0.0f;
-        Y[r * D + lane] = y;
-        if (accum) accum[r * D + lane] += accum_scale * y;
+        const float y = addend ? addend[r * ld + lane] : 0.0f;
+        Y[r * ld + lane] = y;
+        if (accum) accum[r * ld + lane] += accum_scale * y;
     } else if (row_is_split(rb, re)) {
-        Y[r * D + lane] = 0.0f;
+        Y[r * ld + lane] = 0.0f;
     }
 }
 
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void spmm_main_kernel(int n_rows, co
                                                                   const float* __restrict__ X,
                                                                   const float* __restrict__ addend, float* __restrict__ Y,
                                                                   float* __restrict__ accum, float accum_scale,
-                                                                  int64_t nnz) {
+                                                                  int64_t nnz, int ld) {
     const int lane = threadIdx.x & 63;
     const int64_t w = blockIdx.x * static_cast<int64_t>(SP_WAVES) + (threadIdx.x >> 6);
     const int64_t e0 = w * SP_CH;
@@ -285,8 +308,8 @@ __global__ __launch_bounds__(SP_WAVES * 64) void spmm_main_kernel(int n_rows, co
             int k = 0;
             for (; k + 4 <= m; k += 4) {  // four independent 256-byte row gathers in flight
                 const int c_0 = __shfl(cl, k), c_1 = __shfl(cl, k + 1), c_2 = __shfl(cl, k + 2), c_3 = __shfl(cl, k + 3);
-                const float x0 = X[static_cast<int64_t>(c_0) * D + lane], x1 = X[static_cast<int64_t>(c_1) * D + lane];
-                const float x2 = X[static_cast<int64_t>(c_2) * D + lane], x3 = X[static_cast<int64_t>(c_3) * D + lane];
+                const float x0 = X[static_cast<int64_t>(c_0) * ld + lane], x1 = X[static_cast<int64_t>(c_1) * ld + lane];
+                const float x2 = X[static_cast<int64_t>(c_2) * ld + lane], x3 = X[static_cast<int64_t>(c_3) * ld + lane];
                 acc = fmaf(__shfl(vl, k), x0, acc);
                 acc = fmaf(__shfl(vl, k + 1), x1, acc);
                 acc = fmaf(__shfl(vl, k + 2), x2, acc);
@@ -294,34 +317,34 @@ __global__ __launch_bounds__(SP_WAVES * 64) void spmm_main_kernel(int n_rows, co
             }
             for (; k < m; ++k) {
                 const int c_0 = __shfl(cl, k);
-                acc = fmaf(__shfl(vl, k), X[static_cast<int64_t>(c_0) * D + lane], acc);
+                acc = fmaf(__shfl(vl, k), X[static_cast<int64_t>(c_0) * ld + lane], acc);
             }
         }
         if (!row_is_split(rb, re)) {  // this wave saw the whole row: finish it here
             float y = acc;
-            if (addend) y += addend[r * D + lane];
-            Y[r * D + lane] = y;
-            if (accum) accum[r * D + lane] += accum_scale * y;
+            if (addend) y += addend[r * ld + lane];
+            Y[r * ld + lane] = y;
+            if (accum) accum[r * ld + lane] += accum_scale * y;
         } else {
-            atomicAdd(&Y[r * D + lane], acc);
+            atomicAdd(&Y[r * ld + lane], acc);
         }
         e = se;
     }
 }
 
 __global__ void spmm_fix_kernel(int n_rows, const int64_t* __restrict__ rowptr, const float* __restrict__ addend,
-                                float* __restrict__ Y, float* __restrict__ accum, float accum_scale) {
+                                float* __restrict__ Y, float* __restrict__ accum, float accum_scale, int ld) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
     if (r >= n_rows) return;
     const int64_t rb = rowptr[r], re = rowptr[r + 1];
     if (re > rb && row_is_split(rb, re)) {
-        float y = Y[r * D + lane];
+        float y = Y[r * ld + lane];
         if (addend) {
-            y += addend[r * D + lane];
-            Y[r * D + lane] = y;
+            y += addend[r * ld + lane];
+            Y[r * ld + lane] = y;
         }
-        if (accum) accum[r * D + lane] += accum_scale * y;
+        if (accum) accum[r * ld + lane] += accum_scale * y;
     }
 }
 
@@ -330,42 +353,73 @@ __global__ void spmm_fix_kernel(int n_rows, const int64_t* __restrict__ rowptr, 
 // ------------------------------------------------------------------------------------------------
 constexpr float COS_EPS = 1e-8f;  // F.cosine_similarity default
 
+template <int C>
 __global__ void refine_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ E, int64_t n_rows,
                                   float* __restrict__ Z, float* __restrict__ w_out, float* __restrict__ accum) {
+    constexpr int DW = D * C;
     const int lane = threadIdx.x & 63;
     const int64_t r = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
     if (r >= n_rows) return;
-    const float y = Y[r * D + lane], e = E[r * D + lane];
-    const float ny = fmaxf(sqrtf(skr::wave_sum(y * y)), COS_EPS);
-    const float ne = fmaxf(sqrtf(skr::wave_sum(e * e)), COS_EPS);
-    const float w = skr::wave_sum((y / ny) * (e / ne));
-    const float z = w * y;
-    Z[r * D + lane] = z;
-    if (accum) accum[r * D + lane] += z;
+    float y[C], e[C];
+    float sy = 0.0f, se = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        y[c] = Y[r * DW + c * D + lane]; e[c] = E[r * DW + c * D + lane];
+        sy += y[c] * y[c];
+        se += e[c] * e[c];
+    }
+    const float ny = fmaxf(sqrtf(skr::wave_sum(sy)), COS_EPS);
+    const float ne = fmaxf(sqrtf(skr::wave_sum(se)), COS_EPS);
+    float sw = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) sw += (y[c] / ny) * (e[c] / ne);
+    const float w = skr::wave_sum(sw);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float z = w * y[c];
+        Z[r * DW + c * D + lane] = z;
+        if (accum) accum[r * DW + c * D + lane] += z;
+    }
     if (lane == 0) w_out[r] = w;
 }
 
+template <int C>
 __global__ void refine_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ E, const float* __restrict__ w_in,
                                   const float* __restrict__ dZ, int64_t n_rows, float* __restrict__ dY,
                                   float* __restrict__ dE, const uint8_t* __restrict__ row_mask, int zero_skipped) {
+    constexpr int DW = D * C;
     const int lane = threadIdx.x & 63;
     const int64_t r = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
     if (r >= n_rows) return;
     if (row_mask && !row_mask[r]) {            // dZ_r is zero: dY_r is zero and nothing is added to dE_r
-        if (zero_skipped) dY[r * D + lane] = 0.0f;
+        if (zero_skipped) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) dY[r * DW + c * D + lane] = 0.0f;
+        }
         return;
     }
-    const float y = Y[r * D + lane], e = E[r * D + lane], dz = dZ[r * D + lane];
+    float y[C], e[C], dz[C];
+    float sy = 0.0f, se = 0.0f, sd = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        y[c] = Y[r * DW + c * D + lane]; e[c] = E[r * DW + c * D + lane]; dz[c] = dZ[r * DW + c * D + lane];
+        sy += y[c] * y[c];
+        se += e[c] * e[c];
+        sd += dz[c] * y[c];
+    }
     const float w = w_in[r];
-    const float nyr = sqrtf(skr::wave_sum(y * y)), ner = sqrtf(skr::wave_sum(e * e));
+    const float nyr = sqrtf(skr::wave_sum(sy)), ner = sqrtf(skr::wave_sum(se));
     const float ny = fmaxf(nyr, COS_EPS), ne = fmaxf(ner, COS_EPS);
-    const float yh = y / ny, eh = e / ne;
-    const float dw = skr::wave_sum(dz * y);
-    // d(yh)/dy = (I - yh yh^T)/ny when the norm is not clamped, I/eps when it is (clamp_min has zero slope)
-    const float gy = (nyr > COS_EPS) ? (eh - w * yh) / ny : eh / ny;
-    const float ge = (ner > COS_EPS) ? (yh - w * eh) / ne : yh / ne;
-    dY[r * D + lane] = w * dz + dw * gy;
-    dE[r * D + lane] += dw * ge;
+    const float dw = skr::wave_sum(sd);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float yh = y[c] / ny, eh = e[c] / ne;
+        // d(yh)/dy = (I - yh yh^T)/ny when the norm is not clamped, I/eps when it is (clamp_min has zero slope)
+        const float gy = (nyr > COS_EPS) ? (eh - w * yh) / ny : eh / ny;
+        const float ge = (ner > COS_EPS) ? (yh - w * eh) / ne : yh / ne;
+        dY[r * DW + c * D + lane] = w * dz[c] + dw * gy;
+        dE[r * DW + c * D + lane] += dw * ge;
+    }
 }
 
 // rows whose mask byte is set are zeroed (and the byte cleared): restores the "all zero" state of a buffer of which only a
@@ -1322,7 +1376,7 @@ static int bpr_step_launch(const float* d_P, const float* d_Q, const float* d_bi
                  const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n, float loss_scale, float reg,
                  float reg_scale, float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ, float* d_loss,
                  uint8_t* d_touch, const float* d_touch_base, int loss_slots, void* stream, int shard_world = 1,
-                 int shard_rank = 0, float grad_scale = 1.0f) {
+                 int shard_rank = 0, float grad_scale = 1.0f, int dim = D) {
     SKR_REQUIRE(d_P && d_Q && d_RP && d_RQ && d_u && d_i && d_j && d_gP && d_gQ && d_gRP && d_gRQ && d_loss,
                 "skr_bpr_step: NULL argument");
     SKR_REQUIRE(shard_world >= 1 && shard_rank >= 0 && shard_rank < shard_world, "skr_bpr_step_sharded: rank %d of %d", shard_rank,
@@ -1332,11 +1386,30 @@ static int bpr_step_launch(const float* d_P, const float* d_Q, const float* d_bi
     if (n == 0) return SKR_OK;
     int blocks = (n + BPR_WAVES - 1) / BPR_WAVES;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bpr_step_kernel, dim3(blocks), dim3(BPR_WAVES * 64), 0, skr::as_stream(stream), d_P, d_Q, d_bias,
-                       d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP, d_gRQ, d_loss,
-                       d_touch, d_touch_base, loss_slots, shard_world, shard_rank, grad_scale);
+    SKR_REQUIRE(dim == 64 || dim == 128 || dim == 192 || dim == 256, "skr_bpr_step: dim must be 64, 128, 192 or 256 (got %d); pad narrower "
+                "rows with zeros", dim);
+#define SKR_BPR_LAUNCH(C_)                                                                                                       \
+    hipLaunchKernelGGL(bpr_step_kernel<C_>, dim3(blocks), dim3(BPR_WAVES * 64), 0, skr::as_stream(stream), d_P, d_Q, d_bias,     \
+                       d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP, d_gRQ, d_loss,        \
+                       d_touch, d_touch_base, loss_slots, shard_world, shard_rank, grad_scale)
+    switch (dim / 64) {
+        case 1: SKR_BPR_LAUNCH(1); break;
+        case 2: SKR_BPR_LAUNCH(2); break;
+        case 3: SKR_BPR_LAUNCH(3); break;
+        default: SKR_BPR_LAUNCH(4); break;
+    }
+#undef SKR_BPR_LAUNCH
     SKR_LAUNCH_CHECK();
     return SKR_OK;
+}
+
+int skr_bpr_step_dim(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
+                     const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n, int dim, float loss_scale, float reg,
+                     float reg_scale, float* d_gP, float* d_gQ, float* d_gb, float* d_gRP, float* d_gRQ, float* d_loss,
+                     int loss_slots, uint8_t* d_touch, const float* d_touch_base, float grad_scale, void* stream) {
+    SKR_REQUIRE(loss_slots == 1 || loss_slots == SKR_LOSS_SLOTS, "skr_bpr_step_dim: loss_slots must be 1 or %d", SKR_LOSS_SLOTS);
+    return bpr_step_launch(d_P, d_Q, d_bias, d_RP, d_RQ, d_u, d_i, d_j, n, loss_scale, reg, reg_scale, d_gP, d_gQ, d_gb, d_gRP,
+                           d_gRQ, d_loss, d_touch, d_touch_base, loss_slots, stream, 1, 0, grad_scale, dim);
 }
 
 int skr_bpr_step(const float* d_P, const float* d_Q, const float* d_bias, const float* d_RP, const float* d_RQ,
@@ -1432,23 +1505,30 @@ static int adam_step_impl(float* d_p, float* d_g, float* d_m, float* d_v, int64_
 int skr_csr_spmm(int n_rows, const int64_t* d_rowptr, const int32_t* d_col, const float* d_val, const float* d_X,
                  int dim, int64_t nnz, const float* d_addend, float* d_Y, float* d_accum, float accum_scale,
                  void* stream) {
+    return skr_csr_spmm_strided(n_rows, d_rowptr, d_col, d_val, d_X, dim, D, nnz, d_addend, d_Y, d_accum, accum_scale, stream);
+}
+
+int skr_csr_spmm_strided(int n_rows, const int64_t* d_rowptr, const int32_t* d_col, const float* d_val, const float* d_X,
+                         int dim, int ld, int64_t nnz, const float* d_addend, float* d_Y, float* d_accum, float accum_scale,
+                         void* stream) {
     SKR_REQUIRE(d_rowptr && d_col && d_val && d_X && d_Y, "skr_csr_spmm: NULL argument");
-    SKR_REQUIRE(dim == D, "skr_csr_spmm: dim must be 64 (got %d)", dim);
+    SKR_REQUIRE(dim == D, "skr_csr_spmm: dim must be 64 (got %d): wider tables are multiplied in 64-column slices (ld)", dim);
+    SKR_REQUIRE(ld >= D, "skr_csr_spmm: the row stride must be at least 64 floats (got %d)", ld);
     SKR_REQUIRE(n_rows >= 0 && nnz >= 0, "skr_csr_spmm: negative size");
     SKR_REQUIRE(d_Y != d_X, "skr_csr_spmm: in-place propagation is not supported");
     if (n_rows == 0) return SKR_OK;
     hipStream_t st = skr::as_stream(stream);
     hipLaunchKernelGGL(spmm_prep_kernel, dim3(rows_to_blocks(n_rows)), dim3(256), 0, st, n_rows, d_rowptr, d_addend, d_Y,
-                       d_accum, accum_scale);
+                       d_accum, accum_scale, ld);
     SKR_LAUNCH_CHECK();
     if (nnz > 0) {
         const int64_t waves = (nnz + SP_CH - 1) / SP_CH;
         hipLaunchKernelGGL(spmm_main_kernel, dim3(static_cast<unsigned>((waves + SP_WAVES - 1) / SP_WAVES)),
                            dim3(SP_WAVES * 64), 0, st, n_rows, d_rowptr, d_col, d_val, d_X, d_addend, d_Y, d_accum,
-                           accum_scale, nnz);
+                           accum_scale, nnz, ld);
         SKR_LAUNCH_CHECK();
         hipLaunchKernelGGL(spmm_fix_kernel, dim3(rows_to_blocks(n_rows)), dim3(256), 0, st, n_rows, d_rowptr, d_addend,
-                           d_Y, d_accum, accum_scale);
+                           d_Y, d_accum, accum_scale, ld);
         SKR_LAUNCH_CHECK();
     }
     return SKR_OK;
@@ -1457,10 +1537,12 @@ int skr_csr_spmm(int n_rows, const int64_t* d_rowptr, const int32_t* d_col, cons
 int skr_layer_refine_fwd(const float* d_Y, const float* d_E, int64_t n_rows, int dim, float* d_Z, float* d_w,
                          float* d_accum, void* stream) {
     SKR_REQUIRE(d_Y && d_E && d_Z && d_w, "skr_layer_refine_fwd: NULL argument");
-    SKR_REQUIRE(dim == D, "skr_layer_refine_fwd: dim must be 64 (got %d)", dim);
+    SKR_REQUIRE(dim == 64 || dim == 128 || dim == 192 || dim == 256, "skr_layer_refine_fwd: dim must be 64, 128, 192 or 256 (got %d)", dim);
     if (n_rows <= 0) return SKR_OK;
-    hipLaunchKernelGGL(refine_fwd_kernel, dim3(rows_to_blocks(n_rows)), dim3(256), 0, skr::as_stream(stream), d_Y, d_E,
-                       n_rows, d_Z, d_w, d_accum);
+#define SKR_RF(C_) hipLaunchKernelGGL(refine_fwd_kernel<C_>, dim3(rows_to_blocks(n_rows)), dim3(256), 0, skr::as_stream(stream), d_Y, d_E, \
+                                      n_rows, d_Z, d_w, d_accum)
+    switch (dim / 64) { case 1: SKR_RF(1); break; case 2: SKR_RF(2); break; case 3: SKR_RF(3); break; default: SKR_RF(4); break; }
+#undef SKR_RF
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
@@ -1468,10 +1550,12 @@ int skr_layer_refine_fwd(const float* d_Y, const float* d_E, int64_t n_rows, int
 int skr_layer_refine_bwd_masked(const float* d_Y, const float* d_E, const float* d_w, const float* d_dZ, int64_t n_rows, int dim,
                                 float* d_dY, float* d_dE, const uint8_t* d_row_mask, int zero_skipped, void* stream) {
     SKR_REQUIRE(d_Y && d_E && d_w && d_dZ && d_dY && d_dE, "skr_layer_refine_bwd: NULL argument");
-    SKR_REQUIRE(dim == D, "skr_layer_refine_bwd: dim must be 64 (got %d)", dim);
+    SKR_REQUIRE(dim == 64 || dim == 128 || dim == 192 || dim == 256, "skr_layer_refine_bwd: dim must be 64, 128, 192 or 256 (got %d)", dim);
     if (n_rows <= 0) return SKR_OK;
-    hipLaunchKernelGGL(refine_bwd_kernel, dim3(rows_to_blocks(n_rows)), dim3(256), 0, skr::as_stream(stream), d_Y, d_E,
-                       d_w, d_dZ, n_rows, d_dY, d_dE, d_row_mask, zero_skipped);
+#define SKR_RB(C_) hipLaunchKernelGGL(refine_bwd_kernel<C_>, dim3(rows_to_blocks(n_rows)), dim3(256), 0, skr::as_stream(stream), d_Y, d_E, \
+                                      d_w, d_dZ, n_rows, d_dY, d_dE, d_row_mask, zero_skipped)
+    switch (dim / 64) { case 1: SKR_RB(1); break; case 2: SKR_RB(2); break; case 3: SKR_RB(3); break; default: SKR_RB(4); break; }
+#undef SKR_RB
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }

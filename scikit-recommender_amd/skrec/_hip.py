@@ -72,6 +72,8 @@ SIGNATURES = {
     "skr_bpr_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "skr_bpr_step_sharded": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "skr_bpr_step_spread": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "skr_bpr_step_dim": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp, vp, f32, vp]),
+    "skr_csr_spmm_strided": (i32, [i32, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, f32, vp]),
     "skr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, i32, vp, vp]),
     "skr_csr_spmm": (i32, [i32, vp, vp, vp, vp, i32, i64, vp, vp, vp, f32, vp]),
     "skr_spmm_plan_create": (i32, [i32, i32, vp, vp, vp, i64, i32, C.POINTER(vp), vp]),
@@ -96,12 +98,13 @@ SIGNATURES = {
 class SpmmEpilogue(C.Structure):
     """skr_spmm_epilogue (include/skrec_hip.h): what happens to a finished row of a propagation"""
     _fields_ = [("mode", C.c_int32), ("accum_init", C.c_int32), ("addend", vp), ("Y", vp), ("accum", vp), ("accum_base", vp),
-                ("accum_scale", C.c_float), ("reserved_", C.c_float), ("E", vp), ("w", vp), ("Z", vp), ("rawY", vp), ("dE", vp), ("accum_mask", vp), ("addend_mask", vp)]
+                ("accum_scale", C.c_float), ("ld", C.c_int32), ("E", vp), ("w", vp), ("Z", vp), ("rawY", vp), ("dE", vp), ("accum_mask", vp), ("addend_mask", vp)]
 
 
 EPI_PLAIN, EPI_REFINE_FWD, EPI_REFINE_BWD = 0, 1, 2
 
-SKR_MAX_TOPK = 128
+SKR_MAX_TOPK = 128            # skr_eval_fused_topk
+SKR_MAX_TOPK_SCORES = 512     # skr_eval_scores, skr_rank_metrics
 SKR_LOSS_SLOTS = 32      # skr_bpr_step_spread: pairs of loss words per batch
 
 
@@ -173,8 +176,8 @@ def score_matrix(user_table, users, item_table, bias):
     du = torch.as_tensor(np.asarray(users, dtype=np.int32)).to(dev)
     n_items = int(item_table.shape[0])
     out = torch.empty((du.numel(), n_items), dtype=torch.float32, device=dev)
-    check(lib().skr_score_matrix(ptr(user_table), ptr(du), du.numel(), ptr(item_table), ptr(bias), n_items, 64, ptr(out),
-                                 n_items, stream()))
+    check(lib().skr_score_matrix(ptr(user_table), ptr(du), du.numel(), ptr(item_table), ptr(bias), n_items,
+                                 int(item_table.shape[1]), ptr(out), n_items, stream()))
     return out
 
 

@@ -413,9 +413,10 @@ class ShardedLayerGCN(object):
         value 1/sqrt((deg_u + 1e-7)(deg_i + 1e-7)), float64 then rounded to float32"""
         dev, world, rank = self.device, self.ctx.world, self.ctx.rank
         u, i = edge_u.to(dev).long(), edge_i.to(dev).long()
-        ones = torch.ones(u.numel(), dtype=torch.float64, device=dev)
-        du = (torch.zeros(self.num_users, dtype=torch.float64, device=dev).index_add_(0, u, ones) + 1e-7).pow(-0.5)
-        di = (torch.zeros(self.num_items, dtype=torch.float64, device=dev).index_add_(0, i, ones) + 1e-7).pow(-0.5)
+        # (degrees as exact integer counts: a float64 index_add_ of ones gives the same numbers through 10^8 double atomics,
+        #  16 s at 48 M edges)
+        du = (torch.bincount(u, minlength=self.num_users).double() + 1e-7).pow(-0.5)
+        di = (torch.bincount(i, minlength=self.num_items).double() + 1e-7).pow(-0.5)
         sel = (u % world) == rank
         ul, il = torch.div(u[sel], world, rounding_mode="floor"), i[sel]
         vals = (du[u[sel]] * di[il]).float()

@@ -63,8 +63,8 @@ class BPRMF(AbstractRecommender):
         self.config = BPRMFConfig(**model_config)
         super().__init__(run_config, self.config)
         self.num_users, self.num_items = self.dataset.num_users, self.dataset.num_items
-        if self.config.n_dim != 64:
-            raise NotImplementedError("the MI355X kernels are specialised for n_dim=64 (one row per wavefront)")
+        from .LightGCN import pad_columns, padded_width
+        self.dp = padded_width(self.config.n_dim)       # row width of the tables in HBM (zero-padded to a multiple of 64)
         self.device = _hip.require_gpu()
         U, V, b = _init_tables(self.num_users, self.num_items, self.config.n_dim)
         self.step_losses = None  # device [n_steps, 2]: (bpr sum, l2) per step of the last epoch
@@ -72,19 +72,26 @@ class BPRMF(AbstractRecommender):
         # one process per GPU (torchrun): users sharded, item table replicated -- skrec/parallel.py
         from ..parallel import init_from_env, ShardedBPRMF
         self.dist = init_from_env()
+        if self.dist.active and self.config.n_dim != 64:
+            raise NotImplementedError("one process per GPU: the sharded engines are built for n_dim=64")
         self.engine = ShardedBPRMF(self.dist, U, V, b, self.config.lr, self.config.reg, self.device) if self.dist.active \
             else None
         if self.engine is not None:
             self._full_users = None
             return
         # one flat buffer [U | V | b] => one Adam launch per step; the tables are views into it
-        nu, ni, d = self.num_users, self.num_items, self.config.n_dim
+        nu, ni, d = self.num_users, self.num_items, self.dp
+        U, V = pad_columns(U, d), pad_columns(V, d)
         self._flat = torch.cat([U.reshape(-1), V.reshape(-1), b.reshape(-1)]).to(self.device).contiguous()
-        self.user_embeddings = self._flat[:nu * d].view(nu, d)
-        self.item_embeddings = self._flat[nu * d:(nu + ni) * d].view(ni, d)
+        # the tables as the kernels see them: [*, dp]; `user_embeddings` / `item_embeddings` are their first n_dim columns
+        self._user_rows = self._flat[:nu * d].view(nu, d)
+        self._item_rows = self._flat[nu * d:(nu + ni) * d].view(ni, d)
+        self.user_embeddings = self._user_rows[:, :self.config.n_dim]
+        self.item_embeddings = self._item_rows[:, :self.config.n_dim]
         self.item_biases = self._flat[(nu + ni) * d:]
-        # SKR_ADAM_BLOCK = k: look k batches ahead and block the dense Adam over them (1: one dense launch per step)
-        self.adam_block = max(1, min(64, int(os.environ.get("SKR_ADAM_BLOCK", "32"))))
+        # SKR_ADAM_BLOCK = k: look k batches ahead and block the dense Adam over them (1: one dense launch per step).  Rows
+        # wider than one 64-float block take the dense launch per step (the blocked forms name rows by their block)
+        self.adam_block = max(1, min(64, int(os.environ.get("SKR_ADAM_BLOCK", "32")))) if d == 64 else 1
         # SKR_BPR_FUSED=0: two launches per step (skr_bpr_step_spread + skr_adam_block_hot) instead of one (skr_bpr_fused_step)
         self.fused_step = os.environ.get("SKR_BPR_FUSED", "1") != "0"
         self._fused = None
@@ -95,13 +102,13 @@ class BPRMF(AbstractRecommender):
     def train_step(self, users, pos, neg, loss_slot):
         """one mini-batch; ``users/pos/neg`` are int32 device tensors"""
         gU, gV, gb = self._grads
-        _hip.check(_hip.lib().skr_bpr_step(
-            _hip.ptr(self.user_embeddings), _hip.ptr(self.item_embeddings), _hip.ptr(self.item_biases),
-            _hip.ptr(self.user_embeddings), _hip.ptr(self.item_embeddings),
-            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), 1.0, self.config.reg, 1.0,
-            _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(gb), _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(loss_slot),
+        _hip.check(_hip.lib().skr_bpr_step_dim(
+            _hip.ptr(self._user_rows), _hip.ptr(self._item_rows), _hip.ptr(self.item_biases),
+            _hip.ptr(self._user_rows), _hip.ptr(self._item_rows),
+            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), self.dp, 1.0, self.config.reg, 1.0,
+            _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(gb), _hip.ptr(gU), _hip.ptr(gV), _hip.ptr(loss_slot), 1,
             _hip.ptr(self.optimizer.touch), _hip.ptr(self.optimizer.grad) if self.optimizer.touch is not None else None,
-            _hip.stream()))
+            1.0, _hip.stream()))
         self.optimizer.step()
 
     def train_epoch(self, data_iter):
@@ -123,7 +130,7 @@ class BPRMF(AbstractRecommender):
         S = _hip.SKR_LOSS_SLOTS
         spread = torch.zeros((len(data_iter), S, 2), dtype=torch.float32, device=self.device)
         gU, gV, gb = self._grads
-        pU, pV, pb = self.user_embeddings.data_ptr(), self.item_embeddings.data_ptr(), self.item_biases.data_ptr()
+        pU, pV, pb = self._user_rows.data_ptr(), self._item_rows.data_ptr(), self.item_biases.data_ptr()
         pgU, pgV, pgb = gU.data_ptr(), gV.data_ptr(), gb.data_ptr()
         ploss, reg = spread.data_ptr(), self.config.reg
         kblk = self.adam_block
@@ -138,8 +145,8 @@ class BPRMF(AbstractRecommender):
             n_par = opt.flat.numel()
             for k, (u, i, j) in enumerate(data_iter.iter_device()):
                 # slices of the contiguous epoch columns are themselves contiguous (num_neg == 1)
-                rc = L.skr_bpr_step_spread(pU, pV, pb, pU, pV, u.data_ptr(), i.data_ptr(), j.data_ptr(), u.numel(), 1.0, reg, 1.0,
-                                           pgU, pgV, pgb, pgU, pgV, ploss + 8 * S * k, ptouch, pgrad_base, st)
+                rc = L.skr_bpr_step_dim(pU, pV, pb, pU, pV, u.data_ptr(), i.data_ptr(), j.data_ptr(), u.numel(), self.dp, 1.0, reg, 1.0,
+                                        pgU, pgV, pgb, pgU, pgV, ploss + 8 * S * k, S, ptouch, pgrad_base, 1.0, st)
                 opt.t += 1
                 rc |= L.skr_adam_step(pflat, pgrad, pm, pv, n_par, opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.t, 1,
                                       ptouch, st)
@@ -242,7 +249,7 @@ class BPRMF(AbstractRecommender):
             if self._full_users is None:
                 self._full_users = self.engine.gather_user_table()
             return self._full_users, self.engine.item_rows, self.engine.item_bias
-        return self.user_embeddings, self.item_embeddings, self.item_biases
+        return self._user_rows, self._item_rows, self.item_biases
 
     def predict(self, users) -> np.ndarray:
         """dense [len(users), num_items] scores (API surface of BPRMF.py:145-147; the evaluator uses

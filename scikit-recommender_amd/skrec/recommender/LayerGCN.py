@@ -33,7 +33,7 @@ from ..io import PairwiseIterator
 from ..run_config import RunConfig
 from ..utils.py import EarlyStopping, ModelConfig
 from .base import AbstractRecommender, DenseAdam
-from .LightGCN import DEVICE_ADJ_MIN_PAIRS, DeviceCSR
+from .LightGCN import DEVICE_ADJ_MIN_PAIRS, DeviceCSR, pad_columns, padded_width
 
 __all__ = ["LayerGCN", "LayerGCNConfig"]
 
@@ -78,8 +78,7 @@ class LayerGCN(AbstractRecommender):
         super().__init__(run_config, self.config)
         cfg = self.config
         self.num_users, self.num_items = self.dataset.num_users, self.dataset.num_items
-        if cfg.embed_dim != 64:
-            raise NotImplementedError("the MI355X kernels are specialised for embed_dim=64")
+        self.dp = padded_width(cfg.embed_dim)        # row width of the tables in HBM (zero-padded to a multiple of 64)
         if not 0.0 <= cfg.dropout < 1.0:
             raise ValueError("dropout must be in [0, 1)")
         if cfg.prune_draws not in ("reference", "device"):
@@ -95,6 +94,8 @@ class LayerGCN(AbstractRecommender):
         self.step_losses = None
         self.sampler_mode = getattr(run_config, "sampler_mode", None)
         self.engine = None
+        if self.dist.active and cfg.embed_dim != 64:
+            raise NotImplementedError("one process per GPU: the sharded engines are built for embed_dim=64")
         if self.dist.active:
             # user-sharded rows, replicated item rows (skrec/parallel.py); duplicate pairs collapse to one edge
             pairs = np.unique(np.stack([inter.row, inter.col], 1).astype(np.int64), axis=0)
@@ -115,10 +116,11 @@ class LayerGCN(AbstractRecommender):
         self._edge_i = torch.from_numpy(np.asarray(inter.col, dtype=np.int64)).to(self.device)
         self._edge_values = self._normalize_edges(self._edge_u, self._edge_i)
         N = self.num_users + self.num_items
-        self.ego = torch.cat([ue, ie], dim=0).to(self.device).contiguous()
+        dp = self.dp
+        self.ego = pad_columns(torch.cat([ue, ie], dim=0), dp).to(self.device).contiguous()
         self.optimizer = DenseAdam(self.ego.view(-1), lr=cfg.lr)
-        self._g_ego = self.optimizer.grad.view(N, 64)
-        z = lambda: torch.zeros((N, 64), dtype=torch.float32, device=self.device)  # noqa: E731
+        self._g_ego = self.optimizer.grad.view(N, dp)
+        z = lambda: torch.zeros((N, dp), dtype=torch.float32, device=self.device)  # noqa: E731
         K = cfg.n_layers
         self.out = z()                                   # sum of refined layers
         self._y = [z() for _ in range(K)]                # A X_k kept for the backward
@@ -131,13 +133,13 @@ class LayerGCN(AbstractRecommender):
     def user_embeddings(self):
         if self.engine is not None:
             return self.engine.gather_user_table()
-        return self.ego[:self.num_users]
+        return self.ego[:self.num_users, :self.config.embed_dim]
 
     @property
     def item_embeddings(self):
         if self.engine is not None:
             return self.engine.item_rows
-        return self.ego[self.num_users:]
+        return self.ego[self.num_users:, :self.config.embed_dim]
 
     def _device_adjacency(self, inter):
         """get_norm_adj_mat (LayerGCN.py:173-197) on the device: binary bipartite graph (duplicate pairs are one
@@ -146,9 +148,9 @@ class LayerGCN(AbstractRecommender):
         key = torch.unique(torch.from_numpy(np.asarray(inter.row, dtype=np.int64)).to(dev) * self.num_items
                            + torch.from_numpy(np.asarray(inter.col, dtype=np.int64)).to(dev))
         u, i = torch.div(key, self.num_items, rounding_mode="floor"), key % self.num_items
-        one = torch.ones(u.numel(), dtype=torch.float64, device=dev)
-        du = (torch.zeros(nu, dtype=torch.float64, device=dev).index_add_(0, u, one) + 1e-7).pow(-0.5)
-        di = (torch.zeros(self.num_items, dtype=torch.float64, device=dev).index_add_(0, i, one) + 1e-7).pow(-0.5)
+        # degrees as exact integer counts (a float64 index_add_ of ones is the same numbers, through 10^8 double atomics)
+        du = (torch.bincount(u, minlength=nu).double() + 1e-7).pow(-0.5)
+        di = (torch.bincount(i, minlength=self.num_items).double() + 1e-7).pow(-0.5)
         vals = (du[u] * di[i]).float()
         return DeviceCSR.from_device_coo(torch.cat([u, i + nu]), torch.cat([i + nu, u]), torch.cat([vals, vals]), n)
 
@@ -244,21 +246,21 @@ class LayerGCN(AbstractRecommender):
                 self._row_mask = torch.zeros(self.num_users + self.num_items, dtype=torch.uint8, device=self.device)
                 gO.zero_()
             else:
-                _hip.check(L.skr_clear_marked_rows(_hip.ptr(self._row_mask), N, 1, _hip.ptr(gO), 64, st))
+                _hip.check(L.skr_clear_marked_rows(_hip.ptr(self._row_mask), N, 1, _hip.ptr(gO), self.dp, st))
             rows = self._batch_rows(users, pos, neg)
         self.forward(adj, last_rows=rows)
-        _hip.check(L.skr_bpr_step(
+        _hip.check(L.skr_bpr_step_dim(
             _hip.ptr(self.out[:nu]), _hip.ptr(self.out[nu:]), None, _hip.ptr(self.ego[:nu]), _hip.ptr(self.ego[nu:]),
-            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), 1.0, cfg.reg, 1.0,
-            _hip.ptr(gO[:nu]), _hip.ptr(gO[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot),
-            None, None, st))
+            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), users.numel(), self.dp, 1.0, cfg.reg, 1.0,
+            _hip.ptr(gO[:nu]), _hip.ptr(gO[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot), 1,
+            None, None, 1.0, st))
         # backward: dZ_K = gO ; dY_k, dE0 += refine_bwd(dZ_k) ; dZ_{k-1} = gO + A dY_k ; dE0 += A dY_1.  dZ_K is zero outside the
         # batch's rows, so the top refinement only visits those (the plan's product then skips the other columns of dY_K;
         # the plan-free kernel reads every column: there the skipped rows are written as zeros); every further refinement
         # rides in the row epilogue of the hop that produces its dZ.
         K = cfg.n_layers
         dy, nxt = self._t
-        _hip.check(L.skr_layer_refine_bwd_masked(_hip.ptr(self._y[K - 1]), _hip.ptr(self.ego), _hip.ptr(self._w[K - 1]), _hip.ptr(gO), N, 64,
+        _hip.check(L.skr_layer_refine_bwd_masked(_hip.ptr(self._y[K - 1]), _hip.ptr(self.ego), _hip.ptr(self._w[K - 1]), _hip.ptr(gO), N, self.dp,
                                                  _hip.ptr(dy), _hip.ptr(gE), _hip.ptr(rows), 0 if adj.uses_plan() else 1, st))
         for k in range(K - 1, -1, -1):
             cm = rows if k == K - 1 else None

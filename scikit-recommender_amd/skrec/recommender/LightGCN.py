@@ -141,6 +141,10 @@ class DeviceCSR(object):
         [n_rows]): addend IS zero on the rows with a zero byte (hints again: the plan-free path reads / updates every row)."""
         L, st = _hip.lib(), _hip.stream()
         n = self.shape[0]
+        W = int(X.shape[1])
+        if W != 64:
+            return self._spmm_wide(X, Y, W, addend, accum, accum_scale, row_mask, col_mask, accum_base, accum_init, refine_fwd,
+                                   refine_bwd, accum_mask, addend_mask)
         if self.uses_plan():
             if Y is not None and accum_base is None and not accum_init and refine_fwd is None and refine_bwd is None \
                     and accum_mask is None and addend_mask is None:
@@ -184,6 +188,66 @@ class DeviceCSR(object):
             _hip.check(L.skr_layer_refine_bwd(_hip.ptr(rawY), _hip.ptr(E), _hip.ptr(w), _hip.ptr(raw), n, 64, _hip.ptr(Y), _hip.ptr(dE),
                                               st))
         return Y
+
+
+    def _spmm_wide(self, X, Y, W, addend, accum, accum_scale, row_mask, col_mask, accum_base, accum_init, refine_fwd, refine_bwd,
+                   accum_mask, addend_mask):
+        """Embedding widths beyond 64 (tables [n, W], W = 64 C; narrower widths are zero-padded by the models): the product is
+        separable in the columns, so it runs slice by slice through the 64-column kernels with the tables' row stride
+        (skr_spmm_epilogue.ld / skr_csr_spmm_strided); LayerGCN's refinements reduce over whole rows and are launches of
+        their own over the full width."""
+        import ctypes
+        L, st = _hip.lib(), _hip.stream()
+        n, C = self.shape[0], W // 64
+        assert W % 64 == 0 and 2 <= C <= 4, "pad the embedding width to a multiple of 64 (at most 256)"
+        plain = refine_fwd is None and refine_bwd is None
+        raw = Y
+        if Y is None or refine_bwd is not None:
+            if getattr(self, "_tmpw", None) is None or self._tmpw.shape[1] != W:
+                self._tmpw = torch.empty((n, W), dtype=torch.float32, device=X.device)
+            raw = self._tmpw
+        if plain and accum is not None and accum_base is not None:
+            _hip.check(L.skr_scale_copy(float(accum_scale), _hip.ptr(accum_base), _hip.ptr(accum), n * W, st))
+        elif accum is not None and accum_init:
+            accum.zero_()
+        sl = lambda t, c: None if t is None else t.data_ptr() + 256 * c      # noqa: E731  the c-th 64-column slice
+        for t in (X, raw, addend, accum):
+            assert t is None or (t.is_contiguous() and t.shape[1] == W)
+        for c in range(C):
+            if self.uses_plan():
+                ep = _hip.SpmmEpilogue()
+                ep.mode, ep.ld = _hip.EPI_PLAIN, W
+                ep.addend, ep.Y, ep.accum = sl(addend, c), sl(raw, c), sl(accum, c) if plain else None
+                ep.accum_scale = float(accum_scale)
+                ep.accum_mask, ep.addend_mask = _hip.ptr(accum_mask) if plain else None, _hip.ptr(addend_mask)
+                _hip.check(L.skr_spmm_plan_run_ex(self._plan_handle(), sl(X, c), 64, ctypes.byref(ep), _hip.ptr(row_mask),
+                                                  _hip.ptr(col_mask), st))
+            else:
+                _hip.check(L.skr_csr_spmm_strided(n, _hip.ptr(self.rowptr), _hip.ptr(self.col), _hip.ptr(self.val), sl(X, c), 64, W,
+                                                  self.nnz, sl(addend, c), sl(raw, c), sl(accum, c) if plain else None,
+                                                  float(accum_scale), st))
+        if refine_fwd is not None:
+            E, w, Z = refine_fwd
+            _hip.check(L.skr_layer_refine_fwd(_hip.ptr(raw), _hip.ptr(E), n, W, _hip.ptr(Z), _hip.ptr(w), _hip.ptr(accum), st))
+        elif refine_bwd is not None:
+            E, w, rawY, dE = refine_bwd
+            _hip.check(L.skr_layer_refine_bwd(_hip.ptr(rawY), _hip.ptr(E), _hip.ptr(w), _hip.ptr(raw), n, W, _hip.ptr(Y), _hip.ptr(dE),
+                                              st))
+        return Y
+
+
+def padded_width(d):
+    """the kernels' row widths are multiples of 64 floats (one 256-byte access per lane group): an embedding of another width
+    -- n_dim / embed_size / embed_dim are free integers in the reference -- lives in zero-padded rows.  Padded columns have
+    zero gradients, stay zero under Adam and add nothing to a dot product, a norm or a propagation."""
+    dp = 64 * ((int(d) + 63) // 64)
+    if dp > 256:
+        raise NotImplementedError("embedding widths up to 256 are supported by the MI355X kernels")
+    return dp
+
+
+def pad_columns(t, dp):
+    return t if t.shape[1] == dp else torch.nn.functional.pad(t, (0, dp - t.shape[1]))
 
 
 def build_adjacency(users_np, items_np, num_users, num_items, adj_type):
@@ -250,8 +314,7 @@ class LightGCN(AbstractRecommender):
         super().__init__(run_config, self.config)
         cfg = self.config
         self.num_users, self.num_items = self.dataset.num_users, self.dataset.num_items
-        if cfg.embed_size != 64:
-            raise NotImplementedError("the MI355X kernels are specialised for embed_size=64")
+        self.dp = padded_width(cfg.embed_size)       # row width of the tables in HBM (zero-padded to a multiple of 64)
         self.device = _hip.require_gpu()
         # one process per GPU (torchrun): user-sharded propagation, see skrec/parallel.py
         from ..parallel import init_from_env, ShardedLightGCN
@@ -263,6 +326,8 @@ class LightGCN(AbstractRecommender):
         self.sampler_mode = getattr(run_config, "sampler_mode", None)
         self.step_losses = None
         if self.dist.active:
+            if self.dp != 64 or cfg.embed_size != 64:
+                raise NotImplementedError("one process per GPU: the sharded engines are built for embed_size=64")
             ue, ie = nn.Embedding(self.num_users, cfg.embed_size), nn.Embedding(self.num_items, cfg.embed_size)
             get_initializer("xavier_uniform")(ue.weight)
             get_initializer("xavier_uniform")(ie.weight)
@@ -284,10 +349,11 @@ class LightGCN(AbstractRecommender):
         get_initializer("xavier_uniform")(ue.weight)
         get_initializer("xavier_uniform")(ie.weight)
         N = self.num_users + self.num_items
-        self.ego = torch.cat([ue.weight.detach(), ie.weight.detach()], dim=0).to(self.device).contiguous()  # E0
+        dp = self.dp
+        self.ego = pad_columns(torch.cat([ue.weight.detach(), ie.weight.detach()], dim=0), dp).to(self.device).contiguous()  # E0
         self.optimizer = DenseAdam(self.ego.view(-1), lr=cfg.lr)
-        self._g_ego = self.optimizer.grad.view(N, 64)
-        z = lambda: torch.zeros((N, 64), dtype=torch.float32, device=self.device)  # noqa: E731
+        self._g_ego = self.optimizer.grad.view(N, dp)
+        z = lambda: torch.zeros((N, dp), dtype=torch.float32, device=self.device)  # noqa: E731
         self.final = z()          # layer mean, E-bar
         self._x = [z(), z()]      # propagation ping-pong
         self._g_final = z()       # dL/dE-bar, then H = dL/dE-bar / (K+1)
@@ -300,13 +366,13 @@ class LightGCN(AbstractRecommender):
     def user_embeddings(self):
         if self.engine is not None:
             return self.engine.gather_user_table()
-        return self.ego[:self.num_users]
+        return self.ego[:self.num_users, :self.config.embed_size]
 
     @property
     def item_embeddings(self):
         if self.engine is not None:
             return self.engine.item_rows
-        return self.ego[self.num_users:]
+        return self.ego[self.num_users:, :self.config.embed_size]
 
     def _load_adj_mat(self, adj_type):
         out_dir = os.path.join(self.dataset.data_dir, f"_{self.__class__.__name__}_data")
@@ -372,17 +438,17 @@ class LightGCN(AbstractRecommender):
                 self._row_mask = torch.zeros(self.num_users + self.num_items, dtype=torch.uint8, device=self.device)
                 gF.zero_()
             else:
-                _hip.check(_hip.lib().skr_clear_marked_rows(_hip.ptr(self._row_mask), self._row_mask.numel(), 1, _hip.ptr(gF), 64,
+                _hip.check(_hip.lib().skr_clear_marked_rows(_hip.ptr(self._row_mask), self._row_mask.numel(), 1, _hip.ptr(gF), self.dp,
                                                             _hip.stream()))
             rows = self._batch_rows(users, pos, neg)
         self.propagate(last_rows=rows)
         self._final_is_current = False
         # the score part of the gradient is written already divided by K + 1: gF holds H = dL/dE-bar / (K + 1)
-        _hip.check(_hip.lib().skr_bpr_step_sharded(
+        _hip.check(_hip.lib().skr_bpr_step_dim(
             _hip.ptr(self.final[:nu]), _hip.ptr(self.final[nu:]), None, _hip.ptr(self.ego[:nu]), _hip.ptr(self.ego[nu:]),
-            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), n, 1.0 / n, cfg.reg, 1.0 / cfg.batch_size,
-            _hip.ptr(gF[:nu]), _hip.ptr(gF[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot),
-            None, None, 1, 0, 1.0 / (K + 1), _hip.stream()))
+            _hip.ptr(users), _hip.ptr(pos), _hip.ptr(neg), n, self.dp, 1.0 / n, cfg.reg, 1.0 / cfg.batch_size,
+            _hip.ptr(gF[:nu]), _hip.ptr(gF[nu:]), None, _hip.ptr(gE[:nu]), _hip.ptr(gE[nu:]), _hip.ptr(loss_slot), 1,
+            None, None, 1.0 / (K + 1), _hip.stream()))
         # backward through the mean and the K propagations: dL/dE0 += sum_k (A^T)^k H
         x = gF
         for k in range(K):

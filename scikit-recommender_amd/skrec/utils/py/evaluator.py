@@ -124,8 +124,10 @@ class RankingEvaluator(object):
         else:
             self.max_top = int(max(top_k))
             self.top_show = np.sort(top_k)
-        if self.max_top > _hip.SKR_MAX_TOPK:
-            raise NotImplementedError(f"top_k up to {_hip.SKR_MAX_TOPK} is supported by the HIP kernels "
+        # the fused GEMM + top-K kernel ranks up to SKR_MAX_TOPK (128: the reference's default (10, ..., 100) fits); deeper lists
+        # go through the score-matrix path (skr_score_matrix / predict() -> skr_mask_train -> skr_eval_scores)
+        if self.max_top > _hip.SKR_MAX_TOPK_SCORES:
+            raise NotImplementedError(f"top_k up to {_hip.SKR_MAX_TOPK_SCORES} is supported by the HIP kernels "
                                       f"(got {self.max_top})")
 
     def set_train_data(self, user_train_dict: Optional[Dict[int, np.ndarray]] = None):
@@ -219,7 +221,7 @@ class RankingEvaluator(object):
         if factors is not None:
             ut, it, bias = factors
             n_items = int(it.shape[0])
-            fused_ok = (it.shape[1] == 64 and ut.shape[1] == 64 and n_items - st["max_train"] >= K)
+            fused_ok = (it.shape[1] == 64 and ut.shape[1] == 64 and n_items - st["max_train"] >= K and K <= _hip.SKR_MAX_TOPK)
         if factors is not None and fused_ok:
             # pass 1: top-K lists of every user, chunk after chunk without touching the host.  One more entry than needed
             # is asked for where possible (Kq = K + 1): with the (K+1)-th score in hand, a tie that exists ONLY between the

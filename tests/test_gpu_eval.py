@@ -23,7 +23,7 @@ def test_eval_scores_golden_cases(golden):
 
 
 @pytest.mark.parametrize("B,I,K", [(3, 5, 5), (4, 1000, 1), (5, 1024, 10), (2, 4097, 128), (7, 20000, 50),
-                                    (64, 100000, 10), (1, 2048, 100)])
+                                    (64, 100000, 10), (1, 2048, 100), (3, 5000, 300), (2, 100000, 512), (2, 600, 512), (3, 1500, 129)])
 def test_eval_scores_vs_oracle(B, I, K):
     from gpu_utils import eval_scores
     rng = np.random.default_rng(B * 1000 + I + K)
@@ -37,7 +37,7 @@ def test_eval_scores_vs_oracle(B, I, K):
     assert np.array_equal(rows.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("K,I", [(25, 3000), (1, 77), (10, 15), (128, 5000), (50, 100), (64, 64)])
+@pytest.mark.parametrize("K,I", [(25, 3000), (1, 77), (10, 15), (128, 5000), (50, 100), (64, 64), (400, 5000), (512, 700)])
 def test_eval_scores_ties_follow_the_reference_heap_order(K, I):
     """equal scores: the ids AND the metric rows are those of the reference's partial_sort_copy
     (libstdc++ heap order, evaluate.h:39-45) -- quantised scores, all-equal rows, ascending and descending
@@ -69,7 +69,7 @@ def test_eval_scores_argument_errors():
     with pytest.raises(ValueError):
         eval_scores(sc[:, :4], [[] for _ in range(6)], [1], 5)  # top_k > n_items
     with pytest.raises(ValueError):
-        eval_scores(sc, [[] for _ in range(6)], [1], 129)
+        eval_scores(sc, [[] for _ in range(6)], [1], 513)         # beyond SKR_MAX_TOPK_SCORES
 
 
 def test_rank_metrics_vs_oracle():
@@ -229,6 +229,36 @@ def test_fused_evaluator_reranks_structural_ties_in_reference_order(fused_mode):
     _, want, _ = O.ranking_evaluate(M().predict, train, test, metric=["Precision", "Recall", "MAP", "NDCG", "MRR"],
                                     top_k=[5, 10, 20], batch_size=32)
     np.testing.assert_allclose(np.array(list(got.values()), np.float32), want, rtol=1e-6, atol=0)   # fp32 mean order
+
+
+def test_evaluator_ranks_deeper_than_the_fused_kernel_through_the_score_matrix():
+    """top_k is a free integer in the reference (run_config.py:16).  Lists deeper than the fused kernel's 128, and factor
+    widths other than 64, go through the score-matrix path (predict() -> skr_mask_train -> skr_eval_scores): same report
+    as the oracle's evaluator loop"""
+    import torch
+    from skrec import _hip
+    from skrec.utils.py import RankingEvaluator
+    rng = np.random.default_rng(5)
+    nU, nI = 90, 700
+    train = {u: np.sort(rng.choice(nI, rng.integers(1, 40), replace=False)) for u in range(nU)}
+    test = {u: rng.choice(nI, rng.integers(1, 9), replace=False) for u in range(nU) if u % 3}
+    for width, top_k in ((64, (10, 200)), (128, (5, 50)), (128, 300)):
+        Ut = rng.integers(-3, 4, (nU, width)).astype(np.float32)
+        It = rng.integers(-3, 4, (nI, width)).astype(np.float32) + rng.permutation(nI).astype(np.float32)[:, None] / 1024   # no ties
+        dU, dI = torch.from_numpy(Ut).cuda(), torch.from_numpy(It).cuda()
+
+        class M(object):
+            def predict_factors(self):
+                return dU, dI, None
+
+            def predict(self, users):       # the models' predict(): skr_score_matrix at the factors' width
+                return _hip.score_matrix(dU, users, dI, None).cpu().numpy()
+        ev = RankingEvaluator(train, test, metric=["Precision", "Recall", "MAP", "NDCG", "MRR"], top_k=top_k, batch_size=32)
+        got = ev.evaluate(M())
+        ref = lambda us: (Ut[np.asarray(us)].astype(np.float64) @ It.T.astype(np.float64)).astype(np.float32)   # noqa: E731
+        _, want, _ = O.ranking_evaluate(ref, train, test, metric=["Precision", "Recall", "MAP", "NDCG", "MRR"], top_k=top_k,
+                                        batch_size=32)
+        np.testing.assert_allclose(np.array(list(got.values()), np.float32), want, rtol=1e-6, atol=0)
 
 
 def test_fused_evaluator_sees_a_tie_at_the_k_boundary(fused_mode):

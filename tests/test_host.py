@@ -116,7 +116,8 @@ def test_evaluator_bookkeeping():
     with pytest.raises(AssertionError):
         RankingEvaluator(None, {})
     with pytest.raises(NotImplementedError):
-        RankingEvaluator(None, {0: [1]}, top_k=500)
+        RankingEvaluator(None, {0: [1]}, top_k=513)
+    assert RankingEvaluator(None, {0: [1]}, top_k=500).max_top == 500      # beyond the fused kernel's 128: the score-matrix path
 
 
 def test_hot_path_fails_loudly_without_gpu():
