@@ -485,6 +485,35 @@ int skr_bpr_fused_block(float* d_p, float* d_m, float* d_v, int64_t n, float* d_
                         int k, float reg, float* d_loss64, int64_t loss_stride_floats, const int32_t* d_slot_block,
                         const int32_t* d_slot_fin, const int32_t* d_n_slots, const int32_t* d_tag_next, int32_t tag_next_value,
                         void* stream);
+/* The first naming of a row in a block costs the step launch the zero-gradient updates from the block's start to that step
+ * (16 on average at k = 32) -- on the critical path.  For the rows that were COLD in the block before (nearly every user
+ * row) these updates depend on nothing the block itself does, so they are made ahead of time, beside the previous block:
+ *   skr_bpr_fused_plan2   as skr_bpr_fused_plan; with d_tag_prev / tag_prev_value = the hot-block tags of the PREVIOUS block
+ *                         (skr_adam_block_mark) a first naming at a step > 0 of a row that block did not touch gets the
+ *                         value 7 in its word's n0 field: "the state waits in the pre buffer"
+ *   skr_bpr_fused_pre     fills d_pre (float [3][cap][64]: p, m, v by slot) for those rows from the dense tables, which
+ *                         must hold the state the block starts from for them (i.e. behind the previous block's cold
+ *                         pass; it never reads a row the previous block named).  step_t0 / k: the block's own.
+ *   skr_bpr_fused_step2 / _block2   as _step / _block, reading d_pre where a word says so (NULL if no word does).
+ * The same updates in the same arithmetic (the call the step launch would have made): bit-identical results. */
+int skr_bpr_fused_plan2(const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n_batch, int k, int64_t user_block0,
+                        int64_t item_block0, int64_t bias_block0, int64_t n_flat_blocks, void* d_scratch, int32_t* d_meta,
+                        int32_t* d_slot_block, int32_t* d_slot_fin, int32_t* d_n_slots, const int32_t* d_tag_prev,
+                        int32_t tag_prev_value, void* stream);
+int skr_bpr_fused_pre(const float* d_p, const float* d_m, const float* d_v, int64_t n, float* d_pre, int64_t cap,
+                      const int32_t* d_slot_block, const int32_t* d_slot_fin, const int32_t* d_n_slots, float lr, float beta1,
+                      float beta2, float eps, int64_t step_t0, int k, const int32_t* d_tag_prev, int32_t tag_prev_value,
+                      void* stream);
+int skr_bpr_fused_step2(const float* d_p, const float* d_m, const float* d_v, int64_t n, float* d_work, int64_t cap,
+                        const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch,
+                        int64_t user_block0, int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2,
+                        float eps, int64_t step_t0, int k, int s, float reg, float* d_loss64, const float* d_pre, void* stream);
+int skr_bpr_fused_block2(float* d_p, float* d_m, float* d_v, int64_t n, float* d_work, int64_t cap, const int32_t* d_u,
+                         const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch, int64_t user_block0,
+                         int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2, float eps,
+                         int64_t step_t0, int k, float reg, float* d_loss64, int64_t loss_stride_floats,
+                         const int32_t* d_slot_block, const int32_t* d_slot_fin, const int32_t* d_n_slots,
+                         const int32_t* d_tag_next, int32_t tag_next_value, const float* d_pre, void* stream);
 
 /* The cold pass sorts each 64-float block, by the values it starts from, into one of three exact evaluations of
  * the same k updates: AT REST (the update provably rounds to p + q == p for all k steps: only the moments decay),

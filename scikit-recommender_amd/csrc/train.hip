@@ -948,6 +948,7 @@ __global__ __launch_bounds__(256) void adam_hot_kernel(float* __restrict__ p, fl
 // (tests/test_gpu_train.py::test_fused_step_is_bit_identical).
 // ------------------------------------------------------------------------------------------------
 constexpr int FUSED_SLOT_BITS = 20;
+constexpr int FUSED_PRE = 7;     // value of a word's n0 field (n0 mod 6 otherwise): first naming, state waiting in the pre buffer
 
 struct FusedRow {
     float p, m, v, g;
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_fused_step_kernel(
     const float* __restrict__ P, const float* __restrict__ M, const float* __restrict__ V, int64_t n_par, FusedWork w,
     const int32_t* __restrict__ u_ids, const int32_t* __restrict__ i_ids, const int32_t* __restrict__ j_ids,
     const int32_t* __restrict__ meta, int n, int64_t ublk0, int64_t iblk0, int64_t bblk0, int s_now, AdamBlockArgs a,
-    float reg, float* __restrict__ loss, int loss_slots, int dbg) {
+    float reg, float* __restrict__ loss, int loss_slots, int dbg, const float* __restrict__ pre) {
     __shared__ float s_loss[BPR_WAVES], s_l2[BPR_WAVES];
     // dbg & 16: issue priority over the cold pass that shares the SIMDs (side stream).  Measured (bench.py, 200 steps): the
     // step +6 % (42.2 -> 44.9 M interactions/s) but the cold pass 0.47 -> 0.57 ms, which then bounds the block; off
@@ -1053,12 +1054,24 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_fused_step_kernel(
 #pragma unroll
         for (int r = 0; r < 5; ++r) mt[r] = __builtin_amdgcn_readfirstlane(meta[static_cast<int64_t>(r) * n + b]);
         FusedRow row[5];
+        int from[5];      // first zero-gradient index still to apply
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
             const int64_t slot = mt[r] & ((1 << FUSED_SLOT_BITS) - 1);
-            const int n0 = (mt[r] >> FUSED_SLOT_BITS) & 7;
+            int n0 = (mt[r] >> FUSED_SLOT_BITS) & 7;
             row[r] = FusedRow{1.0f, 0.0f, 0.0f, 0.0f};
-            if (((mt[r] >> 24) & 0x7f) == 0) {
+            from[r] = (mt[r] >> 24) & 0x7f;
+            if (n0 == FUSED_PRE) {
+                // the row's first naming in the block, and the row was cold in the block before: its zero-gradient updates up
+                // to this step were applied ahead of time, beside the previous block (bpr_fused_pre_kernel) -- same bits
+                const int64_t e = slot * 64 + lane;
+                row[r].p = pre[e];
+                row[r].m = pre[w.cap * 64 + e];
+                row[r].v = pre[2 * w.cap * 64 + e];
+                from[r] = s_now;
+                mt[r] &= ~(7 << FUSED_SLOT_BITS);        // n0 = 0 from here on
+                n0 = 0;
+            } else if (((mt[r] >> 24) & 0x7f) == 0) {
                 const int64_t e = blk[r] * 64 + lane;
                 if (e < n_par) {
                     row[r].p = P[e];
@@ -1077,7 +1090,7 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_fused_step_kernel(
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const int prev1 = (mt[r] >> 24) & 0x7f;
-                fused_advance(row[r], prev1 - 1, prev1, s_now, a);
+                fused_advance(row[r], prev1 - 1, from[r], s_now, a);
             }
         }
         if (!(dbg & 4)) {
@@ -1143,8 +1156,36 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_fused_step_kernel(
     }
 }
 
+// Ahead of a block, beside the block before it (side stream, behind that block's cold pass): the rows the block names that
+// were COLD in the previous block -- nearly every user row -- are advanced from the block's first index to the step of their
+// first naming, into the pre buffer ([3][cap][64]: p, m, v).  These zero-gradient updates depend on nothing the block
+// itself does; the step launch that first names such a row then finds it current and spends nothing on catching up
+// (16 updates on average at k = 32, on the critical path of the step before).  The same fused_advance call the step
+// would have made: the same bits.
+__global__ __launch_bounds__(256) void bpr_fused_pre_kernel(const float* __restrict__ P, const float* __restrict__ M,
+                                                            const float* __restrict__ V, int64_t n_par, float* __restrict__ pre,
+                                                            int64_t cap, const int32_t* __restrict__ slot_blk,
+                                                            const int32_t* __restrict__ slot_fin, const int32_t* __restrict__ n_slots,
+                                                            AdamBlockArgs a, const int32_t* __restrict__ tag_prev,
+                                                            int32_t tag_prev_value) {
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= *n_slots) return;
+    const int64_t blk = slot_blk[slot];
+    const int first = (slot_fin[slot] >> 16) & 0xff;
+    if (first == 0 || tag_prev[blk] == tag_prev_value) return;       // nothing to catch up / the previous block still owns the row
+    const int64_t e = blk * 64 + lane;
+    FusedRow r{1.0f, 0.0f, 0.0f, 0.0f};
+    if (e < n_par) { r.p = P[e]; r.m = M[e]; r.v = V[e]; }
+    fused_advance(r, -1, 0, first, a);
+    const int64_t o = slot * 64 + lane;
+    pre[o] = r.p;
+    pre[cap * 64 + o] = r.m;
+    pre[2 * cap * 64 + o] = r.v;
+}
+
 // end of a k-step block: every slot is brought to the block's last index and written back; its gradient buffers are
-// left zero for the next block.  fin = (number of namings mod 6) | (step of the last naming << 8)
+// left zero for the next block.  fin = (number of namings mod 6) | (step of the last naming << 8) | (step of the first << 16)
 __global__ __launch_bounds__(256) void bpr_fused_end_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
                                                             int64_t n_par, FusedWork w, const int32_t* __restrict__ slot_blk,
                                                             const int32_t* __restrict__ slot_fin,
@@ -1157,7 +1198,7 @@ __global__ __launch_bounds__(256) void bpr_fused_end_kernel(float* __restrict__ 
     // which = 1: only the rows the NEXT block touches too (it must find them in the dense tables); 2: only the others (they
     // can be written back beside the next block's steps); 0: all
     if (which != 0 && ((tag_next[blk] == tag_next_value) != (which == 1))) return;
-    const int fin = slot_fin[slot], nn = fin & 7, last = fin >> 8;
+    const int fin = slot_fin[slot], nn = fin & 7, last = (fin >> 8) & 0xff;
     FusedRow r;
     {
         const int64_t e = ((nn & 1) * w.cap + slot) * 64 + lane;
@@ -1189,6 +1230,8 @@ struct FusedPlanArgs {
     int64_t ublk0, iblk0, bblk0;
     unsigned long long *named, *claimed, *shared;
     int32_t *slot_of, *meta, *slot_block, *slot_fin, *n_slots;
+    const int32_t* tag_prev;      // hot-block tags of the block BEFORE this one (NULL: no row is pre-advanced)
+    int32_t tag_prev_value;
 };
 
 __device__ __forceinline__ void fused_plan_refs(const FusedPlanArgs& a, int64_t t, int64_t blk[5]) {
@@ -1225,13 +1268,15 @@ __global__ __launch_bounds__(256) void fused_plan_kernel(FusedPlanArgs a) {
                 const int slot = atomicAdd(a.n_slots, 1);
                 a.slot_of[blk[r]] = slot;
                 a.slot_block[slot] = static_cast<int32_t>(blk[r]);
-                a.slot_fin[slot] = (__popcll(mask) % 6) | ((63 - __clzll(static_cast<long long>(mask))) << 8);
+                a.slot_fin[slot] = (__popcll(mask) % 6) | ((63 - __clzll(static_cast<long long>(mask))) << 8) | (s << 16);
             }
         } else if (PASS == 2) {
             const unsigned long long below = a.named[blk[r]] & (bit - 1);
             const int n0 = __popcll(below), prev1 = below ? 64 - __clzll(static_cast<long long>(below)) : 0;
             const int sole = (a.shared[blk[r]] & bit) ? 0 : 1;                // the pair's only reference (bit 31)
-            a.meta[e] = a.meta[e] | a.slot_of[blk[r]] | ((n0 % 6) << FUSED_SLOT_BITS) | (prev1 << 24) |
+            // a first naming at step s > 0 of a row the previous block did not touch: bpr_fused_pre_kernel catches it up
+            const bool pre = a.tag_prev && below == 0 && s > 0 && a.tag_prev[blk[r]] != a.tag_prev_value;
+            a.meta[e] = a.meta[e] | a.slot_of[blk[r]] | ((pre ? FUSED_PRE : n0 % 6) << FUSED_SLOT_BITS) | (prev1 << 24) |
                         static_cast<int32_t>(static_cast<uint32_t>(sole) << 31);
         } else {
             a.named[blk[r]] = 0;
@@ -1887,6 +1932,14 @@ int skr_bpr_fused_step(const float* d_p, const float* d_m, const float* d_v, int
                        const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch,
                        int64_t user_block0, int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2,
                        float eps, int64_t step_t0, int k, int s, float reg, float* d_loss64, void* stream) {
+    return skr_bpr_fused_step2(d_p, d_m, d_v, n, d_work, cap, d_u, d_i, d_j, d_meta, n_batch, user_block0, item_block0, bias_block0, lr,
+                               beta1, beta2, eps, step_t0, k, s, reg, d_loss64, nullptr, stream);
+}
+
+int skr_bpr_fused_step2(const float* d_p, const float* d_m, const float* d_v, int64_t n, float* d_work, int64_t cap,
+                        const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch,
+                        int64_t user_block0, int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2,
+                        float eps, int64_t step_t0, int k, int s, float reg, float* d_loss64, const float* d_pre, void* stream) {
     SKR_REQUIRE(d_p && d_m && d_v && d_work && d_u && d_i && d_j && d_meta && d_loss64, "skr_bpr_fused_step: NULL argument");
     SKR_REQUIRE(n >= 0 && n_batch >= 0 && cap >= 1 && cap <= (1 << FUSED_SLOT_BITS), "skr_bpr_fused_step: need 1 <= cap <= 2^%d",
                 FUSED_SLOT_BITS);
@@ -1899,7 +1952,7 @@ int skr_bpr_fused_step(const float* d_p, const float* d_m, const float* d_v, int
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bpr_fused_step_kernel, dim3(blocks), dim3(BPR_WAVES * 64), 0, skr::as_stream(stream), d_p, d_m, d_v, n,
                        fused_work(d_work, cap), d_u, d_i, d_j, d_meta, n_batch, user_block0, item_block0, bias_block0, s, a, reg,
-                       d_loss64, SKR_LOSS_SLOTS, dbg);
+                       d_loss64, SKR_LOSS_SLOTS, dbg, d_pre);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
@@ -1907,6 +1960,14 @@ int skr_bpr_fused_step(const float* d_p, const float* d_m, const float* d_v, int
 int skr_bpr_fused_plan(const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n_batch, int k, int64_t user_block0,
                        int64_t item_block0, int64_t bias_block0, int64_t n_flat_blocks, void* d_scratch, int32_t* d_meta,
                        int32_t* d_slot_block, int32_t* d_slot_fin, int32_t* d_n_slots, void* stream) {
+    return skr_bpr_fused_plan2(d_u, d_i, d_j, n_batch, k, user_block0, item_block0, bias_block0, n_flat_blocks, d_scratch, d_meta,
+                               d_slot_block, d_slot_fin, d_n_slots, nullptr, 0, stream);
+}
+
+int skr_bpr_fused_plan2(const int32_t* d_u, const int32_t* d_i, const int32_t* d_j, int n_batch, int k, int64_t user_block0,
+                        int64_t item_block0, int64_t bias_block0, int64_t n_flat_blocks, void* d_scratch, int32_t* d_meta,
+                        int32_t* d_slot_block, int32_t* d_slot_fin, int32_t* d_n_slots, const int32_t* d_tag_prev,
+                        int32_t tag_prev_value, void* stream) {
     SKR_REQUIRE(d_u && d_i && d_j && d_scratch && d_meta && d_slot_block && d_slot_fin && d_n_slots, "skr_bpr_fused_plan: NULL argument");
     SKR_REQUIRE(n_batch >= 1 && k >= 1 && k <= AB_KMAX && static_cast<int64_t>(k) * 5 * n_batch <= (1 << FUSED_SLOT_BITS),
                 "skr_bpr_fused_plan: need 1 <= k <= %d and k * 5 * n_batch <= 2^%d", AB_KMAX, FUSED_SLOT_BITS);
@@ -1922,11 +1983,34 @@ int skr_bpr_fused_plan(const int32_t* d_u, const int32_t* d_i, const int32_t* d_
     a.shared = a.claimed + n_flat_blocks;
     a.slot_of = reinterpret_cast<int32_t*>(a.shared + n_flat_blocks);
     a.meta = d_meta, a.slot_block = d_slot_block, a.slot_fin = d_slot_fin, a.n_slots = d_n_slots;
+    a.tag_prev = d_tag_prev, a.tag_prev_value = tag_prev_value;
     const dim3 grid(static_cast<unsigned>((static_cast<int64_t>(k) * n_batch + 255) / 256)), wg(256);
     hipLaunchKernelGGL(fused_plan_kernel<0>, grid, wg, 0, skr::as_stream(stream), a);
     hipLaunchKernelGGL(fused_plan_kernel<1>, grid, wg, 0, skr::as_stream(stream), a);
     hipLaunchKernelGGL(fused_plan_kernel<2>, grid, wg, 0, skr::as_stream(stream), a);
     hipLaunchKernelGGL(fused_plan_kernel<3>, grid, wg, 0, skr::as_stream(stream), a);
+    SKR_LAUNCH_CHECK();
+    return SKR_OK;
+}
+
+int skr_bpr_fused_pre(const float* d_p, const float* d_m, const float* d_v, int64_t n, float* d_pre, int64_t cap,
+                      const int32_t* d_slot_block, const int32_t* d_slot_fin, const int32_t* d_n_slots, float lr, float beta1,
+                      float beta2, float eps, int64_t step_t0, int k, const int32_t* d_tag_prev, int32_t tag_prev_value,
+                      void* stream) {
+    SKR_REQUIRE(d_p && d_m && d_v && d_pre && d_slot_block && d_slot_fin && d_n_slots && d_tag_prev, "skr_bpr_fused_pre: NULL argument");
+    SKR_REQUIRE(n >= 0 && cap >= 1 && cap <= (1 << FUSED_SLOT_BITS), "skr_bpr_fused_pre: need 1 <= cap <= 2^%d", FUSED_SLOT_BITS);
+    SKR_REQUIRE(step_t0 >= 0 && k >= 1 && k <= AB_KMAX, "skr_bpr_fused_pre: need 1 <= k <= %d", AB_KMAX);
+    // (scalars of its own: this runs on another stream than the block's steps, one block ahead of them)
+    AdamBlockArgs a{};
+    a.one_minus_b1 = static_cast<float>(1.0 - static_cast<double>(beta1));
+    a.b2 = beta2;
+    a.one_minus_b2 = static_cast<float>(1.0 - static_cast<double>(beta2));
+    a.eps = eps;
+    a.k = k;
+    adam_block_scalars(a, lr, beta1, beta2, step_t0, k, false);
+    adam_block_thresholds(a, lr, beta1, beta2, eps, k);
+    hipLaunchKernelGGL(bpr_fused_pre_kernel, dim3(static_cast<unsigned>((cap + 3) / 4)), dim3(256), 0, skr::as_stream(stream), d_p, d_m,
+                       d_v, n, d_pre, cap, d_slot_block, d_slot_fin, d_n_slots, a, d_tag_prev, tag_prev_value);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
@@ -1951,12 +2035,23 @@ int skr_bpr_fused_block(float* d_p, float* d_m, float* d_v, int64_t n, float* d_
                         int k, float reg, float* d_loss64, int64_t loss_stride_floats, const int32_t* d_slot_block,
                         const int32_t* d_slot_fin, const int32_t* d_n_slots, const int32_t* d_tag_next, int32_t tag_next_value,
                         void* stream) {
+    return skr_bpr_fused_block2(d_p, d_m, d_v, n, d_work, cap, d_u, d_i, d_j, d_meta, n_batch, user_block0, item_block0, bias_block0, lr,
+                                beta1, beta2, eps, step_t0, k, reg, d_loss64, loss_stride_floats, d_slot_block, d_slot_fin, d_n_slots,
+                                d_tag_next, tag_next_value, nullptr, stream);
+}
+
+int skr_bpr_fused_block2(float* d_p, float* d_m, float* d_v, int64_t n, float* d_work, int64_t cap, const int32_t* d_u,
+                         const int32_t* d_i, const int32_t* d_j, const int32_t* d_meta, int n_batch, int64_t user_block0,
+                         int64_t item_block0, int64_t bias_block0, float lr, float beta1, float beta2, float eps, int64_t step_t0,
+                         int k, float reg, float* d_loss64, int64_t loss_stride_floats, const int32_t* d_slot_block,
+                         const int32_t* d_slot_fin, const int32_t* d_n_slots, const int32_t* d_tag_next, int32_t tag_next_value,
+                         const float* d_pre, void* stream) {
     SKR_REQUIRE(k >= 1 && k <= AB_KMAX && n_batch >= 0 && loss_stride_floats >= 0, "skr_bpr_fused_block: bad shape");
     for (int s = 0; s < k; ++s) {
         const int64_t o = static_cast<int64_t>(s) * n_batch;
-        const int rc = skr_bpr_fused_step(d_p, d_m, d_v, n, d_work, cap, d_u + o, d_i + o, d_j + o, d_meta + 5 * o, n_batch, user_block0,
-                                          item_block0, bias_block0, lr, beta1, beta2, eps, step_t0, k, s, reg,
-                                          d_loss64 + s * loss_stride_floats, stream);
+        const int rc = skr_bpr_fused_step2(d_p, d_m, d_v, n, d_work, cap, d_u + o, d_i + o, d_j + o, d_meta + 5 * o, n_batch, user_block0,
+                                           item_block0, bias_block0, lr, beta1, beta2, eps, step_t0, k, s, reg,
+                                           d_loss64 + s * loss_stride_floats, d_pre, stream);
         if (rc != SKR_OK) return rc;
     }
     return skr_bpr_fused_end(d_p, d_m, d_v, n, d_work, cap, d_slot_block, d_slot_fin, d_n_slots, lr, beta1, beta2, eps, step_t0, k,

@@ -46,6 +46,12 @@ SIGNATURES = {
                                  f32, vp, vp]),
     "skr_bpr_fused_block": (i32, [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i32, i64, i64, i64, f32, f32, f32, f32, i64, i32, f32, vp,
                                   i64, vp, vp, vp, vp, i32, vp]),
+    "skr_bpr_fused_plan2": (i32, [vp, vp, vp, i32, i32, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "skr_bpr_fused_pre": (i32, [vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, f32, f32, f32, i64, i32, vp, i32, vp]),
+    "skr_bpr_fused_step2": (i32, [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i32, i64, i64, i64, f32, f32, f32, f32, i64, i32, i32,
+                                  f32, vp, vp, vp]),
+    "skr_bpr_fused_block2": (i32, [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i32, i64, i64, i64, f32, f32, f32, f32, i64, i32, f32, vp,
+                                   i64, vp, vp, vp, vp, i32, vp, vp]),
     "skr_bpr_fused_end": (i32, [vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, f32, f32, f32, i64, i32, vp, i32, i32, vp]),
     "skr_host_permutation": (i32, [vp, C.POINTER(i32), i64, vp]),
     "skr_shuffle_gather": (i32, [vp, u64, i64, i64, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), vp]),

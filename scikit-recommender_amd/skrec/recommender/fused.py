@@ -16,7 +16,7 @@ from .. import _hip
 SLOT_BITS = 20
 
 
-def build_fused_meta(cu, ci, cj, n_blocks, k, bsz, user_block0, item_block0, bias_block0, chunk_blocks=64):
+def build_fused_meta(cu, ci, cj, n_blocks, k, bsz, user_block0, item_block0, bias_block0, chunk_blocks=64, prev_hot=None):
     """The words ``skr_bpr_fused_plan`` writes, derived independently with sorts and scans (tests compare the two, modulo
     the numbering of the slots).  cu / ci / cj: the epoch's int32 columns (step-major, contiguous); the first n_blocks * k * bsz entries are the full
     blocks.  Returns (meta [n_blocks, k, 5, bsz] int32, slot_block [n_blocks, L] int32 (-1 padded), slot_fin [n_blocks, L]
@@ -54,7 +54,11 @@ def build_fused_meta(cu, ci, cj, n_blocks, k, bsz, user_block0, item_block0, bia
         prev_step = torch.gather(stp, 1, (pair_start - 1).clamp_(min=0))
         first_naming = torch.gather(new_row, 1, pair_start)
         prev1 = torch.where(first_naming, zero, prev_step + 1)
-        word = slot | ((n0 % 6) << SLOT_BITS) | (new_pair.long() << 23) | (prev1 << 24)
+        n0f = n0 % 6
+        if prev_hot is not None:      # [n_blocks, n_flat_blocks] bool: the rows the block BEFORE named (skr_bpr_fused_plan2)
+            cold_before = ~torch.gather(prev_hot[b0:b1], 1, blk)
+            n0f = torch.where((n0 == 0) & (stp > 0) & cold_before, torch.full_like(n0f, 7), n0f)
+        word = slot | (n0f << SLOT_BITS) | (new_pair.long() << 23) | (prev1 << 24)
         meta[b0:b1].scatter_(1, perm, word.int())
         # per slot: its block of the flat buffer; number of namings and the step of the last one
         sb = torch.full((nb, L + 1), -1, dtype=torch.int32, device=dev)
@@ -64,7 +68,9 @@ def build_fused_meta(cu, ci, cj, n_blocks, k, bsz, user_block0, item_block0, bia
         row_last[:, :-1] = new_row[:, 1:]
         sf = torch.zeros((nb, L + 1), dtype=torch.int32, device=dev)
         sf.scatter_(1, torch.where(row_last, slot, torch.full_like(slot, L)), (((n0 + 1) % 6) | (stp << 8)).int())
-        slot_fin[b0:b1] = sf[:, :L]
+        sf1 = torch.zeros((nb, L + 1), dtype=torch.int32, device=dev)        # ... | (step of the first naming << 16)
+        sf1.scatter_(1, torch.where(new_row, slot, torch.full_like(slot, L)), (stp << 16).int())
+        slot_fin[b0:b1] = (sf | sf1)[:, :L]
         n_slots[b0:b1] = (slot[:, -1] + 1).int()
     return meta.view(n_blocks, k, 5, bsz), slot_block, slot_fin, n_slots
 
@@ -98,6 +104,11 @@ class FusedBlocks(object):
         self.tags = torch.zeros((2, self.n_flat_blocks), dtype=torch.int32, device=dev)
         self.serial = 0
         self.split_end = os.environ.get("SKR_FUSED_SPLIT_END", "0") == "1"
+        # the zero-gradient updates a row needs before its FIRST naming in a block are made one block ahead, on the optimiser's
+        # side stream behind the previous block's cold pass, for the rows that block did not touch (skr_bpr_fused_pre);
+        # SKR_FUSED_PRE=0: the step launch that first names a row catches it up itself
+        self.pre_advance = os.environ.get("SKR_FUSED_PRE", "1") != "0"
+        self._ev_pre = [torch.cuda.Event(), torch.cuda.Event()]
         self._plan_stream = torch.cuda.Stream(device=dev)
         self._ev_plan = [torch.cuda.Event(), torch.cuda.Event()]
         self._ev_done = [torch.cuda.Event(), torch.cuda.Event()]
@@ -114,10 +125,12 @@ class FusedBlocks(object):
             self.work = torch.zeros((2 if self.split_end else 1, 9 * cap * 64), dtype=torch.float32, device=dev)
             self.meta, self.slot_block, self.slot_fin = (torch.empty((2, cap), dtype=torch.int32, device=dev) for _ in range(3))
             self.n_slots = torch.zeros((2, 1), dtype=torch.int32, device=dev)
+            self.pre = torch.zeros((2, 3 * cap * 64), dtype=torch.float32, device=dev) if self.pre_advance else None
             self._used = [False, False]
 
-    def _plan(self, q, pu, pi, pj, k, bsz, serial):
-        """words, slot tables and hot-block tags of one block into set q, on the planning stream"""
+    def _plan(self, q, pu, pi, pj, k, bsz, serial, prev=None):
+        """words, slot tables and hot-block tags of one block into set q, on the planning stream; ``prev`` = (tags, value) of
+        the block before it: first namings of rows that block did not touch are marked as pre-advanced"""
         u0, i0, b0 = self.offsets
         ps, L = self._plan_stream, _hip.lib()
         if self._used[q]:
@@ -125,9 +138,10 @@ class FusedBlocks(object):
         # the tags of set q were last read by the cold pass of the set's previous block (and by the write-backs of the
         # block before that one, which sit in front of it on the side stream)
         ps.wait_event(self.opt._ev_cold)
-        rc = L.skr_bpr_fused_plan(pu, pi, pj, bsz, k, u0, i0, b0, self.n_flat_blocks, self.scratch.data_ptr(),
-                                  self.meta[q].data_ptr(), self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(),
-                                  self.n_slots[q].data_ptr(), ps.cuda_stream)
+        rc = L.skr_bpr_fused_plan2(pu, pi, pj, bsz, k, u0, i0, b0, self.n_flat_blocks, self.scratch.data_ptr(),
+                                   self.meta[q].data_ptr(), self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(),
+                                   self.n_slots[q].data_ptr(), prev[0].data_ptr() if prev else None, prev[1] if prev else 0,
+                                   ps.cuda_stream)
         rc |= L.skr_adam_block_mark(self.slot_block[q].data_ptr(), k * 5 * bsz, 0, 64, self.tags[q].data_ptr(), serial, None,
                                     self.opt.t, ps.cuda_stream)
         if rc:
@@ -158,15 +172,30 @@ class FusedBlocks(object):
         for blk in range(n_blocks):
             q, o = blk & 1, blk * blk_bytes
             more = blk + 1 < n_blocks
+            pre_next = more and self.pre_advance
             if more:
-                self._plan(q ^ 1, pu + o + blk_bytes, pi + o + blk_bytes, pj + o + blk_bytes, k, bsz, serial0 + blk + 1)
+                self._plan(q ^ 1, pu + o + blk_bytes, pi + o + blk_bytes, pj + o + blk_bytes, k, bsz, serial0 + blk + 1,
+                           prev=(self.tags[q], serial0 + blk) if pre_next else None)
             cur.wait_event(self._ev_plan[q])      # this block's words and tags
             cur.wait_event(opt._ev_cold)          # the previous cold pass wrote rows this block may read
+            pre_now = blk > 0 and self.pre_advance
+            if pre_now:
+                cur.wait_event(self._ev_pre[q])   # ... and the rows advanced ahead of this block are in its pre buffer
             if self._used[q]:
                 cur.wait_event(self._ev_done[q])  # the set's workspace: its previous block's leftovers are written back
             side.wait_event(self._ev_plan[q])
             opt.launch_cold(self.tags[q], serial0 + blk, k)          # behind the previous block's write-back on that stream
             t0 = opt.t
+            if pre_next:
+                # behind this block's cold pass, beside its steps: the next block's first namings of rows this block does not touch
+                side.wait_event(self._ev_plan[q ^ 1])
+                rc_pre = L.skr_bpr_fused_pre(pp, pm, pv, n_par, self.pre[q ^ 1].data_ptr(), cap, self.slot_block[q ^ 1].data_ptr(),
+                                             self.slot_fin[q ^ 1].data_ptr(), self.n_slots[q ^ 1].data_ptr(), lr, b1, b2, eps, t0 + k, k,
+                                             self.tags[q].data_ptr(), serial0 + blk, side.cuda_stream)
+                if rc_pre:
+                    _hip.check(rc_pre)
+                self._ev_pre[q ^ 1].record(side)
+            ppre = self.pre[q].data_ptr() if pre_now else None
             split = more and self.split_end
             if split:
                 cur.wait_event(self._ev_plan[q ^ 1])                 # the next block's tags decide what is written back where
@@ -182,17 +211,18 @@ class FusedBlocks(object):
                 bt = None
             trip = self.block_event_pool.pop() if (bt is not None and getattr(self, "block_event_pool", None)) else None
             if trip is None:
-                rc = L.skr_bpr_fused_block(pp, pm, pv, n_par, pw, cap, pu + o, pi + o, pj + o, self.meta[q].data_ptr(), bsz, u0, i0, b0,
-                                           lr, b1, b2, eps, t0, k, reg, ploss + blk * k * loss_stride_bytes, loss_stride_bytes // 4,
-                                           self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(), self.n_slots[q].data_ptr(),
-                                           ptag, serial0 + blk + 1, st)
+                rc = L.skr_bpr_fused_block2(pp, pm, pv, n_par, pw, cap, pu + o, pi + o, pj + o, self.meta[q].data_ptr(), bsz, u0, i0, b0,
+                                            lr, b1, b2, eps, t0, k, reg, ploss + blk * k * loss_stride_bytes, loss_stride_bytes // 4,
+                                            self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(), self.n_slots[q].data_ptr(),
+                                            ptag, serial0 + blk + 1, ppre, st)
             else:
                 rc, pmeta = 0, self.meta[q].data_ptr()
                 trip[0].record(cur)
                 for s_ in range(k):
                     os_ = o + 4 * s_ * bsz
-                    rc |= L.skr_bpr_fused_step(pp, pm, pv, n_par, pw, cap, pu + os_, pi + os_, pj + os_, pmeta + 20 * s_ * bsz, bsz, u0,
-                                               i0, b0, lr, b1, b2, eps, t0, k, s_, reg, ploss + (blk * k + s_) * loss_stride_bytes, st)
+                    rc |= L.skr_bpr_fused_step2(pp, pm, pv, n_par, pw, cap, pu + os_, pi + os_, pj + os_, pmeta + 20 * s_ * bsz, bsz, u0,
+                                                i0, b0, lr, b1, b2, eps, t0, k, s_, reg, ploss + (blk * k + s_) * loss_stride_bytes,
+                                                ppre, st)
                 trip[1].record(cur)
                 rc |= L.skr_bpr_fused_end(pp, pm, pv, n_par, pw, cap, self.slot_block[q].data_ptr(), self.slot_fin[q].data_ptr(),
                                           self.n_slots[q].data_ptr(), lr, b1, b2, eps, t0, k, ptag, serial0 + blk + 1,

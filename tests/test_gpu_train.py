@@ -563,6 +563,23 @@ def test_fused_plan_matches_the_sort_based_derivation(k, b, nU, nI):
     # "sole": exactly the references whose (step, row) pair occurs once
     _, inv, cnt = np.unique(pair, return_inverse=True, return_counts=True)
     assert np.array_equal(sole == 1, cnt[inv] == 1)
+    # skr_bpr_fused_plan2 with the previous block's tags: first namings at a step > 0 of rows that block did not touch carry
+    # 7 in the n0 field ("pre-advanced"), every other word is unchanged
+    prev_hot = torch.from_numpy(rng.random(nfb) < 0.4).cuda()
+    tags = torch.where(prev_hot, torch.full((nfb,), 9, dtype=torch.int32, device="cuda"), torch.full((nfb,), 4, dtype=torch.int32, device="cuda"))
+    meta2 = torch.full((n_ref,), -7, dtype=torch.int32, device="cuda")
+    _hip.check(L.skr_bpr_fused_plan2(_hip.ptr(u), _hip.ptr(i), _hip.ptr(j), b, k, 0, nU, nU + nI, nfb, _hip.ptr(scratch),
+                                     _hip.ptr(meta2), _hip.ptr(sb), _hip.ptr(sf), _hip.ptr(ns), _hip.ptr(tags), 9, st()))
+    torch.cuda.synchronize()
+    wm2, _, _, _ = build_fused_meta(u, i, j, 1, k, b, 0, nU, nU + nI, prev_hot=prev_hot.view(1, -1))
+    got2, want2 = meta2.cpu().numpy().astype(np.int64) & 0x7fffffff, wm2.reshape(-1).cpu().numpy().astype(np.int64)
+    assert np.array_equal((got2 >> 20) & 7, (want2 >> 20) & 7) and np.array_equal(got2 >> 24, want2 >> 24)
+    flagged = ((got2 >> 20) & 7) == 7
+    first = ((want >> 24) == 0) & (((want >> 20) & 7) == 0)                         # first namings (n0 = 0, no previous step)
+    blk_of = sb.cpu().numpy()[got2 & 0xfffff]
+    assert np.array_equal(flagged, first & (step > 0) & ~prev_hot.cpu().numpy()[blk_of]) and (flagged.any() or k == 1)
+    # (bit 23, the owner among a pair's references, is decided by an atomic: it may fall on another reference in another call)
+    assert np.array_equal((got2[~flagged] >> 20) & ~8, (got[~flagged] >> 20) & ~8)
 
 
 @pytest.mark.gpu
