@@ -884,7 +884,10 @@ __global__ void pop_sample_kernel(const double* __restrict__ cumsum, int n_items
         z ^= z >> 31;
         u = static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0);     // 53 random bits -> [0, 1)
     }
-    int lo = 0, hi = n_items;      // lower_bound
+    // lower_bound over [0, n_items - 1]: a cumulative sum in float64 may end a few ulps below 1.0, and a uniform above it
+    // would otherwise yield n_items -- an id the reference answers with an IndexError at its gather and that would be an
+    // out-of-range row here; the last item takes those draws
+    int lo = 0, hi = n_items - 1;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (cumsum[mid] < u) lo = mid + 1; else hi = mid;

@@ -207,6 +207,9 @@ def shuffle_gather(columns, perm=None, seed=0, n_out=None):
     import torch
     n = int(columns[0].shape[0])
     n_out = n if n_out is None else int(n_out)
+    if perm is not None:      # the kernel reads int32 indices and trusts them
+        assert perm.dtype == torch.int32 and perm.is_contiguous() and perm.numel() >= n_out, \
+            "shuffle_gather: perm must be a contiguous int32 tensor with at least n_out entries"
     outs = []
     for s in range(0, len(columns), 4):
         cols = columns[s:s + 4]

@@ -116,14 +116,19 @@ class FusedBlocks(object):
         self._used = [False, False]
 
     def _size(self, k, bsz):
-        cap = k * 5 * bsz
-        if cap > self.cap:
+        # the workspace is indexed by slot = distinct row of the block: at most one per reference (k * 5 * bsz) and at most one
+        # per 64-float block of the flat buffer.  9 planes of cap * 256 B (+ 6 with the pre buffers): 380 MB at k = 32,
+        # b = 1 024 -- SKR_ADAM_BLOCK / the batch size set it
+        cap = min(k * 5 * bsz, self.n_flat_blocks)
+        self.refs = k * 5 * bsz
+        if cap > self.cap or self.refs > getattr(self, "_refs_cap", 0):
             dev = self.opt.flat.device
             torch.cuda.synchronize(dev)               # nothing in flight refers to the buffers that are replaced
-            self.cap = cap
+            self.cap, self._refs_cap = max(cap, self.cap), max(self.refs, getattr(self, "_refs_cap", 0))
+            cap = self.cap
             # zero: the invariant between blocks.  One workspace unless a block's leftovers are written back beside the next block
             self.work = torch.zeros((2 if self.split_end else 1, 9 * cap * 64), dtype=torch.float32, device=dev)
-            self.meta, self.slot_block, self.slot_fin = (torch.empty((2, cap), dtype=torch.int32, device=dev) for _ in range(3))
+            self.meta, self.slot_block, self.slot_fin = (torch.empty((2, self._refs_cap), dtype=torch.int32, device=dev) for _ in range(3))
             self.n_slots = torch.zeros((2, 1), dtype=torch.int32, device=dev)
             self.pre = torch.zeros((2, 3 * cap * 64), dtype=torch.float32, device=dev) if self.pre_advance else None
             self._used = [False, False]

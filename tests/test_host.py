@@ -281,7 +281,7 @@ def test_fused_step_words_on_the_host():
     j = rng.integers(0, nI, k * b).astype(np.int32)
     meta, slot_block, slot_fin, n_slots = build_fused_meta(torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(j), 1, k, b, 0, nU, nU + nI)
     meta, slot_block, slot_fin = meta[0].numpy().astype(np.int64), slot_block[0].numpy(), slot_fin[0].numpy()
-    seen, last = {}, {}                                # row -> namings so far / last naming step
+    seen, last, first = {}, {}, {}                     # row -> namings so far / last naming step / first naming step
     owners = set()
     for s in range(k):
         sl = slice(s * b, (s + 1) * b)
@@ -301,8 +301,9 @@ def test_fused_step_words_on_the_host():
         for row in named_now:
             seen[row] = seen.get(row, 0) + 1
             last[row] = s
+            first.setdefault(row, s)
     n = int(n_slots[0])
     assert n == len(seen) and sorted(slot_block[:n]) == sorted(seen) and (slot_block[n:] == -1).all()
     for slot in range(n):
         row = int(slot_block[slot])
-        assert slot_fin[slot] == (seen[row] % 6) | (last[row] << 8)
+        assert slot_fin[slot] == (seen[row] % 6) | (last[row] << 8) | (first[row] << 16)
