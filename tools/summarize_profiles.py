@@ -43,7 +43,7 @@ for fname, counters in (("l2", ("TCC_HIT_sum", "TCC_MISS_sum")), ("tcp", ("TCP_T
         continue
     for r in csv.DictReader(open(pth)):
         extra.setdefault(short(r["Kernel_Name"]), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k in ("adam_cold_rows_kernel<4>", "adam_cold_kernel<2>", "adam_hot_kernel", "bpr_fused_step_kernel", "bpr_fused_end_kernel",
+for k in ("adam_cold_rows_kernel<4>", "adam_cold_kernel<2>", "adam_hot_kernel", "bpr_fused_step_kernel", "bpr_fused_end_kernel", "bpr_fused_pre_kernel", "bpr_step_kernel<1>", "clear_marked_rows_kernel",
           "fused_plan_kernel<0>", "fused_plan_kernel<1>", "fused_plan_kernel<2>", "fused_plan_kernel<3>", "adam_kernel<true, 4, true>", "fused_topk_kernel_v5<true>", "fused_topk_kernel_v4<true>", "fused_topk_kernel_v3<true>", "split_items_kernel",
           "bpr_step_kernel", "exact_assign_kernel<false>", "mt_generate_kernel", "slab_detect_kernel", "slab_resolve_kernel", "slab_scatter_kernel",
           "shuffle_gather_kernel<false>", "adam_kernel<false, 4, true>", "adam_kernel<true, 4, true>", "gru_fwd_kernel<4>", "session_logits_kernel",
