@@ -76,8 +76,8 @@ if os.path.exists(p):
             d[r["Counter_Name"]] = float(r["Counter_Value"])
             d["dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             d["grid_threads"] = int(r["Grid_Size"])
-            d["kernel"] = "v4_bf16x3" if "kernel_v4" in r["Kernel_Name"] else "v3_fp32"
-    for tagk in ("v4_bf16x3", "v3_fp32"):
+            d["kernel"] = "v5_bf16x3" if "kernel_v5" in r["Kernel_Name"] else ("v4_bf16x3" if "kernel_v4" in r["Kernel_Name"] else "v3_fp32")
+    for tagk in ("v5_bf16x3", "v4_bf16x3", "v3_fp32"):
         cand = [d for d in agg.values() if d["kernel"] == tagk]
         if not cand:
             continue
@@ -87,5 +87,12 @@ if os.path.exists(p):
         big["effective_clock_GHz"] = clk / 1e9
         big["mfma_busy_fraction_at_effective_clock"] = simd_cycles / (big["GRBM_GUI_ACTIVE"] / 8)
         summary[f"eval_pmc_largest_launch_{tagk}"] = big
+# entries of the whole-epoch state (tools/profile_epoch.sh -> tools/summarize_epoch_profile.py) live in the same file: keep them
+_old = f"profiles/{tag}_pmc_summary.json"
+if os.path.exists(_old):
+    _prev = json.load(open(_old))
+    summary["kernels"].update({k: v for k, v in _prev.get("kernels", {}).items() if "@" in k})
+    if "epoch_command" in _prev:
+        summary["epoch_command"] = _prev["epoch_command"]
 json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
