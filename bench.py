@@ -214,6 +214,9 @@ def lightgcn_leg(args, world, rank, dev, dist, full, K, W, cpu_baseline):
         del adj
         leg["cpu_baseline"] = {"value": b / t_step, "unit": "train interactions/s", "cores": cores, "kind": "port", "sample": sample}
         leg["speedup_vs_cpu_baseline"] = leg["value"] / leg["cpu_baseline"]["value"]
+        leg["speedup_note"] = ("against a PORT: the reference's torch-CPU op sequence restated and timed on this box's host cores, one "
+                               "layer extrapolated to the step (the reference's Python cannot travel to the GPU box); a reported "
+                               "baseline, not a target")
     # separately labelled large-batch variants (batch_size is a config knob, LightGCN.py:37): the same engine,
     # the same full-graph propagation per step, more interactions per step
     for bl in ([int(x) for x in args.large_batches.split(",") if x] if (world == 1 and args.large_batches) else []):

@@ -1264,8 +1264,18 @@ __global__ __launch_bounds__(256) void fused_plan_kernel(FusedPlanArgs a) {
             if (!owner) atomicOr(&a.shared[blk[r]], bit);                     // a second reference to the pair
             a.meta[e] = owner ? (1 << 23) : 0;
             const unsigned long long mask = a.named[blk[r]];
-            if (owner && (mask & (bit - 1)) == 0) {                           // the row's first naming: draw its slot
-                const int slot = atomicAdd(a.n_slots, 1);
+            // the row's first naming draws its slot: one atomic per wavefront on the shared counter (its lanes' draws are
+            // numbered by their rank among the drawing lanes) -- 60 k same-address atomics per block otherwise
+            const bool draws = owner && (mask & (bit - 1)) == 0;
+            const unsigned long long db = __ballot(draws);
+            int base = 0;
+            if (db) {
+                const int leader = __ffsll(static_cast<long long>(db)) - 1;
+                if (static_cast<int>(threadIdx.x & 63) == leader) base = atomicAdd(a.n_slots, __popcll(db));
+                base = __shfl(base, leader);
+            }
+            if (draws) {
+                const int slot = base + __popcll(db & ((1ull << (threadIdx.x & 63)) - 1ull));
                 a.slot_of[blk[r]] = slot;
                 a.slot_block[slot] = static_cast<int32_t>(blk[r]);
                 a.slot_fin[slot] = (__popcll(mask) % 6) | ((63 - __clzll(static_cast<long long>(mask))) << 8) | (s << 16);
