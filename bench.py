@@ -992,9 +992,13 @@ def main():
             torch.cuda.synchronize()
         return neg
 
+    host_probe = os.environ.get("SKR_BENCH_HOST_PROBE") == "1"      # diagnosis: host-side time of each part of a timed slice
+
     def run_slice(sl, n_steps, phase=None, neg=None):
+        tp0 = time.perf_counter()
         if neg is None:
             neg = sample_slice(sl)
+        tp1 = time.perf_counter()
         # device shuffle + batch assembly: ONE launch of the library's own kernel (a keyed bijection of the
         # slice's interactions, evaluated per output row) -- the first n_steps * b rows of the shuffled epoch slice
         run_slice.shuffles += 1
@@ -1022,6 +1026,7 @@ def main():
                 # ONE launch per step (csrc/train.hip K2c), through the class BPRMF.train_epoch uses: the next block's words and
                 # tags on a stream of their own, the cold pass and the write-back of the rows the next block does not touch
                 # on the side stream
+                tp2 = time.perf_counter()
                 f_opt.t = run_slice.t
                 f_opt.cold_timing = [] if phase is not None else None
                 if phase == "epoch3":       # blocks 256.. of the third whole epoch: the state an epoch runs in
@@ -1035,6 +1040,10 @@ def main():
                     o = 4 * nfull * kblk * b
                     fb.run_blocks(pu + o, pi + o, pj + o, 1, rem, b, P["loss"], 0)
                 f_opt.end_blocks()
+                if host_probe and phase == "timed":
+                    tp3 = time.perf_counter()
+                    print("[bench] host us: sampler call %.0f, shuffle + addresses %.0f, blocks %.0f" % (
+                        (tp1 - tp0) * 1e6, (tp2 - tp1) * 1e6, (tp3 - tp2) * 1e6), file=sys.stderr)
                 run_slice.t = f_opt.t
                 if phase is not None:
                     cold_log.extend(((e0_, e1_), kk_, phase) for e0_, e1_, kk_ in f_opt.cold_timing)
@@ -1215,7 +1224,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # size the sampler's scratch for the timed slice outside the timed region (consumes stream words)
+    # size the sampler's scratch for the timed slices outside the timed regions (consumes stream words), and let it take every
+    # slice's row statistics here: they are a property of the CSR, read back ONCE per CSR (in fit() the CSR is the same every
+    # epoch, so only the first epoch pays that round trip) -- a timed region must not contain the first sight of its slice
+    for sl_ in timed_slices[1:]:
+        _scratch = torch.empty(sl_["nnz"], dtype=torch.int32, device=dev)
+        sampler.sample_epoch_exact(nI, sl_["n_users"], sl_["rowptr"], sl_["items"], sl_["nnz"], 1, _scratch)
     _scratch = torch.empty(timed["nnz"], dtype=torch.int32, device=dev)
     sampler.sample_epoch_exact(nI, timed["n_users"], timed["rowptr"], timed["items"], timed["nnz"], 1, _scratch)
     # ... and run the slice preparation once at the timed slice's size (first use of a kernel loads its code object)

@@ -1182,7 +1182,10 @@ static int run_exact_epoch_slabs(skr_sampler* s, int num_items, int n_users, con
     hipLaunchKernelGGL(slab_begin_kernel, dim3(1), dim3(1), 0, st, s->d_ctl);
     // SKR_SAMPLER_ONE_STREAM=1: everything on the caller's stream (several processes sharing ONE GPU -- rehearsals of the
     // multi-rank paths -- oversubscribe the hardware queues, and cross-queue waits then cost milliseconds)
-    static const bool one_stream = getenv("SKR_SAMPLER_ONE_STREAM") && !strcmp(getenv("SKR_SAMPLER_ONE_STREAM"), "1");
+    static const bool env_one_stream = getenv("SKR_SAMPLER_ONE_STREAM") && !strcmp(getenv("SKR_SAMPLER_ONE_STREAM"), "1");
+    // a call of one piece has nothing to generate BESIDE: the first slab waits for the whole stretch either way, and the two
+    // stream hand-offs (~25 us) would be all the side stream adds
+    const bool one_stream = env_one_stream || n_pieces == 1;
     hipStream_t gst = one_stream ? st : s->gen_stream;
     if (!one_stream) {
         SKR_HIP(hipEventRecord(s->start_event, st));

@@ -133,11 +133,13 @@ class FusedBlocks(object):
             self.pre = torch.zeros((2, 3 * cap * 64), dtype=torch.float32, device=dev) if self.pre_advance else None
             self._used = [False, False]
 
-    def _plan(self, q, pu, pi, pj, k, bsz, serial, prev=None):
+    def _plan(self, q, pu, pi, pj, k, bsz, serial, prev=None, inline=False):
         """words, slot tables and hot-block tags of one block into set q, on the planning stream; ``prev`` = (tags, value) of
         the block before it: first namings of rows that block did not touch are marked as pre-advanced"""
         u0, i0, b0 = self.offsets
-        ps, L = self._plan_stream, _hip.lib()
+        # (``inline``: the first block of a call has nothing to be planned beside -- its words go out on the current stream,
+        #  without the two stream hand-offs)
+        ps, L = (torch.cuda.current_stream() if inline else self._plan_stream), _hip.lib()
         if self._used[q]:
             ps.wait_event(self._ev_done[q])       # the set's previous block is done with its tables and its workspace
         # the tags of set q were last read by the cold pass of the set's previous block (and by the write-backs of the
@@ -173,7 +175,8 @@ class FusedBlocks(object):
         side.wait_stream(cur)                     # ... and whatever wrote the tables before is on it too
         serial0 = self.serial + 1
         self.serial += n_blocks
-        self._plan(0, pu, pi, pj, k, bsz, serial0)
+        self._plan(0, pu, pi, pj, k, bsz, serial0, inline=True)
+        self._plan_stream.wait_event(self._ev_plan[0])     # the planning kernels share one scratch: block 1's come after block 0's
         for blk in range(n_blocks):
             q, o = blk & 1, blk * blk_bytes
             more = blk + 1 < n_blocks
