@@ -307,3 +307,63 @@ def test_fused_step_words_on_the_host():
     for slot in range(n):
         row = int(slot_block[slot])
         assert slot_fin[slot] == (seen[row] % 6) | (last[row] << 8) | (first[row] << 16)
+
+
+def test_gru_session_schedule_is_the_references_loop():
+    """GRU4RecPlus._schedule (the generator train_epoch prepares its 32-step blocks from) against a literal restatement of the
+    reference's session-parallel loop (GRU4RecPlus.py:208-247): the same positions step after step, the same slots reset
+    before the same steps, numpy's generator left in the same state (one permutation per epoch, drawn at the first step)"""
+    from types import SimpleNamespace
+    from skrec.recommender.GRU4RecPlus import GRU4RecPlus
+    rng = np.random.default_rng(3)
+    for n_sessions, b in ((40, 8), (9, 4), (200, 16), (5, 5)):
+        lens = rng.integers(2, 12, n_sessions)
+        lens[rng.integers(0, n_sessions, 3)] = 2                    # sessions of one step
+        offset_idx = np.zeros(n_sessions + 1, np.int32)
+        offset_idx[1:] = np.cumsum(lens)
+        # the reference's loop, verbatim control flow, recording what each step reads and which slots were zeroed before it
+        np.random.seed(11)
+        want, pending = [], None
+        user_idx = np.random.permutation(len(offset_idx) - 1)
+        iters = np.arange(b, dtype=np.int32)
+        maxiter = iters.max()
+        start = offset_idx[user_idx[iters]]
+        end = offset_idx[user_idx[iters] + 1]
+        finished = False
+        while not finished:
+            min_len = (end - start).min()
+            for i in range(min_len - 1):
+                want.append(((start + i).astype(np.int64).copy(), pending))
+                pending = None
+            start = start + min_len - 1
+            mask = np.arange(len(iters))[(end - start) <= 1]
+            for idx in mask:
+                maxiter += 1
+                if maxiter >= len(offset_idx) - 1:
+                    finished = True
+                    break
+                iters[idx] = maxiter
+                start[idx] = offset_idx[user_idx[maxiter]]
+                end[idx] = offset_idx[user_idx[maxiter] + 1]
+            if len(mask):
+                pending = mask if pending is None else np.union1d(pending, mask)
+        state_ref = np.random.get_state()[1].copy()
+        np.random.seed(11)
+        stub = SimpleNamespace(offset_idx=offset_idx, config=SimpleNamespace(batch_size=b))
+        got = list(GRU4RecPlus._schedule(stub))
+        assert np.array_equal(np.random.get_state()[1], state_ref)
+        assert len(got) == len(want) and len(got) > 0
+        for (gp, gr), (wp, wr) in zip(got, want):
+            assert np.array_equal(gp, wp)
+            assert (gr is None) == (wr is None) and (gr is None or np.array_equal(gr, wr))
+
+
+def test_padded_width_and_columns():
+    import torch
+    from skrec.recommender.LightGCN import pad_columns, padded_width
+    assert [padded_width(d) for d in (1, 32, 50, 64, 65, 100, 128, 129, 256)] == [64, 64, 64, 64, 128, 128, 128, 192, 256]
+    with pytest.raises(NotImplementedError):
+        padded_width(257)
+    t = torch.arange(6.0).view(2, 3)
+    p = pad_columns(t, 64)
+    assert p.shape == (2, 64) and torch.equal(p[:, :3], t) and float(p[:, 3:].abs().sum()) == 0.0 and pad_columns(p, 64) is p
