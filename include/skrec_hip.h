@@ -287,7 +287,11 @@ int skr_csr_spmm_strided(int n_rows, const int64_t* d_rowptr, const int32_t* d_c
  *                         CSR pointers -- the arrays must outlive it and keep their contents -- plus a task list and a
  *                         scratch buffer of its own.  Columns must ascend within a row and be < n_cols.
  *                         long_rows_from: 0 = default (512), otherwise >= 2.
- *   skr_spmm_plan_info    h_info4 = {long rows, tasks, column blocks, long_rows_from + (column windows << 32)};
+ *   skr_spmm_plan_info    h_info4 = {long rows + (hot rows << 32), tasks, column blocks, long_rows_from + (column windows << 32)};
+ *                         hot rows: the densest long rows (>= SKR_SPMM_HOT_DENSITY, default 4, entries per 128 columns on
+ *                         average; at most 96) are not gathered at all in calls without d_col_mask -- X is streamed through
+ *                         LDS in blocks of 128 rows and their entries, re-packed block-major at plan time, read it there
+ *                         (SKR_SPMM_HOT=0: off)
  *                         SKR_SPMM_WINDOWS=n (default 1) makes the short-row kernel gather from X in n column windows, one
  *                         launch each (an experiment switch: no gain measured at X = 256 MB)
  * A plan may be run any number of times, by one stream at a time (the scratch buffer is shared between runs). */

@@ -33,6 +33,12 @@ constexpr int SPMM_TASK = 256;       // entries per task at most
 constexpr int ROW_WAVES = 4;         // wavefronts per workgroup, both kernels
 constexpr int ROW_NF = 4;            // 16-byte gathers in flight per lane
 constexpr int BLK_WGS_PER_XCD = 256;
+// the DENSEST rows (round 3): a row that names a sizeable share of ALL columns does not gather -- X is streamed through LDS
+// in blocks of HOT_UB rows and the row's entries read it there
+constexpr int HOT_UB = 128;          // rows of X per LDS block (32 KB)
+constexpr int HOT_V = 128;           // virtual hot rows at most: 8 wavefronts x 4 slots x 4 sixteen-lane groups
+constexpr int HOT_WAVES = 8;         // wavefronts per workgroup
+constexpr int HOT_WGS = 512;         // workgroups (two per CU: 64 KB of LDS each)
 
 struct Task {
     int64_t beg;         // first entry (index into the caller's col / val)
@@ -282,7 +288,8 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
                                                                     const float* __restrict__ val, const float* __restrict__ X,
                                                                     float* __restrict__ part, const int32_t* __restrict__ long_rows,
                                                                     const uint8_t* __restrict__ row_mask,
-                                                                    const uint8_t* __restrict__ col_mask, int ld4) {
+                                                                    const uint8_t* __restrict__ col_mask, int ld4,
+                                                                    const uint8_t* __restrict__ hot_flag) {
     const int b = group * 8 + (blockIdx.x & 7);
     if (b >= n_blocks) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -292,6 +299,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
     const int64_t t_end = first_task[static_cast<int64_t>(b + 1) * n_long];
     for (int64_t t = first_task[static_cast<int64_t>(b) * n_long] + (blockIdx.x >> 3) * ROW_WAVES + wv; t < t_end; t += n_w) {
         const Task tk = tasks[t];
+        if (hot_flag && hot_flag[tk.len_slot >> 8]) continue;          // the row goes through the LDS-streamed form in this call
         if (row_mask && !row_mask[long_rows[tk.len_slot >> 8]]) continue;
         const int len = static_cast<int>(tk.len_slot & 255u) + 1;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -312,9 +320,10 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
 // quarter of the row's slots (8 loads in flight), the four sums are combined in wave order
 __global__ __launch_bounds__(256) void spmm_reduce_kernel(const int32_t* __restrict__ long_rows, const int64_t* __restrict__ part_ptr,
                                                           const float* __restrict__ part, const skr_spmm_epilogue ep,
-                                                          const uint8_t* __restrict__ row_mask) {
+                                                          const uint8_t* __restrict__ row_mask, const uint8_t* __restrict__ hot_flag) {
     __shared__ float s[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (hot_flag && hot_flag[blockIdx.x]) return;                  // finished by spmm_hot_reduce_kernel in this call
     if (row_mask && !row_mask[long_rows[blockIdx.x]]) return;      // the whole workgroup leaves together
     const int64_t b = part_ptr[blockIdx.x], n = part_ptr[blockIdx.x + 1] - b;
     const int64_t q0 = b + n * wv / 4, q1 = b + n * (wv + 1) / 4;
@@ -337,7 +346,191 @@ __global__ __launch_bounds__(256) void spmm_reduce_kernel(const int32_t* __restr
     }
 }
 
+// ---- the densest rows: X streamed through LDS -------------------------------------------------------------------------
+// A row of the item side that names 3 .. 80 % of all users gathers most of X anyway -- row by row, 256 bytes at a time, out
+// of L2 at best.  Those rows (at most HOT_V "virtual" rows: a row far heavier than the others is cut into P pieces, piece p
+// taking every P-th of the row's entries inside each X block) are multiplied the other way round: a workgroup walks a
+// contiguous range of X blocks of HOT_UB rows, brings each into LDS with coalesced loads (X is read exactly once, in
+// order), and the entries read their X rows THERE.  Work mapping: a sixteen-lane group multiplies one virtual row at a
+// time (a lane owns four of the 64 dims: ds_read_b128, four fmas, no cross-lane sum), the four groups of a wavefront
+// take four rows of similar length side by side (the plan sorts them so), a wavefront has four such slots, a workgroup
+// eight wavefronts: 8 x 4 x 4 = 128 rows, each with its own float4 accumulator register per lane.  The entries are re-packed
+// at plan time block-major (hot_meta = column inside the block, hot_val; hot_list_ptr per (block, virtual row)), the first
+// sixteen of every list are fetched one block ahead, and a wavefront hands its 64 fetched entries to its groups through
+// 512 bytes of LDS (a group reads its j-th entry with one broadcast ds_read_b64).  At the end the workgroup's 128 partial
+// rows go to hot_part, and spmm_hot_reduce_kernel adds the workgroups' (and pieces') partial rows in a fixed order and runs
+// the epilogue.  Every order of addition is fixed by the plan: results do not depend on timing.
+constexpr int HOT_SLOTS = 4;         // rows a group handles, one after the other, per block
+
+template <int HOT_PF>     // rounds of sixteen entries fetched ahead per list
+__global__ __launch_bounds__(HOT_WAVES * 64) void spmm_hot_kernel(const int64_t* __restrict__ list_ptr, const int32_t* __restrict__ meta,
+                                                                  const float* __restrict__ hval, const float* __restrict__ X, int ld4,
+                                                                  int n_cols, int n_ub, float* __restrict__ part) {
+    __shared__ float xb[2][HOT_UB * D];
+    __shared__ int2 stage[HOT_WAVES][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int per = (n_ub + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+    const int ub0 = static_cast<int>(blockIdx.x) * per, ub1 = ub0 + per < n_ub ? ub0 + per : n_ub;
+    const float4* X4 = reinterpret_cast<const float4*>(X);
+    float4 r4[4];
+    auto load_block = [&](int ub) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + HOT_WAVES * 64 * q;                    // float4 index inside the block: 128 rows x 16
+            const int64_t c = static_cast<int64_t>(ub) * HOT_UB + (idx >> 4);
+            r4[q] = c < n_cols ? X4[c * ld4 + (idx & 15)] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_block = [&](int b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(xb[b])[tid + HOT_WAVES * 64 * q] = r4[q];
+    };
+    float4 acc[HOT_SLOTS];
+#pragma unroll
+    for (int s_ = 0; s_ < HOT_SLOTS; ++s_) acc[s_] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // virtual row of (wavefront, slot, group) = wv * 16 + slot * 4 + grp; its list of a block: bounds and the first sixteen
+    // entries (a lane of the group each) are fetched one block ahead
+    int64_t l0c[HOT_SLOTS], l0n[HOT_SLOTS];
+    int nc[HOT_SLOTS], nn[HOT_SLOTS];
+    int mc[HOT_SLOTS][HOT_PF], mn[HOT_SLOTS][HOT_PF];
+    float vc[HOT_SLOTS][HOT_PF], vn[HOT_SLOTS][HOT_PF];
+    auto fetch = [&](int ub, int64_t (&l0)[HOT_SLOTS], int (&n)[HOT_SLOTS], int (&m)[HOT_SLOTS][HOT_PF], float (&v)[HOT_SLOTS][HOT_PF]) {
+#pragma unroll
+        for (int s_ = 0; s_ < HOT_SLOTS; ++s_) {
+            l0[s_] = 0; n[s_] = 0;
+#pragma unroll
+            for (int t = 0; t < HOT_PF; ++t) { m[s_][t] = 0; v[s_][t] = 0.0f; }
+            if (ub < ub1) {
+                const int64_t* lp = list_ptr + static_cast<int64_t>(ub) * HOT_V + wv * 16 + s_ * 4 + grp;
+                l0[s_] = lp[0];
+                n[s_] = static_cast<int>(lp[1] - lp[0]);
+#pragma unroll
+                for (int t = 0; t < HOT_PF; ++t)
+                    if (t * 16 + sub < n[s_]) { m[s_][t] = meta[l0[s_] + t * 16 + sub]; v[s_][t] = hval[l0[s_] + t * 16 + sub]; }
+            }
+        }
+    };
+    if (ub0 < ub1) {
+        load_block(ub0);
+        store_block(0);
+    }
+    fetch(ub0, l0c, nc, mc, vc);
+    __syncthreads();
+    for (int ub = ub0; ub < ub1; ++ub) {
+        const int b = (ub - ub0) & 1;
+        if (ub + 1 < ub1) load_block(ub + 1);                           // X of the next block: in flight while this one is multiplied
+        fetch(ub + 1, l0n, nn, mn, vn);                                  // ... and the next block's entries
+        const float4* xs = reinterpret_cast<const float4*>(xb[b]) + sub;
+        const int2* mine = &stage[wv][grp * 16];
+#pragma unroll
+        for (int s_ = 0; s_ < HOT_SLOTS; ++s_) {
+            const int n = nc[s_];
+            int nmax = __builtin_amdgcn_readlane(n, 0);
+            nmax = max(nmax, __builtin_amdgcn_readlane(n, 16));
+            nmax = max(nmax, __builtin_amdgcn_readlane(n, 32));
+            nmax = max(nmax, __builtin_amdgcn_readlane(n, 48));
+            for (int i0 = 0; i0 < nmax; i0 += 16) {
+                int m_ = mc[s_][0];
+                float v_ = vc[s_][0];
+                if (HOT_PF > 1 && i0 == 16) { m_ = mc[s_][HOT_PF - 1]; v_ = vc[s_][HOT_PF - 1]; }
+                if (i0 >= 16 * HOT_PF) {                                 // a longer list: fetched as needed
+                    m_ = 0; v_ = 0.0f;
+                    if (i0 + sub < n) { m_ = meta[l0c[s_] + i0 + sub]; v_ = hval[l0c[s_] + i0 + sub]; }
+                }
+                stage[wv][lane] = make_int2(m_, __float_as_int(v_));     // (lanes behind a list's end: column 0, value 0)
+                const int jn = nmax - i0 < 16 ? nmax - i0 : 16;
+                int j = 0;
+                for (; j + 4 <= jn; j += 4) {
+                    int2 e[4];
+                    float4 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        e[u] = mine[j + u];
+                        x[u] = xs[e[u].x * 16];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float vj = __int_as_float(e[u].y);
+                        acc[s_].x = fmaf(vj, x[u].x, acc[s_].x); acc[s_].y = fmaf(vj, x[u].y, acc[s_].y);
+                        acc[s_].z = fmaf(vj, x[u].z, acc[s_].z); acc[s_].w = fmaf(vj, x[u].w, acc[s_].w);
+                    }
+                }
+                for (; j < jn; ++j) {
+                    const int2 e = mine[j];
+                    const float4 x = xs[e.x * 16];
+                    const float vj = __int_as_float(e.y);
+                    acc[s_].x = fmaf(vj, x.x, acc[s_].x); acc[s_].y = fmaf(vj, x.y, acc[s_].y);
+                    acc[s_].z = fmaf(vj, x.z, acc[s_].z); acc[s_].w = fmaf(vj, x.w, acc[s_].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < HOT_SLOTS; ++s_) {
+            l0c[s_] = l0n[s_]; nc[s_] = nn[s_];
+#pragma unroll
+            for (int t = 0; t < HOT_PF; ++t) { mc[s_][t] = mn[s_][t]; vc[s_][t] = vn[s_][t]; }
+        }
+        if (ub + 1 < ub1) store_block(b ^ 1);
+        __syncthreads();
+    }
+    float4* out = reinterpret_cast<float4*>(part + (static_cast<int64_t>(blockIdx.x) * HOT_V + wv * 16 + grp) * D) + sub;
+#pragma unroll
+    for (int s_ = 0; s_ < HOT_SLOTS; ++s_) out[s_ * 4 * 16] = acc[s_];
+}
+
+// a virtual row = the sum of the workgroups' partial rows, in workgroup order: 16 wavefronts take contiguous shares of the
+// workgroups, their sums are combined in wave order (one workgroup per virtual row: the heaviest real row has 8 of them)
+__global__ __launch_bounds__(1024) void spmm_hot_vsum_kernel(const int32_t* __restrict__ virt_row, const float* __restrict__ part,
+                                                              int n_wgs, float* __restrict__ vsum) {
+    __shared__ float s[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int v = blockIdx.x;
+    if (virt_row[v] < 0) return;
+    const int q0 = n_wgs * wv / 16, q1 = n_wgs * (wv + 1) / 16;
+    float sum = 0.0f;
+    int q = q0;
+    for (; q + 16 <= q1; q += 16) {
+        float x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = part[(static_cast<int64_t>(q + j) * HOT_V + v) * D + lane];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += x[j];
+    }
+    for (; q < q1; ++q) sum += part[(static_cast<int64_t>(q) * HOT_V + v) * D + lane];
+    s[wv][lane] = sum;
+    __syncthreads();
+    if (wv == 0) {
+        float t = s[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t += s[w][lane];
+        vsum[v * D + lane] = t;
+    }
+}
+
+// a hot row = the sum of its pieces (virtual rows), in piece order, then the epilogue: one wavefront per row
+__global__ __launch_bounds__(256) void spmm_hot_reduce_kernel(int n_hot, const int32_t* __restrict__ hot_rows,
+                                                              const int32_t* __restrict__ hot_vptr, const int32_t* __restrict__ hot_vidx,
+                                                              const float* __restrict__ vsum, const skr_spmm_epilogue ep,
+                                                              const uint8_t* __restrict__ row_mask) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n_hot) return;
+    const int64_t row = hot_rows[k];
+    if (row_mask && !row_mask[row]) return;
+    float t = 0.0f;
+    for (int q = hot_vptr[k]; q < hot_vptr[k + 1]; ++q) t += vsum[hot_vidx[q] * D + lane];
+    float y[1] = {t};
+    epilogue<1>(ep, y, row, lane, true);
+}
+
 // ---- plan construction --------------------------------------------------------------------------------------------
+__global__ void long_deg_kernel(int n_long, const int32_t* __restrict__ long_rows, const int64_t* __restrict__ rowptr,
+                                int64_t* __restrict__ deg) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_long) deg[s] = rowptr[long_rows[s] + 1] - rowptr[long_rows[s]];
+}
+
 __global__ void flag_long_kernel(int n_rows, int thr, const int64_t* __restrict__ rowptr, int64_t* __restrict__ flag) {
     const int64_t r = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (r < n_rows) flag[r] = (rowptr[r + 1] - rowptr[r] >= thr) ? 1 : 0;
@@ -384,6 +577,46 @@ __device__ __forceinline__ int64_t lower_col(const int32_t* __restrict__ col, in
         if (col[mid] < c) lo = mid + 1; else hi = mid;
     }
     return lo;
+}
+
+// entries of virtual hot row v in X block ub (0 when the piece does not take that block)
+__global__ void hot_count_kernel(int n_ub, const int32_t* __restrict__ virt_row, const int32_t* __restrict__ virt_piece,
+                                 const int32_t* __restrict__ virt_pieces, const int64_t* __restrict__ rowptr,
+                                 const int32_t* __restrict__ col, int64_t* __restrict__ cnt) {
+    const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (i >= static_cast<int64_t>(n_ub) * HOT_V) return;
+    const int ub = static_cast<int>(i / HOT_V), v = static_cast<int>(i % HOT_V);
+    int64_t n = 0;
+    const int r = virt_row[v];
+    if (r >= 0) {      // piece p of P takes the entries p, p + P, ... of the row's segment in this block
+        const int64_t rb = rowptr[r], re = rowptr[r + 1];
+        const int64_t e0 = lower_col(col, rb, re, static_cast<int64_t>(ub) * HOT_UB);
+        const int64_t len = lower_col(col, e0, re, static_cast<int64_t>(ub + 1) * HOT_UB) - e0;
+        const int P = virt_pieces[v], q = virt_piece[v];
+        n = len > q ? (len - q + P - 1) / P : 0;
+    }
+    cnt[i] = n;
+}
+
+// one wavefront per (block, virtual row): its entries, in column order, to their place in the block-major lists
+__global__ __launch_bounds__(256) void hot_fill_kernel(int n_ub, const int32_t* __restrict__ virt_row,
+                                                       const int32_t* __restrict__ virt_piece, const int32_t* __restrict__ virt_pieces,
+                                                       const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const float* __restrict__ val, const int64_t* __restrict__ list_ptr,
+                                                       int32_t* __restrict__ meta, float* __restrict__ hval) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (i >= static_cast<int64_t>(n_ub) * HOT_V) return;
+    const int64_t o = list_ptr[i], n = list_ptr[i + 1] - o;
+    if (n == 0) return;
+    const int ub = static_cast<int>(i / HOT_V), v = static_cast<int>(i % HOT_V);
+    const int r = virt_row[v];
+    const int64_t e0 = lower_col(col, rowptr[r], rowptr[r + 1], static_cast<int64_t>(ub) * HOT_UB);
+    const int P = virt_pieces[v], q = virt_piece[v];
+    for (int64_t k = lane; k < n; k += 64) {
+        meta[o + k] = col[e0 + q + k * P] - ub * HOT_UB;
+        hval[o + k] = val[e0 + q + k * P];
+    }
 }
 
 // tasks per (block, long row) segment, written twice: block-major (the order the tasks run in) and row-major (the order
@@ -445,6 +678,19 @@ struct skr_spmm_plan {
     int64_t* split = nullptr;            // [n_rows * (n_win - 1)]
     Task* tasks = nullptr;               // [n_tasks] block-major
     float* part = nullptr;               // [n_tasks, 64]
+    // the densest rows (spmm_hot_kernel)
+    int n_hot = 0, n_virt = 0, n_ub = 0, hot_wgs = 0;
+    int64_t hot_nnz = 0;
+    int32_t* hot_rows = nullptr;         // [n_hot] row ids
+    int32_t* hot_vptr = nullptr;         // [n_hot + 1] a row's virtual rows ...
+    int32_t* hot_vidx = nullptr;         // [n_virt]    ... as indices 0 .. HOT_V - 1
+    int32_t* virt_tab = nullptr;         // [3][HOT_V]: row (-1: unused), piece, pieces
+    uint8_t* hot_flag = nullptr;         // [n_long] 1 = the long row is a hot row
+    int64_t* hot_list_ptr = nullptr;     // [n_ub * HOT_V + 1]
+    int32_t* hot_meta = nullptr;         // [hot_nnz]
+    float* hot_val = nullptr;            // [hot_nnz]
+    float* hot_part = nullptr;           // [hot_wgs, HOT_V, 64]
+    float* hot_vsum = nullptr;           // [HOT_V, 64]
 };
 
 namespace {
@@ -456,6 +702,9 @@ void free_plan(skr_spmm_plan* p) {
     (void)hipFree(p->tasks);
     (void)hipFree(p->part);
     (void)hipFree(p->split);
+    (void)hipFree(p->hot_rows); (void)hipFree(p->hot_vptr); (void)hipFree(p->hot_vidx); (void)hipFree(p->virt_tab);
+    (void)hipFree(p->hot_flag); (void)hipFree(p->hot_list_ptr); (void)hipFree(p->hot_meta); (void)hipFree(p->hot_val);
+    (void)hipFree(p->hot_part); (void)hipFree(p->hot_vsum);
     delete p;
 }
 }  // namespace
@@ -555,6 +804,110 @@ int skr_spmm_plan_create(int n_rows, int n_cols, const int64_t* d_rowptr, const 
         hipLaunchKernelGGL(part_ptr_kernel, dim3(static_cast<unsigned>((n_long + 1 + 255) / 256)), dim3(256), 0, st, p->n_long, p->n_blocks,
                            cnt_rm, p->part_ptr);
         PLAN_HIP(hipStreamSynchronize(st));
+        // 3. the densest rows: at least `dens` entries per HOT_UB columns on average (SKR_SPMM_HOT_DENSITY, default 4; 0: none).
+        //    Chosen on the host from the long rows' lengths (a few thousand numbers): the densest first, a row far heavier than a
+        //    wavefront's fair share cut into pieces, pieces dealt to the 8 wavefronts' 16 slots by load (largest first).
+        static const double dens = [] { const char* e = getenv("SKR_SPMM_HOT_DENSITY"); return e ? atof(e) : 4.0; }();
+        if (dens > 0.0 && n_cols >= HOT_UB) {
+            int64_t* d_deg = nullptr;
+            PLAN_HIP(hipMalloc(&d_deg, sizeof(int64_t) * n_long));
+            hipLaunchKernelGGL(long_deg_kernel, dim3(static_cast<unsigned>((n_long + 255) / 256)), dim3(256), 0, st, p->n_long, p->long_rows,
+                               d_rowptr, d_deg);
+            std::vector<int64_t> deg(n_long);
+            std::vector<int32_t> lrows(n_long);
+            hipError_t e1 = hipMemcpyAsync(deg.data(), d_deg, sizeof(int64_t) * n_long, hipMemcpyDeviceToHost, st);
+            hipError_t e2 = hipMemcpyAsync(lrows.data(), p->long_rows, sizeof(int32_t) * n_long, hipMemcpyDeviceToHost, st);
+            hipError_t e3 = hipStreamSynchronize(st);
+            (void)hipFree(d_deg);
+            PLAN_HIP(e1); PLAN_HIP(e2); PLAN_HIP(e3);
+            const double thr = dens * static_cast<double>(n_cols) / HOT_UB;
+            std::vector<int> cand;
+            for (int s_ = 0; s_ < static_cast<int>(n_long); ++s_)
+                if (static_cast<double>(deg[s_]) >= thr) cand.push_back(s_);
+            std::sort(cand.begin(), cand.end(), [&](int x, int y) { return deg[x] != deg[y] ? deg[x] > deg[y] : x < y; });
+            if (cand.size() > 96) cand.resize(96);           // room for the pieces of the heaviest ones among HOT_V virtual rows
+            double total = 0.0;
+            for (int s_ : cand) total += static_cast<double>(deg[s_]);
+            struct Virt { int slot, piece, pieces; double load; };
+            std::vector<Virt> virt;
+            std::vector<int> kept;
+            for (int s_ : cand) {
+                int pieces = static_cast<int>(std::ceil(static_cast<double>(deg[s_]) / (total / 64.0)));
+                if (pieces < 1) pieces = 1;
+                if (pieces > 8) pieces = 8;
+                if (static_cast<int>(virt.size()) + pieces > HOT_V) break;
+                for (int q = 0; q < pieces; ++q) virt.push_back(Virt{s_, q, pieces, static_cast<double>(deg[s_]) / pieces});
+                kept.push_back(s_);
+            }
+            if (!virt.empty()) {
+                // The four groups of a wavefront run side by side, each on one row of a slot, for as many trips as the longest
+                // of the four needs: the virtual rows, sorted by length, are taken four at a time (a CHUNK = rows of similar
+                // length), and the chunks are dealt to the 8 wavefronts' 4 slots by load, largest first.
+                std::vector<int> order(virt.size());
+                for (size_t q = 0; q < virt.size(); ++q) order[q] = static_cast<int>(q);
+                std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return virt[x].load > virt[y].load; });
+                double wload[HOT_WAVES] = {0};
+                int wcnt[HOT_WAVES] = {0};
+                std::vector<int32_t> tab(3 * HOT_V, 0);
+                for (int v = 0; v < HOT_V; ++v) { tab[v] = -1; tab[2 * HOT_V + v] = 1; }
+                std::vector<int> v_of(virt.size());
+                for (size_t c0 = 0; c0 < order.size(); c0 += 4) {
+                    int best = -1;
+                    for (int w_ = 0; w_ < HOT_WAVES; ++w_)
+                        if (wcnt[w_] < HOT_SLOTS && (best < 0 || wload[w_] < wload[best])) best = w_;
+                    const int slot = wcnt[best]++;
+                    for (size_t c = c0; c < c0 + 4 && c < order.size(); ++c) {
+                        const int q = order[c];
+                        const int v = best * 16 + slot * 4 + static_cast<int>(c - c0);
+                        wload[best] += virt[q].load;
+                        v_of[q] = v;
+                        tab[v] = lrows[virt[q].slot];
+                        tab[HOT_V + v] = virt[q].piece;
+                        tab[2 * HOT_V + v] = virt[q].pieces;
+                    }
+                }
+                p->n_hot = static_cast<int>(kept.size());
+                p->n_virt = static_cast<int>(virt.size());
+                p->n_ub = (n_cols + HOT_UB - 1) / HOT_UB;
+                static const int wgs_max = [] { const char* e = getenv("SKR_SPMM_HOT_WGS"); const int v = e ? atoi(e) : HOT_WGS; return v < 1 ? 1 : (v > 2048 ? 2048 : v); }();
+                p->hot_wgs = p->n_ub < wgs_max ? p->n_ub : wgs_max;
+                std::vector<int32_t> h_rows(p->n_hot), h_vptr(p->n_hot + 1, 0), h_vidx;
+                std::vector<uint8_t> h_flag(n_long, 0);
+                for (int k_ = 0; k_ < p->n_hot; ++k_) {
+                    h_rows[k_] = lrows[kept[k_]];
+                    h_flag[kept[k_]] = 1;
+                    for (size_t q = 0; q < virt.size(); ++q)
+                        if (virt[q].slot == kept[k_]) h_vidx.push_back(v_of[q]);          // pieces in order 0 .. P - 1
+                    h_vptr[k_ + 1] = static_cast<int32_t>(h_vidx.size());
+                }
+                const int64_t n_seg = static_cast<int64_t>(p->n_ub) * HOT_V;
+                PLAN_HIP(hipMalloc(&p->hot_rows, sizeof(int32_t) * p->n_hot));
+                PLAN_HIP(hipMalloc(&p->hot_vptr, sizeof(int32_t) * (p->n_hot + 1)));
+                PLAN_HIP(hipMalloc(&p->hot_vidx, sizeof(int32_t) * p->n_virt));
+                PLAN_HIP(hipMalloc(&p->virt_tab, sizeof(int32_t) * 3 * HOT_V));
+                PLAN_HIP(hipMalloc(&p->hot_flag, n_long));
+                PLAN_HIP(hipMalloc(&p->hot_list_ptr, sizeof(int64_t) * (n_seg + 1)));
+                PLAN_HIP(hipMalloc(&p->hot_part, sizeof(float) * static_cast<size_t>(p->hot_wgs) * HOT_V * D));
+                PLAN_HIP(hipMalloc(&p->hot_vsum, sizeof(float) * HOT_V * D));
+                PLAN_HIP(hipMemcpyAsync(p->hot_rows, h_rows.data(), sizeof(int32_t) * p->n_hot, hipMemcpyHostToDevice, st));
+                PLAN_HIP(hipMemcpyAsync(p->hot_vptr, h_vptr.data(), sizeof(int32_t) * (p->n_hot + 1), hipMemcpyHostToDevice, st));
+                PLAN_HIP(hipMemcpyAsync(p->hot_vidx, h_vidx.data(), sizeof(int32_t) * p->n_virt, hipMemcpyHostToDevice, st));
+                PLAN_HIP(hipMemcpyAsync(p->virt_tab, tab.data(), sizeof(int32_t) * 3 * HOT_V, hipMemcpyHostToDevice, st));
+                PLAN_HIP(hipMemcpyAsync(p->hot_flag, h_flag.data(), n_long, hipMemcpyHostToDevice, st));
+                PLAN_HIP(hipMemsetAsync(p->hot_list_ptr + n_seg, 0, sizeof(int64_t), st));
+                hipLaunchKernelGGL(hot_count_kernel, dim3(static_cast<unsigned>((n_seg + 255) / 256)), dim3(256), 0, st, p->n_ub, p->virt_tab,
+                                   p->virt_tab + HOT_V, p->virt_tab + 2 * HOT_V, d_rowptr, d_col, p->hot_list_ptr);
+                hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, p->hot_list_ptr, n_seg + 1);
+                PLAN_HIP(hipMemcpyAsync(&p->hot_nnz, p->hot_list_ptr + n_seg, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+                PLAN_HIP(hipStreamSynchronize(st));                       // (the host vectors above are done with, too)
+                PLAN_HIP(hipMalloc(&p->hot_meta, sizeof(int32_t) * std::max<int64_t>(p->hot_nnz, 1)));
+                PLAN_HIP(hipMalloc(&p->hot_val, sizeof(float) * std::max<int64_t>(p->hot_nnz, 1)));
+                hipLaunchKernelGGL(hot_fill_kernel, dim3(static_cast<unsigned>((n_seg + 3) / 4)), dim3(256), 0, st, p->n_ub, p->virt_tab,
+                                   p->virt_tab + HOT_V, p->virt_tab + 2 * HOT_V, d_rowptr, d_col, d_val, p->hot_list_ptr, p->hot_meta,
+                                   p->hot_val);
+                PLAN_HIP(hipStreamSynchronize(st));
+            }
+        }
     }
     PLAN_HIP(hipGetLastError());
     (void)hipFree(slot_of);
@@ -570,7 +923,7 @@ int skr_spmm_plan_destroy(skr_spmm_plan* plan) {
 
 int skr_spmm_plan_info(const skr_spmm_plan* plan, int64_t* h_info4) {
     SKR_REQUIRE(plan && h_info4, "skr_spmm_plan_info: NULL argument");
-    h_info4[0] = plan->n_long;
+    h_info4[0] = plan->n_long + (static_cast<int64_t>(plan->n_hot) << 32);      // hot rows (LDS-streamed) in the high half
     h_info4[1] = plan->n_tasks;
     h_info4[2] = plan->n_blocks;
     h_info4[3] = plan->long_thr + (static_cast<int64_t>(plan->n_win) << 32);     // column windows in the high half
@@ -605,6 +958,25 @@ int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, c
                                d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w);
     }
     SKR_LAUNCH_CHECK();
+    // the densest rows through LDS -- unless the call says that most of X is zero (col_mask: the first backward hop), where
+    // streaming all of X would be the waste; SKR_SPMM_HOT=0 keeps them on the task path
+    static const bool hot_on = [] { const char* e = getenv("SKR_SPMM_HOT"); return !(e && atoi(e) == 0); }();
+    const bool hot = hot_on && plan->n_hot > 0 && !d_col_mask;
+    const uint8_t* hot_flag = hot ? plan->hot_flag : nullptr;
+    if (hot) {
+        static const int pf = [] { const char* e = getenv("SKR_SPMM_HOT_PF"); return e ? atoi(e) : 1; }();
+        if (pf >= 2)
+            hipLaunchKernelGGL(spmm_hot_kernel<2>, dim3(plan->hot_wgs), dim3(HOT_WAVES * 64), 0, st, plan->hot_list_ptr, plan->hot_meta,
+                               plan->hot_val, d_X, ld >> 2, plan->n_cols, plan->n_ub, plan->hot_part);
+        else
+            hipLaunchKernelGGL(spmm_hot_kernel<1>, dim3(plan->hot_wgs), dim3(HOT_WAVES * 64), 0, st, plan->hot_list_ptr, plan->hot_meta,
+                               plan->hot_val, d_X, ld >> 2, plan->n_cols, plan->n_ub, plan->hot_part);
+        hipLaunchKernelGGL(spmm_hot_vsum_kernel, dim3(HOT_V), dim3(1024), 0, st, plan->virt_tab, plan->hot_part, plan->hot_wgs,
+                           plan->hot_vsum);
+        hipLaunchKernelGGL(spmm_hot_reduce_kernel, dim3((plan->n_hot + 3) / 4), dim3(256), 0, st, plan->n_hot, plan->hot_rows,
+                           plan->hot_vptr, plan->hot_vidx, plan->hot_vsum, ep, d_row_mask);
+        SKR_LAUNCH_CHECK();
+    }
     if (plan->n_long > 0) {
         if (plan->n_tasks > 0) {
             const int groups = (plan->n_blocks + 7) / 8;
@@ -613,15 +985,15 @@ int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, c
             for (int g = 0; g < groups; ++g) {
                 if (d_col_mask)
                     hipLaunchKernelGGL(spmm_tasks_kernel<true>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
-                                       plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask, ld >> 2);
+                                       plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask, ld >> 2, hot_flag);
                 else
                     hipLaunchKernelGGL(spmm_tasks_kernel<false>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
-                                       plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask, ld >> 2);
+                                       plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask, ld >> 2, hot_flag);
             }
             SKR_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(spmm_reduce_kernel, dim3(plan->n_long), dim3(256), 0, st, plan->long_rows, plan->part_ptr, plan->part, ep,
-                           d_row_mask);
+                           d_row_mask, hot_flag);
         SKR_LAUNCH_CHECK();
     }
     return SKR_OK;

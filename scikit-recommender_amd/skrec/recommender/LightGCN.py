@@ -108,8 +108,8 @@ class DeviceCSR(object):
         import ctypes
         info = (ctypes.c_int64 * 4)()
         _hip.check(_hip.lib().skr_spmm_plan_info(self._plan_handle(), info))
-        return dict(long_rows=info[0], tasks=info[1], column_blocks=info[2], long_rows_from=info[3] & 0xffffffff,
-                    column_windows=info[3] >> 32)
+        return dict(long_rows=info[0] & 0xffffffff, hot_rows=info[0] >> 32, tasks=info[1], column_blocks=info[2],
+                    long_rows_from=info[3] & 0xffffffff, column_windows=info[3] >> 32)
 
     def __del__(self):
         h = getattr(self, "_plan", None)

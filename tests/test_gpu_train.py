@@ -194,7 +194,7 @@ def test_spmm_plan_rectangular_blocks_and_determinism(n_rows, n_cols, long_from,
     info = (C.c_int64 * 4)()
     _hip.check(L.skr_spmm_plan_info(h, info))
     thr = long_from or 512
-    assert info[0] == int((lens >= thr).sum()) and info[2] == -(-n_cols // 16384) and (info[3] & 0xffffffff) == thr
+    assert (info[0] & 0xffffffff) == int((lens >= thr).sum()) and info[2] == -(-n_cols // 16384) and (info[3] & 0xffffffff) == thr
     assert (info[3] >> 32) == (int(windows) if windows else 1)
     # tasks: one per 256 entries of every (long row, column block) segment
     want_tasks = 0
