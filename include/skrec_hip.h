@@ -310,6 +310,14 @@ int skr_spmm_plan_run_masked(const skr_spmm_plan* plan, const float* d_X, int di
                              float* d_accum, float accum_scale, const uint8_t* d_row_mask, const uint8_t* d_col_mask,
                              void* stream);
 int skr_mark_ids(const int32_t* d_ids, int64_t n, int64_t offset, uint8_t* d_mask, void* stream);
+/* The product with the TRANSPOSE of a CSR matrix A [n_rows, *] where X [n_rows, 64] is zero outside the rows marked in
+ * d_row_mask:  Y[c] += A[r, c] * X[r]  for every entry of every marked row (Y initialised by the caller: zeros, or the
+ * addend).  The item side of LightGCN's FIRST backward hop is this: dL/dE-bar is zero outside the batch's <= batch users, so
+ * instead of every item row scanning its users for marked ones (48 M entries looked at) the batch users' own rows -- the
+ * user-side block, whose entries are the same non-zeros -- are walked (~50 k entries) with one 256-byte row atomic each.
+ * Float atomics: the order of the additions into a row varies from run to run, as it does in skr_bpr_step's scatter. */
+int skr_csr_scatter_marked_rows(int n_rows, const int64_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                                const uint8_t* d_row_mask, const float* d_X, int dim, float* d_Y, void* stream);
 /* The general form: what happens to a finished row y = (A X)_r (+ addend_r) is described by a skr_spmm_epilogue, so that the
  * row-local passes around a propagation ride in the product's row epilogue instead of being launches of their own (a
  * wavefront holds the whole 64-float row there):

@@ -89,6 +89,7 @@ SIGNATURES = {
     "skr_clear_marked_rows": (i32, [vp, i64, i64, vp, i32, vp]),
     "skr_layer_refine_bwd_masked": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp, i32, vp]),
     "skr_mark_ids": (i32, [vp, i64, i64, vp, vp]),
+    "skr_csr_scatter_marked_rows": (i32, [i32, vp, vp, vp, vp, vp, i32, vp, vp]),
     "skr_spmm_plan_info": (i32, [vp, C.POINTER(i64)]),
     "skr_spmm_plan_destroy": (i32, [vp]),
     "skr_layer_refine_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp]),

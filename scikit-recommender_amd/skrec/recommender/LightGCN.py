@@ -120,6 +120,13 @@ class DeviceCSR(object):
                 pass
             self._plan = None
 
+    def scatter_marked_rows(self, row_mask, X, Y):
+        """Y[c] += A[r, c] * X[r] over the entries of the rows marked in ``row_mask`` (uint8 [n_rows]): the product with the
+        TRANSPOSE where X is zero outside the marked rows (skr_csr_scatter_marked_rows); Y must be initialised"""
+        _hip.check(_hip.lib().skr_csr_scatter_marked_rows(self.shape[0], _hip.ptr(self.rowptr), _hip.ptr(self.col), _hip.ptr(self.val),
+                                                          _hip.ptr(row_mask), _hip.ptr(X), 64, _hip.ptr(Y), _hip.stream()))
+        return Y
+
     def uses_plan(self):
         """whether products of this matrix go through the plan (which honours the row / column masks)"""
         mode = os.environ.get("SKR_SPMM_PLAN", "auto")

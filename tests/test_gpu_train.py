@@ -363,6 +363,13 @@ def test_spmm_row_epilogues_equal_the_separate_passes(plan, monkeypatch):
     Y2 = z()
     csr.spmm(X, Y2, addend=poisoned, addend_mask=mask)       # (plan: the rows outside the mask must not even be read)
     close(Y2, raw + add_sparse)
+    # the product with the transpose restricted to marked rows (skr_csr_scatter_marked_rows; float atomics: to rounding)
+    Yt = add.clone()
+    csr.scatter_marked_rows(mask, X, Yt)
+    Xm = X.cpu().numpy().astype(np.float64) * mask_np[:, None]
+    want_t = add.cpu().numpy() + A.T.astype(np.float64) @ Xm
+    mass_t = np.abs(add.cpu().numpy()) + abs(A.T).astype(np.float64) @ np.abs(Xm)
+    assert np.all(np.abs(Yt.cpu().numpy() - want_t) <= 2e-6 * mass_t + 1e-6)
     # skr_clear_marked_rows
     T, m2 = torch.ones((n, 64), device=dev()), mask.clone()
     _hip.check(L.skr_clear_marked_rows(_hip.ptr(m2), n, 1, _hip.ptr(T), 64, st))
