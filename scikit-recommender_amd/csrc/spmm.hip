@@ -80,22 +80,10 @@ __device__ __forceinline__ void sum_groups(float4& acc) {
 // keep only the entries whose column is marked in `col_mask` (the others would multiply rows of X that are known to be
 // zero): kept entries move to the front of the block in their order, the others behind them with value 0; returns how
 // many were kept.  Every lane takes part in the two permutes.
-constexpr int MASK_BITS_MAX = 262144;     // column masks of up to this many columns are tested as bits in LDS (32 KB)
-
-// a byte mask as bits (word w: columns 32 w .. 32 w + 31)
-__global__ void pack_mask_bits_kernel(const uint8_t* __restrict__ mask, int n, uint32_t* __restrict__ bits) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w * 32 >= n) return;
-    uint32_t b = 0;
-    for (int k = 0; k < 32 && w * 32 + k < n; ++k) b |= (mask[w * 32 + k] != 0 ? 1u : 0u) << k;
-    bits[w] = b;
-}
-
-
-__device__ __forceinline__ int keep_marked(const uint8_t* __restrict__ col_mask, const uint32_t* s_bits, int lane, int m, int& cl,
-                                           float& vl) {
-    // s_bits: the mask as bits in LDS -- a byte per entry out of L2 costs the vector-memory path as much as a row gather does
-    const bool keep = lane < m && (s_bits ? ((s_bits[cl >> 5] >> (cl & 31)) & 1u) != 0 : col_mask[cl] != 0);
+// (tried in round 3: the mask as bits in LDS instead of a byte per entry out of L2 -- LightGCN 10.92-10.94 vs 10.96 ms per step:
+//  the mask look-ups are not what the column-masked products wait for)
+__device__ __forceinline__ int keep_marked(const uint8_t* __restrict__ col_mask, int lane, int m, int& cl, float& vl) {
+    const bool keep = lane < m && col_mask[cl] != 0;
     const unsigned long long b = __ballot(keep);
     const int kept = __popcll(b);
     const int below = __popcll(b & ((1ull << lane) - 1ull));
@@ -243,8 +231,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, i
                                                                    const float* __restrict__ X, const skr_spmm_epilogue ep,
                                                                    const uint8_t* __restrict__ row_mask,
                                                                    const uint8_t* __restrict__ col_mask,
-                                                                   const int64_t* __restrict__ split, int n_win, int win,
-                                                                   const uint32_t* __restrict__ col_bits, int n_mask_words) {
+                                                                   const int64_t* __restrict__ split, int n_win, int win) {
     // split / n_win / win: the columns are cut into n_win WINDOWS (X is far larger than the Infinity Cache: each launch
     // gathers from one window of it); split[r * (n_win - 1) + w] = first entry of row r in window w + 1.  Launch `win`
     // takes the row's entries of its window; the first writes Y, the later ones add to it, the last applies the epilogue.
@@ -252,15 +239,6 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, i
     const int grp = lane >> 4, sub = lane & 15;
     const float4* X4 = reinterpret_cast<const float4*>(X);
     const int ld = ep.ld ? ep.ld : D, ld4 = ld >> 2;
-    const uint32_t* s_bits = nullptr;
-    if (COLMASK) {
-        __shared__ uint32_t s_mask[MASK_BITS_MAX / 32];
-        if (col_bits) {                       // wave-uniform: the plan packed the mask (it fits)
-            for (int i = threadIdx.x; i < n_mask_words; i += ROW_WAVES * 64) s_mask[i] = col_bits[i];
-            __syncthreads();
-            s_bits = s_mask;
-        }
-    }
     for (int64_t r = blockIdx.x * ROW_WAVES + wv; r < n_rows; r += static_cast<int64_t>(gridDim.x) * ROW_WAVES) {
         if (row_mask && !row_mask[r]) continue;
         int64_t rb = rowptr[r], re = rowptr[r + 1];
@@ -277,7 +255,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, i
             int cl = 0;
             float vl = 0.0f;
             if (lane < m) { cl = col[e + lane]; vl = val[e + lane]; }
-            if (COLMASK) m = keep_marked(col_mask, s_bits, lane, m, cl, vl);
+            if (COLMASK) m = keep_marked(col_mask, lane, m, cl, vl);
             gather_block(X4, cl, vl, m, grp, sub, acc, ld4);
         }
         sum_groups(acc);
@@ -332,7 +310,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
             int cl = col[tk.beg];          // padding lanes gather the task's first column: an address inside the block
             float vl = 0.0f;
             if (lane < m) { cl = col[tk.beg + e0 + lane]; vl = val[tk.beg + e0 + lane]; }
-            if (COLMASK) m = keep_marked(col_mask, nullptr, lane, m, cl, vl);
+            if (COLMASK) m = keep_marked(col_mask, lane, m, cl, vl);
             gather_block(X4, cl, vl, m, grp, sub, acc, ld4);
         }
         sum_groups(acc);
@@ -715,7 +693,6 @@ struct skr_spmm_plan {
     float* hot_val = nullptr;            // [hot_nnz]
     float* hot_part = nullptr;           // [hot_wgs, HOT_V, 64]
     float* hot_vsum = nullptr;           // [HOT_V, 64]
-    uint32_t* col_bits = nullptr;        // [(n_cols + 31) / 32] a call's column mask as bits (n_cols <= MASK_BITS_MAX)
 };
 
 namespace {
@@ -729,7 +706,7 @@ void free_plan(skr_spmm_plan* p) {
     (void)hipFree(p->split);
     (void)hipFree(p->hot_rows); (void)hipFree(p->hot_vptr); (void)hipFree(p->hot_vidx); (void)hipFree(p->virt_tab);
     (void)hipFree(p->hot_flag); (void)hipFree(p->hot_list_ptr); (void)hipFree(p->hot_meta); (void)hipFree(p->hot_val);
-    (void)hipFree(p->hot_part); (void)hipFree(p->hot_vsum); (void)hipFree(p->col_bits);
+    (void)hipFree(p->hot_part); (void)hipFree(p->hot_vsum);
     delete p;
 }
 }  // namespace
@@ -773,10 +750,6 @@ int skr_spmm_plan_create(int n_rows, int n_cols, const int64_t* d_rowptr, const 
             hipLaunchKernelGGL(window_split_kernel, dim3(static_cast<unsigned>((n_sp + 255) / 256)), dim3(256), 0, st, n_rows, p->long_thr, n_win,
                                win_cols, d_rowptr, d_col, p->split);
         }
-    }
-    if (n_cols <= MASK_BITS_MAX) {
-        hipError_t eb = hipMalloc(&p->col_bits, sizeof(uint32_t) * ((static_cast<size_t>(n_cols) + 31) / 32));
-        if (eb != hipSuccess) { free_plan(p); *out = nullptr; return skr::fail(SKR_EHIP, "hipMalloc failed: %s", hipGetErrorString(eb)); }
     }
     // 1. the long rows, in ascending order
     int64_t* slot_of = nullptr;
@@ -978,21 +951,13 @@ int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, c
     int64_t wgs = (static_cast<int64_t>(plan->n_rows) + ROW_WAVES - 1) / ROW_WAVES;
     if (wgs > 8192) wgs = 8192;
     const dim3 rgrid(static_cast<unsigned>(wgs)), blk(ROW_WAVES * 64), tgrid(8 * BLK_WGS_PER_XCD);
-    // a column mask that fits is tested as bits in LDS by the short-row kernel (SKR_SPMM_MASK_BITS=0: bytes out of L2)
-    static const bool bits_on = [] { const char* e = getenv("SKR_SPMM_MASK_BITS"); return !(e && atoi(e) == 0); }();
-    const uint32_t* col_bits = nullptr;
-    const int n_mask_words = (plan->n_cols + 31) / 32;
-    if (d_col_mask && plan->col_bits && bits_on) {
-        hipLaunchKernelGGL(pack_mask_bits_kernel, dim3((n_mask_words + 255) / 256), dim3(256), 0, st, d_col_mask, plan->n_cols, plan->col_bits);
-        col_bits = plan->col_bits;
-    }
     for (int w = 0; w < plan->n_win; ++w) {
         if (d_col_mask)
             hipLaunchKernelGGL(spmm_rows_kernel<true>, rgrid, blk, 0, st, plan->n_rows, plan->long_thr, plan->rowptr, plan->col, plan->val,
-                               d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w, col_bits, n_mask_words);
+                               d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w);
         else
             hipLaunchKernelGGL(spmm_rows_kernel<false>, rgrid, blk, 0, st, plan->n_rows, plan->long_thr, plan->rowptr, plan->col, plan->val,
-                               d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w, col_bits, n_mask_words);
+                               d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w);
     }
     SKR_LAUNCH_CHECK();
     // the densest rows through LDS -- unless the call says that most of X is zero (col_mask: the first backward hop), where
