@@ -1123,6 +1123,309 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v5(FusedAr
     }
 }
 
+// ================================================================================================
+// fused_topk_kernel_v6 (round 3): the bf16x3 sweep on v_mfma_f32_16x16x32_bf16, one step = a GROUP of 16 items over all 64
+// dims.  Why another shape: under bf16 MFMA load the chip holds its clock down (1.7 GHz in v5's loop, MFMA pipe busy 75 %
+// of it), so cycles are not what the wall time is made of; MI355X_MICROARCH.md ("DVFS give-back", item 7) measures the
+// 16x16x32 form at 1.12-1.15 x the FLOP/s of the 32x32x16 form at equal cycles on random data.  The shape also turns the
+// schedule round:
+//   * an output tile is 16 items x 16 users with FOUR accumulator registers; a wavefront's 64 users are four user groups,
+//     so a step (16 items x 64 users x 64 dims = 2 k-steps x 6 piece products x 4 user groups = 48 MFMAs of 16 cycles, the
+//     same matrix-pipe time as v5's half tile) FINISHES 16 accumulator registers, and two such sets alternate in the 32
+//     registers v5's one tile needs.  The threshold tests of step hs-1 therefore issue between the MFMAs of step hs
+//     (one v_cmp + one scalar OR per accumulator register, pinned two per slot), with no second accumulator pair: what
+//     VERDICT round 2, item 4 asked for without the 32 VGPRs it was priced at;
+//   * lane l holds, per user group g, the scores of user 16 g + (l & 15) against items 4 (l >> 4) + i, i < 4: a user's
+//     16 scores of a step sit in four lanes, the list lengths live in registers replicated over those four lanes and the
+//     passing counts cross them by v_permlane16_swap / v_permlane32_swap (no LDS trip);
+//   * everything outside the arithmetic is v5's: ONE ring of three 6 KB blocks per workgroup (a block = one item group:
+//     2 k-steps x 3 pieces), brought by the four wavefronts together, one workgroup barrier per step, candidate lists in
+//     HBM scratch, the same compaction code.
+// split_items_kernel_v6 writes the table in this kernel's fragment order: group (16 items) x k-step (32 dims) x piece ->
+// 1 KB blocks in which lane l's 16 bytes are A[row l & 15][k = 8 (l >> 4) + j].
+// ================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define F6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(A), as_bf16x8(B), C, 0, 0, 0)
+constexpr int F6_GI = 16;               // items per step
+
+__global__ __launch_bounds__(256) void split_items_kernel_v6(const float* __restrict__ table, int n_items, int n_tiles,
+                                                             uint4* __restrict__ frags) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;   // (group, k-step, lane)
+    if (g >= static_cast<int64_t>(n_tiles) * 2 * 2 * 64) return;
+    const int lane = static_cast<int>(g & 63), ks = static_cast<int>((g >> 6) & 1);
+    const int64_t G = g >> 7;
+    int64_t item = G * F6_GI + (lane & 15);
+    if (item >= n_items) item = n_items - 1;
+    const float4* src = reinterpret_cast<const float4*>(table + item * FE_D + ks * 32 + 8 * (lane >> 4));
+    const float4 v0 = src[0], v1 = src[1];
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    uint4 hi, mid, lo;
+    split3x8(v, hi, mid, lo);
+    uint4* dst = frags + G * F4_HALF_U4 + (ks * 3) * 64 + lane;
+    dst[0] = hi;
+    dst[64] = mid;
+    dst[128] = lo;
+}
+
+struct CandRegs6 {
+    int cnt[4];   // list length of user 16 g + (lane & 15), the same value in the four lanes that share the user
+};
+
+__device__ __forceinline__ void cand6_sync_to_lds(const WaveCtx& w, const CandRegs6& cr) {
+    if (w.lane < 16) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) w.cnt[16 * g + w.lane] = cr.cnt[g];
+    }
+    __threadfence_block();
+}
+
+__device__ __forceinline__ float select4(const f32x4& v, int r) {
+    const float a0 = (r & 1) ? v[1] : v[0], a1 = (r & 1) ? v[3] : v[2];
+    return (r & 2) ? a1 : a0;
+}
+
+// candidate path of one finished item group (taken only when some score of the wavefront passed its threshold)
+__device__ __forceinline__ void group_candidates_v6(const FusedArgs& a, const WaveCtx& w, const f32x4 (&acc)[4], int base,
+                                                    float (&thr)[4], CandRegs6& cr) {
+    const int qd = w.lane >> 4, c16 = w.lane & 15;
+    uint32_t m[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint32_t mm = 0;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) mm = 2u * mm + ((acc[g][i] > thr[g]) ? 1u : 0u);
+        m[g] = mm;
+    }
+    if (base + F6_GI > a.n_items) {   // only the last tile has rows that are not items
+        uint32_t valid = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (base + 4 * qd + i < a.n_items) valid |= 1u << i;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) m[g] &= valid;
+    }
+    if (!__any((m[0] | m[1] | m[2] | m[3]) != 0u)) return;
+    // the four groups' counts in one register (a byte each), every quarter's register brought to every lane:
+    // permlane16_swap(x, x) = {rows 0 0 2 2 of x, rows 1 1 3 3 of x}, permlane32_swap of each spreads a half's value
+    const uint32_t packed = static_cast<uint32_t>(__popc(m[0])) | (static_cast<uint32_t>(__popc(m[1])) << 8) |
+                            (static_cast<uint32_t>(__popc(m[2])) << 16) | (static_cast<uint32_t>(__popc(m[3])) << 24);
+    const auto e = __builtin_amdgcn_permlane16_swap(packed, packed, false, false);
+    const auto ev = __builtin_amdgcn_permlane32_swap(e[0], e[0], false, false);   // [0]: quarter 0's, [1]: quarter 2's
+    const auto od = __builtin_amdgcn_permlane32_swap(e[1], e[1], false, false);   // [0]: quarter 1's, [1]: quarter 3's
+    const uint32_t p0 = ev[0], p1 = od[0], p2 = ev[1], p3 = od[1];
+    const uint32_t total = p0 + p1 + p2 + p3;                                     // <= 16 per byte
+    const uint32_t before = (qd > 0 ? p0 : 0u) + (qd > 1 ? p1 : 0u) + (qd > 2 ? p2 : 0u);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint32_t mm = m[g];
+        uint64_t* list = w.my_cand + static_cast<int64_t>(16 * g + c16) * a.cap + cr.cnt[g] + static_cast<int>((before >> (8 * g)) & 0xffu);
+        cr.cnt[g] += static_cast<int>((total >> (8 * g)) & 0xffu);   // <= trigger + 16 <= cap by the compaction rule
+        while (mm) {
+            const int r = __ffs(static_cast<int>(mm)) - 1;
+            mm &= mm - 1;
+            *list++ = skr::rank_key(select4(acc[g], r), base + 4 * qd + r);
+        }
+    }
+    uint64_t need = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) need |= (__ballot(cr.cnt[g] > a.trigger) & 0xffffull) << (16 * g);
+    if (need) {
+        cand6_sync_to_lds(w, cr);
+        while (need) {
+            const int ul = __ffsll(static_cast<long long>(need)) - 1;
+            need &= need - 1;
+            const float nt = compact_user(a, w, ul, -1);
+            const int ug = ul >> 4;   // wave-uniform
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (g == ug && c16 == (ul & 15)) thr[g] = nt;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cr.cnt[g] = w.cnt[16 * g + c16];
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler (see tile_candidates_v4)
+    }
+}
+
+// VAR: timing experiments on the bare loop (SKR_FUSED_ABLATE 13..15; results are wrong by construction): 1 = no threshold
+// tests between the MFMAs, 2 = no fragment reads (the first group's fragments are reused), 3 = both
+template <bool HAS_BIAS, int VAR = 0>
+__global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedArgs a, const uint4* __restrict__ frags) {
+    __shared__ uint4 s_tile[F5_RING * F4_HALF_U4];             // ONE ring of F5_RING item groups for the workgroup's four wavefronts
+    __shared__ float4 s_bias[3][16];                           // a tile's bias row (the DMA writes 4 B for each of the 64 lanes: 32 items, twice);
+                                                               // three rows: tile t+2's arrives while t's is read in both of t's steps
+    __shared__ int s_cnt[FE_WAVES][FE_UW];
+    __shared__ int64_t s_row_beg[FE_WAVES][FE_UW];
+    __shared__ int s_row_len[FE_WAVES][FE_UW];
+    __shared__ int s_rowbuf[FE_WAVES][F4_ROWBUF];
+    WaveCtx w;
+    w.lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: it selects DMA blocks (scalar operands)
+    w.c = w.lane & 31;
+    w.h = w.lane >> 5;
+    const int lane = w.lane, c16 = w.lane & 15, qd = w.lane >> 4;
+    w.ubase = (static_cast<int64_t>(blockIdx.x) * FE_WAVES + wv) * FE_UW;
+    // a wavefront whose users lie beyond B stays: it carries its share of the DMA and of the workgroup barriers
+    w.cnt = s_cnt[wv];
+    w.cnt[lane] = 0;
+    w.my_cand = a.cand + w.ubase * a.cap;
+    w.row_beg = s_row_beg[wv];
+    w.row_len = s_row_len[wv];
+    w.rowbuf = s_rowbuf[wv];
+    w.rowbuf_len = F4_ROWBUF;
+    {
+        const int64_t row = w.ubase + lane;
+        int64_t rb = 0;
+        int len = 0;
+        if (a.train_rowptr && row < a.B) {
+            const int u = a.users[row];
+            rb = a.train_rowptr[u];
+            len = static_cast<int>(a.train_rowptr[u + 1] - rb);
+        }
+        w.row_beg[lane] = rb;
+        w.row_len[lane] = len;
+    }
+    // user fragments: B[k = 8 qd + j][col c16] of user group g and k-step ks, three pieces each
+    uint4 bh[4][2], bm[4][2], bl[4][2];
+    float thr[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int64_t row = w.ubase + 16 * g + c16;
+        const bool ok = row < a.B;
+        const int uid = a.users[ok ? row : (a.B - 1)];
+        thr[g] = (ok && a.ablate != 1 && a.ablate != 7 && a.ablate != 11 && a.ablate < 12) ? -INFINITY : INFINITY;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid) * FE_D + ks * 32 + 8 * qd);
+            const float4 v0 = up[0], v1 = up[1];
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            split3x8(v, bh[g][ks], bm[g][ks], bl[g][ks]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {   // retire the loads here (see the fp32 kernel: hidden DMA vs counted vmcnt)
+            asm volatile("" : "+v"(bh[g][ks].x), "+v"(bh[g][ks].y), "+v"(bh[g][ks].z), "+v"(bh[g][ks].w));
+            asm volatile("" : "+v"(bm[g][ks].x), "+v"(bm[g][ks].y), "+v"(bm[g][ks].z), "+v"(bm[g][ks].w));
+            asm volatile("" : "+v"(bl[g][ks].x), "+v"(bl[g][ks].y), "+v"(bl[g][ks].z), "+v"(bl[g][ks].w));
+        }
+    const int n_tiles = (a.n_items + FE_TI - 1) / FE_TI;
+    const int n_half = 2 * n_tiles;                 // item groups (the second one of the last tile may lie wholly beyond n_items)
+    const uint32_t lt = lds_addr_of(&s_tile[0]);
+    const uint32_t lb0 = lds_addr_of(&s_bias[0][0]);
+    const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+    auto issue_half = [&](int hs, int slot, int brow) {   // group hs -> ring slot; with a tile's first group travels the tile's bias row (-> s_bias[brow])
+        const char* sbase = reinterpret_cast<const char*>(frags) + static_cast<int64_t>(hs) * (F4_HALF_U4 * 16);   // wave-uniform
+        const uint32_t dst = lt + slot * (F4_HALF_U4 * 16);
+        glds_b128_s(lane16, sbase + wv * 1024, dst + wv * 1024);
+        if (wv < 2) glds_b128_s(lane16, sbase + (4 + wv) * 1024, dst + (4 + wv) * 1024);
+        if (HAS_BIAS && !(hs & 1) && wv == 3) {
+            int bi = (hs >> 1) * FE_TI + (lane & 31);
+            bi = bi < a.n_items ? bi : a.n_items - 1;
+            glds_b32(a.item_bias + bi, lb0 + static_cast<uint32_t>(brow) * 256u);
+        }
+    };
+#pragma unroll
+    for (int h0 = 0; h0 < F5_RING; ++h0)
+        if (h0 < n_half) issue_half(h0, h0, h0 >> 1);   // n_half >= 2 always
+    FE2_WAIT();
+    __syncthreads();                                // every wavefront's blocks have landed
+    uint4 afA[6], afB[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) afA[i] = s_tile[i * 64 + lane];
+    if (VAR & 2) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) afB[i] = afA[i];
+    }
+    f32x4 accA[4], accB[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accB[g][i] = -INFINITY;   // "group -1": nothing passes
+    CandRegs6 cr{{0, 0, 0, 0}};
+    int slot = 0;                                   // ring slot of the group held in afA at an even step
+    int brow = 0, brow2 = 2;                        // bias rows of tile t and of tile t + 2 (t mod 3)
+    // one step = one item group.  Prologue as in v5 (fragments of group hs in registers -> its slot takes the DMA of group
+    // hs+3; the fragments of hs+1 are fetched behind a counted wait); then 12 slots of four MFMAs (one piece product on
+    // the four user groups), slots 0..7 each carrying two threshold tests of group hs-1.
+#define F6_SLOT(S, AF, BP, ACC, PRV)                                                                          \
+    {                                                                                                         \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                      \
+            ACC[g_] = F6_MFMA(AF, BP[g_][(S) / 6], (S) == 0 ? seed_ : ACC[g_]);                               \
+        if ((S) < 8) {                                                                                        \
+            const int i_ = (S) & 3, gp_ = (((S) & 7) >> 2) * 2;                                               \
+            if (!(VAR & 1)) any_ |= (PRV[gp_][i_] > thr[gp_]) | (PRV[gp_ + 1][i_] > thr[gp_ + 1]);            \
+            else asm volatile("" :: "v"(PRV[gp_][i_]), "v"(PRV[gp_ + 1][i_]));   /* keeps the MFMAs alive */  \
+        }                                                                                                     \
+        FE3_PIN();                                                                                            \
+    }
+#define F6_STEP(CUR, NXT, HS, ACC, PRV)                                                                       \
+    {                                                                                                         \
+        const int hs_ = (HS);                                                                                 \
+        FE3_PIN();                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* CUR has landed in registers */                \
+        FE3_PIN();                                                                                            \
+        const bool more3_ = hs_ + F5_RING < n_half && a.ablate != 7 && a.ablate != 11 && a.ablate < 12;       \
+        const int nslot_ = slot == F5_RING - 1 ? 0 : slot + 1;                                                \
+        if (hs_ + 1 < n_half) {                                                                               \
+            if (hs_ + 2 >= n_half) FE2_WAIT();                                                                \
+            else if (wv < 2 || (HAS_BIAS && !(hs_ & 1) && wv == 3)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); \
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                             \
+        }                                                                                                     \
+        if (a.ablate != 11) __syncthreads();   /* 11: timing experiment, bare loop without the barrier */     \
+        FE3_PIN();                                                                                            \
+        if (more3_) issue_half(a.ablate == 8 ? ((hs_ + F5_RING) & 31) : hs_ + F5_RING, slot, brow2);          \
+        /* the bias read goes first: LDS answers in order, so the first MFMA waits for it alone (counted) */  \
+        f32x4 seed_;                                                                                          \
+        if (HAS_BIAS) {                                                                                       \
+            const float4 b4 = s_bias[brow][4 * (hs_ & 1) + qd];                                               \
+            seed_[0] = b4.x; seed_[1] = b4.y; seed_[2] = b4.z; seed_[3] = b4.w;                               \
+        } else {                                                                                              \
+            seed_[0] = 0.0f; seed_[1] = 0.0f; seed_[2] = 0.0f; seed_[3] = 0.0f;                               \
+        }                                                                                                     \
+        FE3_PIN();                                                                                            \
+        /* unconditional (behind the last group it fetches a stale slot that nobody uses): a branch here would make  \
+           hipcc wait for ALL LDS reads in front of the first MFMA */                                         \
+        if (!(VAR & 2)) {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i) NXT[i] = s_tile[nslot_ * F4_HALF_U4 + i * 64 + lane]; \
+        } else {                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(NXT[i].x), "+v"(NXT[i].y), "+v"(NXT[i].z), "+v"(NXT[i].w)); \
+        }                                                                                                     \
+        bool any_ = false;                                                                                    \
+        FE3_PIN();                                                                                            \
+        /* small terms first, per k-step: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi */                     \
+        F6_SLOT(0, CUR[2], bh, ACC, PRV)  F6_SLOT(1, CUR[0], bl, ACC, PRV)  F6_SLOT(2, CUR[1], bm, ACC, PRV)  \
+        F6_SLOT(3, CUR[1], bh, ACC, PRV)  F6_SLOT(4, CUR[0], bm, ACC, PRV)  F6_SLOT(5, CUR[0], bh, ACC, PRV)  \
+        F6_SLOT(6, CUR[5], bh, ACC, PRV)  F6_SLOT(7, CUR[3], bl, ACC, PRV)  F6_SLOT(8, CUR[4], bm, ACC, PRV)  \
+        F6_SLOT(9, CUR[4], bh, ACC, PRV)  F6_SLOT(10, CUR[3], bm, ACC, PRV) F6_SLOT(11, CUR[3], bh, ACC, PRV) \
+        if (__any(any_)) group_candidates_v6(a, w, PRV, (hs_ - 1) * F6_GI, thr, cr);                          \
+        slot = nslot_;                                                                                        \
+    }
+    for (int t = 0; t < n_tiles; ++t) {
+        F6_STEP(afA, afB, 2 * t, accA, accB)
+        F6_STEP(afB, afA, 2 * t + 1, accB, accA)
+        brow = brow == 2 ? 0 : brow + 1;
+        brow2 = brow2 == 2 ? 0 : brow2 + 1;
+    }
+#undef F6_STEP
+#undef F6_SLOT
+    {
+        bool any_ = false;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) any_ |= accB[g][i] > thr[g];
+        if (__any(any_)) group_candidates_v6(a, w, accB, (n_half - 1) * F6_GI, thr, cr);
+    }
+    cand6_sync_to_lds(w, cr);
+    if (a.ablate >= 12) return;   // timing experiment: bare loop without the final compactions
+    for (int ul = 0; ul < FE_UW; ++ul) {
+        const int64_t row = w.ubase + ul;
+        if (row >= a.B) break;
+        compact_user(a, w, ul, row);
+    }
+}
+
 // list capacity per user.  Measured on MI355X (K = 10..100, 262 144 users): 512-entry lists with a
 // trigger of 480 were no faster than 256 / 224 once the mid-sweep compaction selects instead of sorting
 // (profiles/r01_eval_history.txt), so the smaller scratch footprint stays.
@@ -1173,13 +1476,15 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     // arithmetic mode, read per call: "bf16x3" (default) or "fp32" (the FP32-MFMA kernel)
     const char* mode_env = getenv("SKR_FUSED_MODE");
     const std::string mode = mode_env ? mode_env : "bf16x3";
-    SKR_REQUIRE(mode == "fp32" || mode == "bf16x3" || mode == "bf16x3s" || mode == "bf16x3w",
-                "SKR_FUSED_MODE must be 'bf16x3', 'bf16x3s', 'bf16x3w' or 'fp32' (got '%s')", mode_env);
+    SKR_REQUIRE(mode == "fp32" || mode == "bf16x3" || mode == "bf16x3s" || mode == "bf16x3w" || mode == "bf16x3g",
+                "SKR_FUSED_MODE must be 'bf16x3', 'bf16x3g', 'bf16x3s', 'bf16x3w' or 'fp32' (got '%s')", mode_env);
     const bool mode_bf16x3 = mode != "fp32";
     // bf16x3: the workgroup-shared tile ring (v5) for short lists, the ring per wavefront (v4) for long ones -- measured on
     // 262 144 users x 100 k items: top-10 17.3 vs 18.1 ms, top-50 21.2 vs 21.4, top-100 25.3 vs 25.1 (a wavefront that compacts
     // a list holds its three neighbours at the next barrier, and long lists are compacted more often); "s" / "w" force one
     const bool shared_ring = mode == "bf16x3s" || (mode == "bf16x3" && top_k <= 32);
+    // "g": the 16x16x32 form (fused_topk_kernel_v6: steps of 16 items, the threshold tests between the next step's MFMAs)
+    const bool groups16 = mode == "bf16x3g";
     if (mode_bf16x3) {
         // library-owned scratch for the split item table (38 MB at 100 k items), grown on demand
         static uint4* frag_buf = nullptr;
@@ -1197,11 +1502,25 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
             frag_cap = need;
         }
         const int64_t nthr = static_cast<int64_t>(n_tiles) * 256;
-        hipLaunchKernelGGL(split_items_kernel, dim3(static_cast<unsigned>((nthr + 255) / 256)), dim3(256), 0, st, d_item_table,
-                           n_items, n_tiles, frag_buf);
+        if (groups16)
+            hipLaunchKernelGGL(split_items_kernel_v6, dim3(static_cast<unsigned>((nthr + 255) / 256)), dim3(256), 0, st, d_item_table,
+                               n_items, n_tiles, frag_buf);
+        else
+            hipLaunchKernelGGL(split_items_kernel, dim3(static_cast<unsigned>((nthr + 255) / 256)), dim3(256), 0, st, d_item_table,
+                               n_items, n_tiles, frag_buf);
         SKR_LAUNCH_CHECK();
         static const unsigned dyn_lds = [] { const char* e = getenv("SKR_FUSED_DYN_LDS"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();   // occupancy experiments
-        if (shared_ring) {
+        if (groups16) {
+            if (d_item_bias)
+                switch (ablate) {
+                    case 13: hipLaunchKernelGGL((fused_topk_kernel_v6<true, 1>), dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf); break;
+                    case 14: hipLaunchKernelGGL((fused_topk_kernel_v6<true, 2>), dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf); break;
+                    case 15: hipLaunchKernelGGL((fused_topk_kernel_v6<true, 3>), dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf); break;
+                    default: hipLaunchKernelGGL((fused_topk_kernel_v6<true, 0>), dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
+                }
+            else
+                hipLaunchKernelGGL((fused_topk_kernel_v6<false, 0>), dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
+        } else if (shared_ring) {
             if (d_item_bias)
                 hipLaunchKernelGGL(fused_topk_kernel_v5<true>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
             else
