@@ -622,9 +622,11 @@ def eval_leg(args, world, rank, dev, dist, U, V, bias, ds, nU, nI, out):
         else:
             # every fp32 product is formed from six bf16 x bf16 MFMA products with fp32 accumulation, so the matrix
             # pipe issues 6x the algorithmic flops: the peak for THIS arithmetic is the dense bf16 peak / 6
-            v5 = mode == "bf16x3s" or (mode == "bf16x3" and args.top_k <= 32)
-            out["roofline_eval"] = {"kernel": ("fused_topk_kernel_v5 (one item-tile ring per workgroup; " if v5 else
-                                               "fused_topk_kernel_v4 (one item-tile ring per wavefront; ") +
+            kname = {"bf16x3s": "fused_topk_kernel_v5 (v_mfma_f32_32x32x16_bf16, one item-tile ring per workgroup; ",
+                     "bf16x3w": "fused_topk_kernel_v4 (v_mfma_f32_32x32x16_bf16, one item-tile ring per wavefront; "}.get(
+                mode, "fused_topk_kernel_v6 (v_mfma_f32_16x16x32_bf16, steps of 16 items, threshold tests between the MFMAs, "
+                      "one item ring per workgroup; ")
+            out["roofline_eval"] = {"kernel": kname +
                                               "fp32 operands split into 3 bf16 pieces, 6 bf16 MFMAs per "
                                               "fp32 product, fp32 accumulate; GEMM + mask + top-K)", "bound": "mfma",
                                     "achieved": tf, "peak": MFMA_BF16_PEAK_TF / 6.0, "unit": "TFLOP/s", "unit_note": "fp32-equivalent (algorithmic 2*B*I*64 flop)",

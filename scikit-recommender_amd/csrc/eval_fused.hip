@@ -112,10 +112,29 @@ struct WaveCtx {
     int rowbuf_len;      // its capacity in ints (a multiple of 64, at most FE_ROWBUF)
 };
 
+// The user's train row, fetched into registers when it is short enough to be staged in LDS: issued TOGETHER with the loads
+// of the candidate list (one memory round trip per compaction instead of two: a compaction holds the three other
+// wavefronts of its workgroup at the next barrier for as long as it takes).
+struct RowRegs {
+    int v[FE_ROWBUF / 64];
+};
+__device__ __forceinline__ RowRegs prefetch_row(const FusedArgs& a, const WaveCtx& w, int ul) {
+    RowRegs r;
+    const int len = w.row_len[ul];   // wave-uniform
+    const int32_t* __restrict__ row = a.train_items + w.row_beg[ul];
+#pragma unroll
+    for (int e = 0; e < FE_ROWBUF / 64; ++e) {
+        const int idx = e * 64 + w.lane;
+        r.v[e] = (len <= w.rowbuf_len && idx < len) ? row[idx] : 0;
+    }
+    return r;
+}
+
 // Drop the user's train items from the NR keys each lane holds: NR binary searches per lane advance in
 // lock-step, so a compaction pays ceil(log2(row length)) dependent load latencies, not NR times that.
 template <int NR>
-__device__ __forceinline__ void mask_train_lockstep(const FusedArgs& a, const WaveCtx& w, int ul, uint64_t (&k)[NR]) {
+__device__ __forceinline__ void mask_train_lockstep(const FusedArgs& a, const WaveCtx& w, int ul, uint64_t (&k)[NR],
+                                                    const RowRegs& rr) {
     const int len = w.row_len[ul];   // wave-uniform
     if (len <= 0) return;
     const int32_t* __restrict__ row = a.train_items + w.row_beg[ul];
@@ -133,7 +152,7 @@ __device__ __forceinline__ void mask_train_lockstep(const FusedArgs& a, const Wa
 #pragma unroll
         for (int e = 0; e < FE_ROWBUF / 64; ++e) {
             const int idx = e * 64 + w.lane;
-            if (idx < len) buf[idx] = row[idx];   // len <= rowbuf_len bounds the writes
+            if (idx < len) buf[idx] = rr.v[e];    // len <= rowbuf_len bounds the writes
         }
         __threadfence_block();   // the wave's own LDS writes, ordered before its reads
         for (int s = 0; s < steps; ++s) {
@@ -176,21 +195,13 @@ __device__ __forceinline__ void mask_train_lockstep(const FusedArgs& a, const Wa
     }
 }
 
-// Sort user `ul`'s candidate list (at most 64*NR entries), drop train items, keep the best top_k at
-// the front.  Returns the new threshold (score of the K-th best, or -inf while fewer than K are
-// known).  If out_row >= 0 the final top_k ids / scores are also written to the outputs.
+// End of the sweep: sort user `ul`'s candidate list (at most 64*NR entries, already in registers together with the
+// train row), drop train items, write the best top_k ids / scores to the outputs.
 template <int NR>
-__device__ __forceinline__ float compact_user_n(const FusedArgs& a, const WaveCtx& w, int ul, int n, int64_t out_row) {
+__device__ __forceinline__ void final_user(const FusedArgs& a, const WaveCtx& w, int ul, uint64_t (&k)[NR], const RowRegs& rr,
+                                           int64_t out_row) {
     const int lane = w.lane;
-    uint64_t* __restrict__ list = w.my_cand + static_cast<int64_t>(ul) * a.cap;
-    int* cnt_p = &w.cnt[ul];
-    uint64_t k[NR];
-#pragma unroll
-    for (int e = 0; e < NR; ++e) {
-        const int idx = e * 64 + lane;
-        k[e] = (idx < n) ? list[idx] : SKR_KEY_MIN;
-    }
-    mask_train_lockstep<NR>(a, w, ul, k);
+    mask_train_lockstep<NR>(a, w, ul, k, rr);
     wave_sort_desc<NR>(k, lane);
     int valid = 0;
 #pragma unroll
@@ -201,23 +212,55 @@ __device__ __forceinline__ float compact_user_n(const FusedArgs& a, const WaveCt
     for (int e = 0; e < 2 && e < NR; ++e) {  // top_k <= 128: the survivors live in elements 0..127
         const int idx = e * 64 + lane;
         if (idx < keep) {
-            list[idx] = k[e];
-            if (out_row >= 0) {
-                if (a.out_ids) a.out_ids[out_row * K + idx] = skr::key_id(k[e]);
-                if (a.out_scores) a.out_scores[out_row * K + idx] = skr::key_score(k[e]);
-            }
+            if (a.out_ids) a.out_ids[out_row * K + idx] = skr::key_id(k[e]);
+            if (a.out_scores) a.out_scores[out_row * K + idx] = skr::key_score(k[e]);
         }
     }
-    if (lane == 0) *cnt_p = keep;
-    float thr = -INFINITY;
-    if (keep == K) {
-        const int src = (K - 1) & 63;
-        const uint64_t ke = (NR > 1 && ((K - 1) >> 6)) ? k[NR > 1 ? 1 : 0] : k[0];
-        const int lo = __shfl(static_cast<int>(static_cast<uint32_t>(ke)), src, 64);
-        const int hi = __shfl(static_cast<int>(static_cast<uint32_t>(ke >> 32)), src, 64);
-        thr = skr::key_score((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo));
+}
+
+// The final compactions of a wavefront's users, software-pipelined: the loads of user ul + 1 (candidate list and train
+// row) are in flight while user ul is masked and sorted -- run one after the other a user costs two dependent memory
+// round trips, 64 times per wavefront, at a point where every wavefront of the chip is doing the same and no MFMA runs.
+template <int NR>
+__device__ __forceinline__ void final_compactions_n(const FusedArgs& a, const WaveCtx& w) {
+    const int64_t left = static_cast<int64_t>(a.B) - w.ubase;
+    const int n_users = left < FE_UW ? static_cast<int>(left) : FE_UW;
+    if (n_users <= 0) return;
+    __threadfence_block();   // the wave's appends, re-read below by other lanes of the same wave
+    uint64_t kn[NR];
+    RowRegs rn;
+    int nn = 0;
+    auto fetch = [&](int ul) {
+        const int n = w.cnt[ul];   // wave-uniform
+        nn = n;
+        const uint64_t* __restrict__ list = w.my_cand + static_cast<int64_t>(ul) * a.cap;
+        rn = prefetch_row(a, w, ul);
+#pragma unroll
+        for (int e = 0; e < NR; ++e) {
+            const int idx = e * 64 + w.lane;
+            kn[e] = (idx < n) ? list[idx] : SKR_KEY_MIN;
+        }
+    };
+    fetch(0);
+    for (int ul = 0; ul < n_users; ++ul) {
+        uint64_t k[NR];
+#pragma unroll
+        for (int e = 0; e < NR; ++e) k[e] = kn[e];
+        const RowRegs rr = rn;
+        const int n = nn;
+        if (ul + 1 < n_users) fetch(ul + 1);
+        if (n <= 64 && a.top_k <= 64) {   // the common case at top-10: a 64-key sort instead of a 128-key one
+            uint64_t k1[1] = {k[0]};
+            final_user<1>(a, w, ul, k1, rr, w.ubase + ul);
+        } else {
+            final_user<NR>(a, w, ul, k, rr, w.ubase + ul);
+        }
     }
-    return thr;
+}
+__device__ __forceinline__ void final_compactions(const FusedArgs& a, const WaveCtx& w) {
+    // a list never holds more than trigger + 32 entries (the compaction rule)
+    if (a.trigger + FE_TI <= 128) final_compactions_n<2>(a, w);
+    else final_compactions_n<4>(a, w);
 }
 
 // smallest real key among the NR*64 held by the wave (the K-th best when exactly K are real)
@@ -248,13 +291,14 @@ __device__ __forceinline__ float compact_select_n(const FusedArgs& a, const Wave
     uint64_t* __restrict__ list = w.my_cand + static_cast<int64_t>(ul) * a.cap;
     int* cnt_p = &w.cnt[ul];
     uint64_t k[NR];
+    const RowRegs rr = prefetch_row(a, w, ul);
 #pragma unroll
     for (int e = 0; e < NR; ++e) {
         const int idx = e * 64 + lane;
         k[e] = (idx < n) ? list[idx] : SKR_KEY_MIN;
     }
-    mask_train_lockstep<NR>(a, w, ul, k);
-    if (a.ablate == 6) mask_train_lockstep<NR>(a, w, ul, k);
+    mask_train_lockstep<NR>(a, w, ul, k, rr);
+    if (a.ablate == 6) mask_train_lockstep<NR>(a, w, ul, k, rr);
     const int K = a.top_k;
     int valid = 0;
 #pragma unroll
@@ -307,19 +351,14 @@ __device__ __forceinline__ float compact_select_n(const FusedArgs& a, const Wave
     return (base == K && valid >= K) ? skr::key_score(valid > K ? T : kth_min_key<NR>(k, lane)) : -INFINITY;
 }
 
-__device__ __forceinline__ float compact_user(const FusedArgs& a, const WaveCtx& w, int ul, int64_t out_row) {
+// mid-sweep compaction of one list; returns the user's new threshold
+__device__ __forceinline__ float compact_user(const FusedArgs& a, const WaveCtx& w, int ul, int64_t /*unused: mid-sweep only*/) {
     __threadfence_block();  // this wave's earlier appends are re-read below by other lanes of the same wave (same CU, same L1: in order)
     const int n = w.cnt[ul];   // wave-uniform
     float thr;
-    if (out_row < 0) {      // mid-sweep: select
-        if (n <= 64) thr = compact_select_n<1>(a, w, ul, n);
-        else if (n <= 128) thr = compact_select_n<2>(a, w, ul, n);
-        else thr = compact_select_n<4>(a, w, ul, n);
-    } else {                // end of the sweep: sort, write the results
-        if (n <= 64 && a.top_k <= 64) thr = compact_user_n<1>(a, w, ul, n, out_row);
-        else if (n <= 128) thr = compact_user_n<2>(a, w, ul, n, out_row);
-        else thr = compact_user_n<4>(a, w, ul, n, out_row);
-    }
+    if (n <= 64) thr = compact_select_n<1>(a, w, ul, n);
+    else if (n <= 128) thr = compact_select_n<2>(a, w, ul, n);
+    else thr = compact_select_n<4>(a, w, ul, n);
     __threadfence_block();
     return thr;
 }
@@ -619,11 +658,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v3(FusedAr
 #undef FE3_FAST_STEP
 #undef FE3_SEED
 #undef FE3_READ_HALF
-    for (int ul = 0; ul < FE_UW; ++ul) {
-        const int64_t row = w.ubase + ul;
-        if (row >= a.B) break;
-        compact_user(a, w, ul, row);
-    }
+    final_compactions(a, w);
 }
 
 // ================================================================================================
@@ -944,11 +979,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v4(FusedAr
     }
 #undef F4_STEP
     cand_sync_to_lds(w, cr);
-    for (int ul = 0; ul < FE_UW; ++ul) {
-        const int64_t row = w.ubase + ul;
-        if (row >= a.B) break;
-        compact_user(a, w, ul, row);
-    }
+    final_compactions(a, w);
 }
 
 constexpr int F5_RING = 3;              // half tiles resident per WORKGROUP (the counted waits and the two bias rows assume 3)
@@ -1116,11 +1147,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v5(FusedAr
     }
 #undef F5_STEP
     cand_sync_to_lds(w, cr);
-    for (int ul = 0; ul < FE_UW; ++ul) {
-        const int64_t row = w.ubase + ul;
-        if (row >= a.B) break;
-        compact_user(a, w, ul, row);
-    }
+    final_compactions(a, w);
 }
 
 // ================================================================================================
@@ -1136,8 +1163,9 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v5(FusedAr
 //     (one v_cmp + one scalar OR per accumulator register, pinned two per slot), with no second accumulator pair: what
 //     VERDICT round 2, item 4 asked for without the 32 VGPRs it was priced at;
 //   * lane l holds, per user group g, the scores of user 16 g + (l & 15) against items 4 (l >> 4) + i, i < 4: a user's
-//     16 scores of a step sit in four lanes, the list lengths live in registers replicated over those four lanes and the
-//     passing counts cross them by v_permlane16_swap / v_permlane32_swap (no LDS trip);
+//     16 scores of a step sit in four lanes; the list lengths live in LDS and a passing lane reserves its slot with one
+//     LDS atomic (group_candidates_v6; a first form carried the lengths in registers and crossed the four lanes' counts
+//     by v_permlane16_swap / v_permlane32_swap: correct, ~4x the vector instructions per event);
 //   * everything outside the arithmetic is v5's: ONE ring of three 6 KB blocks per workgroup (a block = one item group:
 //     2 k-steps x 3 pieces), brought by the four wavefronts together, one workgroup barrier per step, candidate lists in
 //     HBM scratch, the same compaction code.
@@ -1167,70 +1195,32 @@ __global__ __launch_bounds__(256) void split_items_kernel_v6(const float* __rest
     dst[128] = lo;
 }
 
-struct CandRegs6 {
-    int cnt[4];   // list length of user 16 g + (lane & 15), the same value in the four lanes that share the user
-};
-
-__device__ __forceinline__ void cand6_sync_to_lds(const WaveCtx& w, const CandRegs6& cr) {
-    if (w.lane < 16) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) w.cnt[16 * g + w.lane] = cr.cnt[g];
-    }
-    __threadfence_block();
-}
-
-__device__ __forceinline__ float select4(const f32x4& v, int r) {
-    const float a0 = (r & 1) ? v[1] : v[0], a1 = (r & 1) ? v[3] : v[2];
-    return (r & 2) ? a1 : a0;
-}
-
-// candidate path of one finished item group (taken only when some score of the wavefront passed its threshold)
-__device__ __forceinline__ void group_candidates_v6(const FusedArgs& a, const WaveCtx& w, const f32x4 (&acc)[4], int base,
-                                                    float (&thr)[4], CandRegs6& cr) {
+// Candidate path of one finished item group, taken only when some score of the wavefront passed its threshold.  The
+// sixteen threshold tests were made between the MFMAs (one lane mask per accumulator register); here every register
+// with a passing lane is handled under that mask: the lane reserves a slot of its user's list with ONE LDS atomic on the
+// list length (up to four lanes hold scores of the same user) and stores the key.  Rows of the last tile that are not
+// items carry -inf (the kernel seeds them so) and never pass.  No per-lane bit masks, no counts
+// carried between lanes, no loops: ~10 vector instructions per register that has an event, none for the others.
+// (Tried and dropped: counting the key stores left in flight and adding them to the counted vmcnt waits of the tile DMA,
+// which otherwise also wait for those younger stores -- no gain, the extra branches cost what the shorter waits saved.)
+__device__ __forceinline__ void group_candidates_v6(const FusedArgs& a, const WaveCtx& w, const f32x4 (&acc)[4],
+                                                    const bool (&pass)[4][4], int base, float (&thr)[4]) {
     const int qd = w.lane >> 4, c16 = w.lane & 15;
-    uint32_t m[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        uint32_t mm = 0;
-#pragma unroll
-        for (int i = 3; i >= 0; --i) mm = 2u * mm + ((acc[g][i] > thr[g]) ? 1u : 0u);
-        m[g] = mm;
-    }
-    if (base + F6_GI > a.n_items) {   // only the last tile has rows that are not items
-        uint32_t valid = 0;
+        int* cnt_p = &w.cnt[16 * g + c16];
+        uint64_t* list = w.my_cand + static_cast<int64_t>(16 * g + c16) * a.cap;
+        int pos[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (base + 4 * qd + i < a.n_items) valid |= 1u << i;
+            if (pass[g][i]) pos[i] = __hip_atomic_fetch_add(cnt_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) m[g] &= valid;
+        for (int i = 0; i < 4; ++i)
+            if (pass[g][i]) list[pos[i]] = skr::rank_key(acc[g][i], base + 4 * qd + i);   // pos < trigger + 16 <= cap by the compaction rule
     }
-    if (!__any((m[0] | m[1] | m[2] | m[3]) != 0u)) return;
-    // the four groups' counts in one register (a byte each), every quarter's register brought to every lane:
-    // permlane16_swap(x, x) = {rows 0 0 2 2 of x, rows 1 1 3 3 of x}, permlane32_swap of each spreads a half's value
-    const uint32_t packed = static_cast<uint32_t>(__popc(m[0])) | (static_cast<uint32_t>(__popc(m[1])) << 8) |
-                            (static_cast<uint32_t>(__popc(m[2])) << 16) | (static_cast<uint32_t>(__popc(m[3])) << 24);
-    const auto e = __builtin_amdgcn_permlane16_swap(packed, packed, false, false);
-    const auto ev = __builtin_amdgcn_permlane32_swap(e[0], e[0], false, false);   // [0]: quarter 0's, [1]: quarter 2's
-    const auto od = __builtin_amdgcn_permlane32_swap(e[1], e[1], false, false);   // [0]: quarter 1's, [1]: quarter 3's
-    const uint32_t p0 = ev[0], p1 = od[0], p2 = ev[1], p3 = od[1];
-    const uint32_t total = p0 + p1 + p2 + p3;                                     // <= 16 per byte
-    const uint32_t before = (qd > 0 ? p0 : 0u) + (qd > 1 ? p1 : 0u) + (qd > 2 ? p2 : 0u);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        uint32_t mm = m[g];
-        uint64_t* list = w.my_cand + static_cast<int64_t>(16 * g + c16) * a.cap + cr.cnt[g] + static_cast<int>((before >> (8 * g)) & 0xffu);
-        cr.cnt[g] += static_cast<int>((total >> (8 * g)) & 0xffu);   // <= trigger + 16 <= cap by the compaction rule
-        while (mm) {
-            const int r = __ffs(static_cast<int>(mm)) - 1;
-            mm &= mm - 1;
-            *list++ = skr::rank_key(select4(acc[g], r), base + 4 * qd + r);
-        }
-    }
-    uint64_t need = 0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) need |= (__ballot(cr.cnt[g] > a.trigger) & 0xffffull) << (16 * g);
+    // the wavefront's LDS operations are executed in order: the lengths read here include every reservation above
+    uint64_t need = __ballot(w.cnt[w.lane] > a.trigger);
     if (need) {
-        cand6_sync_to_lds(w, cr);
         while (need) {
             const int ul = __ffsll(static_cast<long long>(need)) - 1;
             need &= need - 1;
@@ -1240,8 +1230,6 @@ __device__ __forceinline__ void group_candidates_v6(const FusedArgs& a, const Wa
             for (int g = 0; g < 4; ++g)
                 if (g == ug && c16 == (ul & 15)) thr[g] = nt;
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) cr.cnt[g] = w.cnt[16 * g + c16];
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler (see tile_candidates_v4)
     }
 }
@@ -1292,7 +1280,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
         const int64_t row = w.ubase + 16 * g + c16;
         const bool ok = row < a.B;
         const int uid = a.users[ok ? row : (a.B - 1)];
-        thr[g] = (ok && a.ablate != 1 && a.ablate != 7 && a.ablate != 11 && a.ablate < 12) ? -INFINITY : INFINITY;
+        thr[g] = (ok && a.ablate != 1 && a.ablate != 7 && a.ablate != 11 && (a.ablate < 12 || a.ablate > 15)) ? -INFINITY : INFINITY;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid) * FE_D + ks * 32 + 8 * qd);
@@ -1342,7 +1330,6 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) accB[g][i] = -INFINITY;   // "group -1": nothing passes
-    CandRegs6 cr{{0, 0, 0, 0}};
     int slot = 0;                                   // ring slot of the group held in afA at an even step
     int brow = 0, brow2 = 2;                        // bias rows of tile t and of tile t + 2 (t mod 3)
     // one step = one item group.  Prologue as in v5 (fragments of group hs in registers -> its slot takes the DMA of group
@@ -1354,18 +1341,22 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
             ACC[g_] = F6_MFMA(AF, BP[g_][(S) / 6], (S) == 0 ? seed_ : ACC[g_]);                               \
         if ((S) < 8) {                                                                                        \
             const int i_ = (S) & 3, gp_ = (((S) & 7) >> 2) * 2;                                               \
-            if (!(VAR & 1)) any_ |= (PRV[gp_][i_] > thr[gp_]) | (PRV[gp_ + 1][i_] > thr[gp_ + 1]);            \
+            if (!(VAR & 1)) {                                                                                 \
+                pass_[gp_][i_] = PRV[gp_][i_] > thr[gp_];                                                     \
+                pass_[gp_ + 1][i_] = PRV[gp_ + 1][i_] > thr[gp_ + 1];                                         \
+                any_ |= pass_[gp_][i_] | pass_[gp_ + 1][i_];                                                  \
+            }                                                                                                 \
             else asm volatile("" :: "v"(PRV[gp_][i_]), "v"(PRV[gp_ + 1][i_]));   /* keeps the MFMAs alive */  \
         }                                                                                                     \
         FE3_PIN();                                                                                            \
     }
-#define F6_STEP(CUR, NXT, HS, ACC, PRV)                                                                       \
+#define F6_STEP(CUR, NXT, HS, ACC, PRV, LAST)                                                                     \
     {                                                                                                         \
         const int hs_ = (HS);                                                                                 \
         FE3_PIN();                                                                                            \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* CUR has landed in registers */                \
         FE3_PIN();                                                                                            \
-        const bool more3_ = hs_ + F5_RING < n_half && a.ablate != 7 && a.ablate != 11 && a.ablate < 12;       \
+        const bool more3_ = hs_ + F5_RING < n_half && a.ablate != 7 && a.ablate != 11 && (a.ablate < 12 || a.ablate > 15); \
         const int nslot_ = slot == F5_RING - 1 ? 0 : slot + 1;                                                \
         if (hs_ + 1 < n_half) {                                                                               \
             if (hs_ + 2 >= n_half) FE2_WAIT();                                                                \
@@ -1391,39 +1382,46 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
         } else {                                                                                              \
             _Pragma("unroll") for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(NXT[i].x), "+v"(NXT[i].y), "+v"(NXT[i].z), "+v"(NXT[i].w)); \
         }                                                                                                     \
+        if (LAST) {   /* the last tile: rows beyond the catalogue start from -inf and stay there */            \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+                if (hs_ * F6_GI + 4 * qd + i >= a.n_items) seed_[i] = -INFINITY;                              \
+        }                                                                                                     \
         bool any_ = false;                                                                                    \
+        bool pass_[4][4] = {};                                                                                \
         FE3_PIN();                                                                                            \
         /* small terms first, per k-step: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi */                     \
         F6_SLOT(0, CUR[2], bh, ACC, PRV)  F6_SLOT(1, CUR[0], bl, ACC, PRV)  F6_SLOT(2, CUR[1], bm, ACC, PRV)  \
         F6_SLOT(3, CUR[1], bh, ACC, PRV)  F6_SLOT(4, CUR[0], bm, ACC, PRV)  F6_SLOT(5, CUR[0], bh, ACC, PRV)  \
         F6_SLOT(6, CUR[5], bh, ACC, PRV)  F6_SLOT(7, CUR[3], bl, ACC, PRV)  F6_SLOT(8, CUR[4], bm, ACC, PRV)  \
         F6_SLOT(9, CUR[4], bh, ACC, PRV)  F6_SLOT(10, CUR[3], bm, ACC, PRV) F6_SLOT(11, CUR[3], bh, ACC, PRV) \
-        if (__any(any_)) group_candidates_v6(a, w, PRV, (hs_ - 1) * F6_GI, thr, cr);                          \
+        if (__any(any_)) group_candidates_v6(a, w, PRV, pass_, (hs_ - 1) * F6_GI, thr);                       \
         slot = nslot_;                                                                                        \
     }
-    for (int t = 0; t < n_tiles; ++t) {
-        F6_STEP(afA, afB, 2 * t, accA, accB)
-        F6_STEP(afB, afA, 2 * t + 1, accB, accA)
+    for (int t = 0; t < n_tiles - 1; ++t) {
+        F6_STEP(afA, afB, 2 * t, accA, accB, false)
+        F6_STEP(afB, afA, 2 * t + 1, accB, accA, false)
         brow = brow == 2 ? 0 : brow + 1;
         brow2 = brow2 == 2 ? 0 : brow2 + 1;
     }
+    F6_STEP(afA, afB, 2 * (n_tiles - 1), accA, accB, true)
+    F6_STEP(afB, afA, 2 * (n_tiles - 1) + 1, accB, accA, true)
 #undef F6_STEP
 #undef F6_SLOT
     {
         bool any_ = false;
+        bool pass_[4][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) any_ |= accB[g][i] > thr[g];
-        if (__any(any_)) group_candidates_v6(a, w, accB, (n_half - 1) * F6_GI, thr, cr);
+            for (int i = 0; i < 4; ++i) {
+                pass_[g][i] = accB[g][i] > thr[g];
+                any_ |= pass_[g][i];
+            }
+        if (__any(any_)) group_candidates_v6(a, w, accB, pass_, (n_half - 1) * F6_GI, thr);
     }
-    cand6_sync_to_lds(w, cr);
-    if (a.ablate >= 12) return;   // timing experiment: bare loop without the final compactions
-    for (int ul = 0; ul < FE_UW; ++ul) {
-        const int64_t row = w.ubase + ul;
-        if (row >= a.B) break;
-        compact_user(a, w, ul, row);
-    }
+    __threadfence_block();
+    if (a.ablate >= 12 && a.ablate <= 15) return;   // timing experiment: bare loop without the final compactions
+    final_compactions(a, w);
 }
 
 // list capacity per user.  Measured on MI355X (K = 10..100, 262 144 users): 512-entry lists with a
@@ -1479,12 +1477,12 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     SKR_REQUIRE(mode == "fp32" || mode == "bf16x3" || mode == "bf16x3s" || mode == "bf16x3w" || mode == "bf16x3g",
                 "SKR_FUSED_MODE must be 'bf16x3', 'bf16x3g', 'bf16x3s', 'bf16x3w' or 'fp32' (got '%s')", mode_env);
     const bool mode_bf16x3 = mode != "fp32";
-    // bf16x3: the workgroup-shared tile ring (v5) for short lists, the ring per wavefront (v4) for long ones -- measured on
-    // 262 144 users x 100 k items: top-10 17.3 vs 18.1 ms, top-50 21.2 vs 21.4, top-100 25.3 vs 25.1 (a wavefront that compacts
-    // a list holds its three neighbours at the next barrier, and long lists are compacted more often); "s" / "w" force one
-    const bool shared_ring = mode == "bf16x3s" || (mode == "bf16x3" && top_k <= 32);
-    // "g": the 16x16x32 form (fused_topk_kernel_v6: steps of 16 items, the threshold tests between the next step's MFMAs)
-    const bool groups16 = mode == "bf16x3g";
+    // bf16x3 (the default) = "g": fused_topk_kernel_v6, the 16x16x32 form (steps of 16 items, the threshold tests between the
+    // next step's MFMAs).  Measured on 262 144 users x 100 k items, same box, against the two older kernels, which stay
+    // selectable -- "s": fused_topk_kernel_v5 (32x32x16, one tile ring per workgroup), "w": fused_topk_kernel_v4 (a ring per
+    // wavefront, no barriers): top-10 16.3 vs 17.6 (s) ms, top-20 17.7 vs 19.4 (s), top-50 21.0 vs 21.9 (w), top-100 25.1 vs 25.4 (w)
+    const bool shared_ring = mode == "bf16x3s";
+    const bool groups16 = mode == "bf16x3g" || mode == "bf16x3";
     if (mode_bf16x3) {
         // library-owned scratch for the split item table (38 MB at 100 k items), grown on demand
         static uint4* frag_buf = nullptr;
