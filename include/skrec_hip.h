@@ -167,7 +167,8 @@ int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
  * Arithmetic (environment SKR_FUSED_MODE, read per call): "bf16x3" (default) forms every fp32 product from six
  * bf16 x bf16 MFMA products of the exactly split operands with fp32 accumulation -- measured error vs float64
  * below the plain chain's -- and keeps a library-owned device buffer of n_items*64*6 bytes for the split item
- * table; "fp32" runs exact fp32 FMA chains on the FP32 MFMA.
+ * table; "fp32" runs exact fp32 FMA chains on the FP32 MFMA.  ("bf16x3" is fused_topk_kernel_v6, 16-item steps on
+ * v_mfma_f32_16x16x32_bf16; "bf16x3s" / "bf16x3w" select the two older 32x32x16 kernels, same arithmetic.)
  * Requires n_items - max train row length >= top_k (else SKR_EINVAL: use skr_eval_scores). */
 size_t skr_eval_fused_workspace(int B, int top_k);
 int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B,

@@ -1201,6 +1201,9 @@ __global__ __launch_bounds__(256) void split_items_kernel_v6(const float* __rest
 // list length (up to four lanes hold scores of the same user) and stores the key.  Rows of the last tile that are not
 // items carry -inf (the kernel seeds them so) and never pass.  No per-lane bit masks, no counts
 // carried between lanes, no loops: ~10 vector instructions per register that has an event, none for the others.
+// (Tried and dropped: RAW list entries -- score bits and item id stored as they are, rank_key applied on the load side of a
+// compaction where 64 lanes are active instead of here where one or two are: slower at every top_k, 1.023 vs 0.990 of the
+// older kernel's time at top-100.)
 // (Tried and dropped: counting the key stores left in flight and adding them to the counted vmcnt waits of the tile DMA,
 // which otherwise also wait for those younger stores -- no gain, the extra branches cost what the shorter waits saved.)
 __device__ __forceinline__ void group_candidates_v6(const FusedArgs& a, const WaveCtx& w, const f32x4 (&acc)[4],

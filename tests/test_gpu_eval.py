@@ -116,7 +116,11 @@ NOISE = 2e-5  # >> 64 * 2^-24 * sum|a*b| for the factor scales used here
 @pytest.mark.parametrize("B,I,K,with_bias,with_mask", [(1, 40, 5, True, True), (64, 32, 10, False, True),
                                                        (65, 1000, 20, True, True), (200, 5000, 50, True, False),
                                                        (130, 33, 3, False, True), (300, 20011, 128, True, True),
-                                                       (1000, 3000, 10, False, True)])
+                                                       (1000, 3000, 10, False, True),
+                                                       # catalogues that end inside the first 16-item group, on its edge, one item
+                                                       # into the second, and on a tile's first group (fused_topk_kernel_v6's steps)
+                                                       (2, 5, 4, True, True), (3, 16, 4, False, False), (70, 17, 9, True, True),
+                                                       (64, 48, 10, True, False), (5, 49, 7, False, True)])
 def test_fused_topk_vs_fp64(B, I, K, with_bias, with_mask, fused_mode):
     from gpu_utils import fused_topk
     rng = np.random.default_rng(B + I + K)
