@@ -696,7 +696,7 @@ def finish(args, world, rank, dev, dist, full, V, bias, out):
                                        not args.no_cpu_baseline)
     if not args.no_gru and 128 % world == 0:
         out["gru4rec"] = gru_leg(args, world, rank, dev, dist, args.gru_steps, 10, not args.no_cpu_baseline)
-    out.update(dist_info(world, dist))
+    out.update(dist_info(world, dist), compute_stream=compute_stream_note())
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -809,6 +809,10 @@ def dist_info(world, dist):
     return {"dist_backend": None, "rccl_ranks": 1, "gpus_visible": torch.cuda.device_count()}
 
 
+def compute_stream_note():
+    return "own" if torch.cuda.current_stream() != torch.cuda.default_stream() else "null"
+
+
 def launch_command(n_ranks, argv, port, script=None):
     """the driver's own N > 1 form: one fresh process per GPU under torch.distributed.run, rendezvous on 127.0.0.1"""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
@@ -890,6 +894,12 @@ def main():
     local_dev = local_rank % n_dev           # one process per GPU; the modulo only matters for rehearsals on one card
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    # the legs run on a compute stream of their own, as fit() does (skrec/recommender/base.py: on_compute_stream -- launches on
+    # the device's null stream cost the host more: the 20-step slice 35.0 -> 36.6 M interactions/s, an epoch 1.14 -> 1.07 s
+    # on the same box).  SKR_COMPUTE_STREAM=0: the null stream; SKR_BENCH_STEP_PRIORITY=1: that stream at high queue
+    # priority (measured: 17.6 M interactions/s, the step launch 45 us instead of 18.5 -- not used)
+    if os.environ.get("SKR_COMPUTE_STREAM", "1") != "0":
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("SKR_BENCH_STEP_PRIORITY") == "1" else 0))
     import torch.distributed as dist
     if world > 1:
         # "nccl" is RCCL on ROCm.  SKR_DIST_BACKEND=gloo rehearses the N > 1 code path on a single-GPU box.
@@ -909,7 +919,7 @@ def main():
         out = {"metric": "train interactions/sec + eval users/sec (HR@10/NDCG@10) at 1/2/4/8 MI355X", "higher_is_better": True,
                "vs_baseline": None, "data": "synthetic"}
         out.update(leg)
-        out.update(dist_info(world, dist))
+        out.update(dist_info(world, dist), compute_stream=compute_stream_note())
         if rank == 0:
             print(json.dumps(out))
         if world > 1:
@@ -921,7 +931,7 @@ def main():
         out = {"metric": "train interactions/sec + eval users/sec (HR@10/NDCG@10) at 1/2/4/8 MI355X", "higher_is_better": True,
                "vs_baseline": None, "data": "synthetic"}
         out.update(leg)
-        out.update(dist_info(world, dist))
+        out.update(dist_info(world, dist), compute_stream=compute_stream_note())
         if rank == 0:
             print(json.dumps(out))
         if world > 1:

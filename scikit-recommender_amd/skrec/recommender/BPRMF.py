@@ -20,7 +20,7 @@ from ..io import PairwiseIterator
 from ..run_config import RunConfig
 from ..utils.py import EarlyStopping, ModelConfig
 from ..utils.torch import get_initializer
-from .base import AbstractRecommender, DenseAdam
+from .base import AbstractRecommender, DenseAdam, on_compute_stream
 
 __all__ = ["BPRMF", "BPRMFConfig"]
 
@@ -206,6 +206,7 @@ class BPRMF(AbstractRecommender):
         opt.end_blocks()
         self.step_losses = spread.sum(1)
 
+    @on_compute_stream
     def fit(self):
         data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
                                      drop_last=False, sampler_mode=self.sampler_mode)

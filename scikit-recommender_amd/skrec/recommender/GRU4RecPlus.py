@@ -30,7 +30,7 @@ import torch.nn as nn
 from .. import _hip
 from ..run_config import RunConfig
 from ..utils.py import EarlyStopping, ModelConfig
-from .base import AbstractRecommender, DenseAdam
+from .base import AbstractRecommender, DenseAdam, on_compute_stream
 
 __all__ = ["GRU4RecPlus", "GRU4RecPlusConfig", "SessionGRU", "ShardedSessionGRU"]
 
@@ -457,6 +457,7 @@ class GRU4RecPlus(AbstractRecommender):
         net.end_blocks()
         self.step_losses = torch.cat(losses).cpu().numpy() if losses else np.zeros(0, np.float32)
 
+    @on_compute_stream
     def fit(self):
         self.logger.info("metrics:".ljust(12) + f"\t{self.evaluator.metrics_str}")
         if len(self.offset_idx) - 1 < self.config.batch_size:

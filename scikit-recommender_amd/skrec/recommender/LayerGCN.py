@@ -32,7 +32,7 @@ from .. import _hip
 from ..io import PairwiseIterator
 from ..run_config import RunConfig
 from ..utils.py import EarlyStopping, ModelConfig
-from .base import AbstractRecommender, DenseAdam
+from .base import AbstractRecommender, DenseAdam, on_compute_stream
 from .LightGCN import DEVICE_ADJ_MIN_PAIRS, DeviceCSR, pad_columns, padded_width
 
 __all__ = ["LayerGCN", "LayerGCNConfig"]
@@ -288,6 +288,7 @@ class LayerGCN(AbstractRecommender):
             else:
                 self.train_step(u.contiguous(), i.contiguous(), j.contiguous(), self.step_losses[k])
 
+    @on_compute_stream
     def fit(self):
         data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
                                      drop_last=False, sampler_mode=self.sampler_mode)

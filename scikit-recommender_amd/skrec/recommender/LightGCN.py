@@ -23,7 +23,7 @@ from ..run_config import RunConfig
 from ..utils.common import make_sure_dirs, normalize_adj_matrix
 from ..utils.py import EarlyStopping, ModelConfig
 from ..utils.torch import get_initializer
-from .base import AbstractRecommender, DenseAdam
+from .base import AbstractRecommender, DenseAdam, on_compute_stream
 
 __all__ = ["LightGCN", "LightGCNConfig", "DeviceCSR"]
 
@@ -475,6 +475,7 @@ class LightGCN(AbstractRecommender):
             else:
                 self.train_step(u.contiguous(), i.contiguous(), j.contiguous(), self.step_losses[k])
 
+    @on_compute_stream
     def fit(self):
         data_iter = PairwiseIterator(self.dataset.train_data, batch_size=self.config.batch_size, shuffle=True,
                                      drop_last=False, sampler_mode=self.sampler_mode)

@@ -85,10 +85,13 @@ def test_bprmf_config0_shape_fit_replays_the_oracle(n_dim, tmp_path, monkeypatch
         return r
 
     def train_epoch(it):
+        # fit() runs on a stream of the library's own (base.on_compute_stream), ordered against the caller's
+        assert torch.cuda.current_stream() != torch.cuda.default_stream()
         te(it)
         losses.append(m.step_losses.cpu().numpy().copy())
     m.evaluate, m.train_epoch = evaluate, train_epoch
     m.fit()
+    assert torch.cuda.current_stream() == torch.cuda.default_stream()
     got_losses = np.concatenate(losses, 0)
 
     # ---- the oracle's replay -----------------------------------------------------------------------------------

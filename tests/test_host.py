@@ -367,3 +367,17 @@ def test_padded_width_and_columns():
     t = torch.arange(6.0).view(2, 3)
     p = pad_columns(t, 64)
     assert p.shape == (2, 64) and torch.equal(p[:, :3], t) and float(p[:, 3:].abs().sum()) == 0.0 and pad_columns(p, 64) is p
+
+
+def test_on_compute_stream_is_a_passthrough_without_a_gpu(monkeypatch):
+    """fit() is wrapped by base.on_compute_stream; without a GPU (and with SKR_COMPUTE_STREAM=0) the wrapper only calls through"""
+    from skrec.recommender.base import on_compute_stream
+
+    class M:
+        @on_compute_stream
+        def fit(self, a, b=2):
+            """doc"""
+            return a + b
+    assert M().fit(1, b=5) == 6 and M.fit.__doc__ == "doc"
+    monkeypatch.setenv("SKR_COMPUTE_STREAM", "0")
+    assert M().fit(1) == 3
