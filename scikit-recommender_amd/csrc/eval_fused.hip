@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
             else if (wv < 2 || (HAS_BIAS && !(hs_ & 1) && wv == 3)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); \
             else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                             \
         }                                                                                                     \
-        if (a.ablate != 11) __syncthreads();   /* 11: timing experiment, bare loop without the barrier */     \
+        if (a.ablate != 11 && a.ablate != 19) __syncthreads();   /* 11, 19: timing experiments without the barrier (bare loop; whole kernel, results then unreliable) */ \
         FE3_PIN();                                                                                            \
         if (more3_) issue_half(a.ablate == 8 ? ((hs_ + F5_RING) & 31) : hs_ + F5_RING, slot, brow2);          \
         /* the bias read goes first: LDS answers in order, so the first MFMA waits for it alone (counted) */  \
