@@ -111,6 +111,7 @@ class BPRMF(AbstractRecommender):
             1.0, _hip.stream()))
         self.optimizer.step()
 
+    @on_compute_stream
     def train_epoch(self, data_iter):
         """one epoch; the per-step host work is two ctypes calls on cached addresses"""
         self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
@@ -229,6 +230,7 @@ class BPRMF(AbstractRecommender):
         log("best:".ljust(12) + f"\t{early_stopping.best_result.values_str}")
         return early_stopping.best_result
 
+    @on_compute_stream
     def evaluate(self, test_users=None):
         if self.engine is None:
             return self.evaluator.evaluate(self, test_users)

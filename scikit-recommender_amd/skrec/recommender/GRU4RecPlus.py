@@ -416,6 +416,7 @@ class GRU4RecPlus(AbstractRecommender):
             if len(mask):
                 reset = mask if reset is None else np.union1d(reset, mask)
 
+    @on_compute_stream
     def train_epoch(self):
         """The session-parallel loop of GRU4RecPlus.fit (:210-247).  The schedule is host logic (``_schedule``), so the steps
         are prepared SKR_ADAM_BLOCK (default 32) at a time: one upload of the positions, one gather of the inputs / targets,
@@ -493,6 +494,7 @@ class GRU4RecPlus(AbstractRecommender):
         full[mine] = self.net.user_embeddings(rp, hist, max_len)
         return full
 
+    @on_compute_stream
     def evaluate(self, test_users=None):
         if self.dist.active:
             # every rank sweeps and ranks its own share of the users; only the fp64 metric sums are all-reduced

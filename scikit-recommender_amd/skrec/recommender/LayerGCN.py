@@ -279,6 +279,7 @@ class LayerGCN(AbstractRecommender):
         _hip.check(L.skr_mark_ids(_hip.ptr(neg), neg.numel(), nu, _hip.ptr(m), st))
         return m
 
+    @on_compute_stream
     def train_epoch(self, data_iter):
         self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
         for k, (u, i, j) in enumerate(data_iter.iter_device()):
@@ -315,6 +316,7 @@ class LayerGCN(AbstractRecommender):
         else:
             self.forward()
 
+    @on_compute_stream
     def evaluate(self, test_users=None):
         self._refresh_outputs()
         if self.engine is None:

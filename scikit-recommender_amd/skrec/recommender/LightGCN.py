@@ -466,6 +466,7 @@ class LightGCN(AbstractRecommender):
             x = y
         self.optimizer.step()
 
+    @on_compute_stream
     def train_epoch(self, data_iter):
         self.step_losses = torch.zeros((len(data_iter), 2), dtype=torch.float32, device=self.device)
         for k, (u, i, j) in enumerate(data_iter.iter_device()):
@@ -504,6 +505,7 @@ class LightGCN(AbstractRecommender):
             self.propagate()
         self._final_is_current = True
 
+    @on_compute_stream
     def evaluate(self, test_users=None):
         self.eval()
         if self.engine is None:
