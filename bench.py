@@ -844,11 +844,34 @@ def launch_ranks(n_ranks, argv, script=None, env=None):
         env.setdefault("SKR_ADAM_OVERLAP", "0")
         env.setdefault("SKR_SAMPLER_ONE_STREAM", "1")
     cmd = launch_command(n_ranks, argv, port, script)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout:            # relayed as it comes; stderr goes straight through
-        sys.stdout.write(line)
-        sys.stdout.flush()
-    return proc.wait()
+    # the ranks get a process group of their own, and a deadline: a rank that never returns from a collective (a peer that
+    # died, a rendezvous that cannot complete) must not hold the caller for ever.  Only THIS group is ever signalled.
+    deadline = float(env.get("SKR_BENCH_RANKS_TIMEOUT", "1500"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    import signal
+    import threading
+    timed_out = []
+
+    def expire():
+        timed_out.append(True)
+        print(f"[bench] the {n_ranks} ranks did not finish within {deadline:.0f} s: ending their process group", file=sys.stderr)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                return
+            time.sleep(5 if sig == signal.SIGTERM else 0)
+    timer = threading.Timer(deadline, expire)
+    timer.daemon = True
+    timer.start()
+    try:
+        for line in proc.stdout:            # relayed as it comes; stderr goes straight through
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        rc = proc.wait()
+    finally:
+        timer.cancel()
+    return 124 if timed_out else rc
 
 
 def main():

@@ -137,3 +137,17 @@ def test_launcher_starts_fresh_ranks_and_relays_rank0(tmp_path, capfd):
     assert line["backend_env"] == "gloo"          # no GPU visible here: fewer devices than ranks => rehearsal backend
     env["STUB_EXIT"] = "3"
     assert bench.launch_ranks(2, [], script=str(stub), env=env) != 0      # a failing rank fails the launcher
+
+
+def test_launcher_ends_ranks_that_never_finish(tmp_path, capfd):
+    """a rank stuck in a collective must not hold the caller: past SKR_BENCH_RANKS_TIMEOUT the launcher ends the ranks' own
+    process group and reports 124"""
+    import time
+    stub = tmp_path / "hang.py"
+    stub.write_text("import time\ntime.sleep(600)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SKR_DIST_BACKEND")}
+    env["SKR_BENCH_RANKS_TIMEOUT"] = "8"
+    t0 = time.time()
+    assert bench.launch_ranks(2, [], script=str(stub), env=env) == 124
+    assert time.time() - t0 < 60
+    assert "did not finish" in capfd.readouterr().err
