@@ -1,7 +1,8 @@
-# usage: bash tools/cold_bpc_sweep.sh -- training leg by blocks per CU of the cold pass (its share of the chip) and block length k
-for k in 24; do for bpc in 2 3 4 8; do
-  SKR_ADAM_BLOCK=$k SKR_COLD_BPC=$bpc python bench.py --no-cpu-baseline --no-eval --no-epoch --steps 960 --warmup 48 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('k=$k bpc=$bpc value=%.0f ms/step=%.4f cold ms=%.3f'%(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms']))"
-done; done
+#!/bin/bash
+# workgroups per CU of the persistent cold pass (SKR_COLD_BPC), same box: the driver's slice + whole epochs
+for v in ${@:-4 3 5 6 4}; do
+  SKR_COLD_BPC=$v timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-lightgcn --no-gru --no-eval --large-batches "" 2> gpurun_out/cold_bpc.err | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('bpc $v value', round(d['value']/1e6, 2), 'epochs', [round(x, 4) for x in d.get('full_epoch', {}).get('epochs_seconds', [])], 'step_us', round(d['roofline_step']['avg_launch_us'], 2), 'cold_ms', round(d['roofline']['avg_launch_ms'], 4))" || exit 1
+done
