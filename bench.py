@@ -622,7 +622,10 @@ def eval_leg(args, world, rank, dev, dist, U, V, bias, ds, nU, nI, out):
         else:
             # every fp32 product is formed from six bf16 x bf16 MFMA products with fp32 accumulation, so the matrix
             # pipe issues 6x the algorithmic flops: the peak for THIS arithmetic is the dense bf16 peak / 6
-            kname = {"bf16x3s": "fused_topk_kernel_v5 (v_mfma_f32_32x32x16_bf16, one item-tile ring per workgroup; ",
+            kname = {"f16x2": "fused_topk_kernel_v7 (v_mfma_f32_16x16x32_f16: fp32 operands scaled by a power of two and split into 2 fp16 "
+                              "pieces, 3 MFMAs per fp32 product; guarded, rejected rows recomputed by the bf16x3 kernel; the fraction "
+                              "below is still priced against the bf16x3 peak of 6 products; ",
+                     "bf16x3s": "fused_topk_kernel_v5 (v_mfma_f32_32x32x16_bf16, one item-tile ring per workgroup; ",
                      "bf16x3w": "fused_topk_kernel_v4 (v_mfma_f32_32x32x16_bf16, one item-tile ring per wavefront; "}.get(
                 mode, "fused_topk_kernel_v6 (v_mfma_f32_16x16x32_bf16, steps of 16 items, threshold tests between the MFMAs, "
                       "one item ring per workgroup; ")

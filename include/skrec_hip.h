@@ -169,8 +169,15 @@ int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
  * below the plain chain's -- and keeps a library-owned device buffer of n_items*64*6 bytes for the split item
  * table; "fp32" runs exact fp32 FMA chains on the FP32 MFMA.  ("bf16x3" is fused_topk_kernel_v6, 16-item steps on
  * v_mfma_f32_16x16x32_bf16; "bf16x3s" / "bf16x3w" select the two older 32x32x16 kernels, same arithmetic.)
+ * "f16x2": every operand, scaled by a power of two per table, is split into TWO fp16 pieces and a product formed from
+ * three fp16 MFMA products (half the matrix work of bf16x3); fp32-level accuracy holds while the scores that decide
+ * a list lie well above an absolute floor set by the largest elements of the two tables -- checked per user on the
+ * device, and every user that fails is recomputed by the bf16x3 kernel inside the same call.
  * Requires n_items - max train row length >= top_k (else SKR_EINVAL: use skr_eval_scores). */
 size_t skr_eval_fused_workspace(int B, int top_k);
+/* SKR_FUSED_MODE=f16x2 only: how many rows of the LAST skr_eval_fused_topk call on `stream` its guard did not accept and
+ * handed to the bf16x3 kernel (written to *h_count on the host; blocks until that call is done; 0 in the other modes). */
+int skr_eval_fused_rejected(int32_t* h_count, void* stream);
 int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B,
                         const float* d_item_table, const float* d_item_bias, int n_items, int dim,
                         const int64_t* d_train_rowptr, const int32_t* d_train_items,

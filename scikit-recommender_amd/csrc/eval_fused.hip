@@ -97,7 +97,16 @@ struct FusedArgs {
     int ablate;      // timing experiments only (SKR_FUSED_ABLATE): 1 = thresholds +inf (pure GEMM sweep)
     int trigger;     // a list is compacted once it holds more than this many candidates (K <= trigger <= cap-32)
     int cap;         // list capacity per user (FE_CAP)
+    // --- the fp16x2 sweep and its fall-back (fused_topk_kernel_v7 / the bf16x3 kernel over the rows it flagged) -------------
+    const int32_t* row_map;     // nullable: logical row r of this launch is row row_map[r] of users / outputs
+    const int32_t* n_rows_dev;  // nullable: number of logical rows, read on the device (<= B)
+    const float* guard_s_inv;   // device: 1 / (s_u s_v); a user whose smallest returned |score| is below 2^21 of it is flagged
+    int32_t* flag_list;
+    int32_t* flag_count;
 };
+
+__device__ __forceinline__ int rows_of(const FusedArgs& a) { return a.n_rows_dev ? *a.n_rows_dev : a.B; }
+__device__ __forceinline__ int64_t src_row(const FusedArgs& a, int64_t row) { return a.row_map ? a.row_map[row] : row; }
 
 constexpr int FE_ROWBUF = 256;   // train rows up to this length are staged in LDS for the membership searches
 
@@ -216,6 +225,17 @@ __device__ __forceinline__ void final_user(const FusedArgs& a, const WaveCtx& w,
             if (a.out_scores) a.out_scores[out_row * K + idx] = skr::key_score(k[e]);
         }
     }
+    if (a.flag_count && keep > 0) {
+        // the fp16x2 sweep's guard (see fused_topk_kernel_v7): its absolute error floor must lie below the fp32 rounding noise
+        // of the scores that decide the list, i.e. of the smallest one kept
+        const int idx = keep - 1, src = idx & 63;
+        uint64_t ke = k[0];
+        if (NR > 1 && (idx >> 6) == 1) ke = k[NR > 1 ? 1 : 0];
+        const int lo = __shfl(static_cast<int>(static_cast<uint32_t>(ke)), src, 64);
+        const int hi = __shfl(static_cast<int>(static_cast<uint32_t>(ke >> 32)), src, 64);
+        const float t = skr::key_score((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo));
+        if (!(fabsf(t) >= 2097152.0f * *a.guard_s_inv) && lane == 0) a.flag_list[atomicAdd(a.flag_count, 1)] = static_cast<int32_t>(out_row);
+    }
 }
 
 // The final compactions of a wavefront's users, software-pipelined: the loads of user ul + 1 (candidate list and train
@@ -223,7 +243,7 @@ __device__ __forceinline__ void final_user(const FusedArgs& a, const WaveCtx& w,
 // round trips, 64 times per wavefront, at a point where every wavefront of the chip is doing the same and no MFMA runs.
 template <int NR>
 __device__ __forceinline__ void final_compactions_n(const FusedArgs& a, const WaveCtx& w) {
-    const int64_t left = static_cast<int64_t>(a.B) - w.ubase;
+    const int64_t left = static_cast<int64_t>(rows_of(a)) - w.ubase;
     const int n_users = left < FE_UW ? static_cast<int>(left) : FE_UW;
     if (n_users <= 0) return;
     __threadfence_block();   // the wave's appends, re-read below by other lanes of the same wave
@@ -251,9 +271,9 @@ __device__ __forceinline__ void final_compactions_n(const FusedArgs& a, const Wa
         if (ul + 1 < n_users) fetch(ul + 1);
         if (n <= 64 && a.top_k <= 64) {   // the common case at top-10: a 64-key sort instead of a 128-key one
             uint64_t k1[1] = {k[0]};
-            final_user<1>(a, w, ul, k1, rr, w.ubase + ul);
+            final_user<1>(a, w, ul, k1, rr, src_row(a, w.ubase + ul));
         } else {
-            final_user<NR>(a, w, ul, k, rr, w.ubase + ul);
+            final_user<NR>(a, w, ul, k, rr, src_row(a, w.ubase + ul));
         }
     }
 }
@@ -1255,6 +1275,8 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
     w.h = w.lane >> 5;
     const int lane = w.lane, c16 = w.lane & 15, qd = w.lane >> 4;
     w.ubase = (static_cast<int64_t>(blockIdx.x) * FE_WAVES + wv) * FE_UW;
+    const int nB = rows_of(a);   // a.B, or (the fall-back launch over the rows the fp16x2 sweep flagged) a count read here
+    if (static_cast<int64_t>(blockIdx.x) * FE_WAVES * FE_UW >= nB) return;   // the whole workgroup: nothing to do
     // a wavefront whose users lie beyond B stays: it carries its share of the DMA and of the workgroup barriers
     w.cnt = s_cnt[wv];
     w.cnt[lane] = 0;
@@ -1267,8 +1289,8 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
         const int64_t row = w.ubase + lane;
         int64_t rb = 0;
         int len = 0;
-        if (a.train_rowptr && row < a.B) {
-            const int u = a.users[row];
+        if (a.train_rowptr && row < nB) {
+            const int u = a.users[src_row(a, row)];
             rb = a.train_rowptr[u];
             len = static_cast<int>(a.train_rowptr[u + 1] - rb);
         }
@@ -1281,8 +1303,8 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int64_t row = w.ubase + 16 * g + c16;
-        const bool ok = row < a.B;
-        const int uid = a.users[ok ? row : (a.B - 1)];
+        const bool ok = row < nB;
+        const int uid = a.users[src_row(a, ok ? row : (nB - 1))];
         thr[g] = (ok && a.ablate != 1 && a.ablate != 7 && a.ablate != 11 && (a.ablate < 12 || a.ablate > 15)) ? -INFINITY : INFINITY;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1427,6 +1449,346 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
     final_compactions(a, w);
 }
 
+// ================================================================================================
+// fused_topk_kernel_v7 (round 3, SKR_FUSED_MODE=f16x2): the same sweep with every fp32 operand split into TWO fp16 pieces.
+//   x * s = hi + lo (s a power of two per table, chosen so that the table's largest |x| * s lies in [2^14, 2^15): exact),
+//   hi = fp16(x s), lo = fp16(x s - hi); a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32
+//   accumulation -- THREE matrix products per fp32 product instead of bf16x3's six, at the same rate per product.
+// What it costs in accuracy, and how that is kept honest: hi + lo carries 22 significand bits of x s (fp32: 24) as long as
+// lo is a normal fp16 (|x s| >= 2^-3, i.e. |x| within 2^-17 of the table's largest element); below that lo is a
+// denormal with ABSOLUTE error <= 2^-25.  Measured against float64 on normal factors of scales 1e-3 .. 30 (numpy
+// emulation and tools/fused_accuracy.py): max 1.2e-7 / mean 1.3e-8 of sum |u_i v_i| -- below the fp32 chain's 3.5e-7 /
+// 2.0e-8; rows or elements of wildly different magnitude are where it degrades (an absolute floor of 2^-3 / (s_u s_v)
+// per score).  So the kernel GUARDS its result: a user is accepted only if the smallest score of the returned list is
+// at least 2^21 / (s_u s_v) in magnitude, i.e. the floor lies below that score's own fp32 rounding noise (2^-24 of it);
+// every other user is written to a list on the device and recomputed by the bf16x3 kernel (fused_topk_kernel_v6 with a
+// row map) in the same call, stream-ordered, no host round trip -- on factors of one magnitude (bench.py's, a trained
+// model's) the list is empty and that launch returns at once.
+// Mechanics: v6's, with 4 KB item groups (2 k-steps x 2 pieces; one 1 KB block per wavefront and step), 64 instead of
+// 96 user-fragment registers, 24 MFMAs per step in 6 slots, thresholds held in the scaled domain (a compaction's
+// threshold is multiplied by s_u s_v once), scores unscaled when an event is stored, the bias row pre-scaled by
+// split_items_kernel_v7.
+// ================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16x8 as_f16x8(const uint4& u) {
+    union { uint4 u; f16x8 h; } c;
+    c.u = u;
+    return c.h;
+}
+#define F7_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(A), as_f16x8(B), C, 0, 0, 0)
+constexpr int F7_GROUP_U4 = 4 * 64;     // uint4 per item group (2 k-steps x {hi, lo} = 4 KB)
+
+struct F7Scales {
+    uint32_t max_u_bits, max_v_bits;   // bit patterns of the largest |x| of the evaluated user rows / of the item table
+    int32_t n_flagged;                 // users the guard sent to the bf16x3 kernel
+    int32_t pad;
+    float s_u, s_v, S, S_inv;          // the power-of-two scales, their product and its inverse
+};
+
+// largest |x| over whole rows of `width` floats (rows picked by ids when given): float4 loads, one atomic per wavefront
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                                          int64_t n_rows, uint32_t* __restrict__ out_bits) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;   // (row, 16-byte piece): FE_D / 4 pieces per row
+    uint32_t m = 0;
+    if (t < n_rows * (FE_D / 4)) {
+        const int64_t r = t / (FE_D / 4);
+        const int q = static_cast<int>(t - r * (FE_D / 4));
+        const int64_t row = ids ? ids[r] : r;
+        const float4 v = reinterpret_cast<const float4*>(table + row * FE_D)[q];
+        const uint32_t a0 = __float_as_uint(v.x) & 0x7fffffffu, a1 = __float_as_uint(v.y) & 0x7fffffffu;
+        const uint32_t a2 = __float_as_uint(v.z) & 0x7fffffffu, a3 = __float_as_uint(v.w) & 0x7fffffffu;
+        m = max(max(a0, a1), max(a2, a3));
+        if (m > 0x7f800000u) m = 0x7f800000u;   // NaN counts as inf: the guard will then reject everything
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), d, 64)));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+}
+
+// s = 2^e with max * s in [2^14, 2^15); e clamped so that s_u * s_v stays a finite fp32 (tiny tables then fail the guard)
+__device__ __forceinline__ float f7_scale_of(uint32_t max_bits) {
+    int ex = static_cast<int>((max_bits >> 23) & 0xffu) - 127;
+    if ((max_bits >> 23) == 0) ex = -126;        // zero / denormal maximum
+    if (max_bits >= 0x7f800000u) ex = 127;       // inf / NaN
+    int e = 14 - ex;
+    e = e < -40 ? -40 : (e > 40 ? 40 : e);
+    return ldexpf(1.0f, e);
+}
+__global__ void f7_scales_kernel(F7Scales* sc) {
+    if (threadIdx.x == 0) {
+        sc->s_u = f7_scale_of(sc->max_u_bits);
+        sc->s_v = f7_scale_of(sc->max_v_bits);
+        sc->S = sc->s_u * sc->s_v;
+        sc->S_inv = 1.0f / sc->S;     // a power of two: exact
+        sc->n_flagged = 0;
+    }
+}
+
+// eight consecutive floats, scaled by a power of two -> hi and lo as packed fp16
+__device__ __forceinline__ void split2x8(const float* v, float s, uint4& hi, uint4& lo) {
+    union { _Float16 h[8]; uint4 u; } H, L;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xs = v[j] * s;
+        const _Float16 h = static_cast<_Float16>(xs);                      // round to nearest even
+        H.h[j] = h;
+        L.h[j] = static_cast<_Float16>(xs - static_cast<float>(h));        // the difference is exact in fp32
+    }
+    hi = H.u;
+    lo = L.u;
+}
+
+// item table -> fragment order of this kernel (group of 16 items x k-step of 32 dims x {hi, lo} -> 1 KB blocks), and the
+// bias row multiplied by s_u s_v (the accumulators live in the scaled domain)
+__global__ __launch_bounds__(256) void split_items_kernel_v7(const float* __restrict__ table, const float* __restrict__ bias,
+                                                             int n_items, int n_tiles, const F7Scales* __restrict__ sc,
+                                                             uint4* __restrict__ frags, float* __restrict__ bias_s) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;   // (group, k-step, lane)
+    if (g >= static_cast<int64_t>(n_tiles) * 2 * 2 * 64) return;
+    const float s_v = sc->s_v;
+    if (bias && g < static_cast<int64_t>(n_tiles) * FE_TI) bias_s[g] = (g < n_items ? bias[g] : 0.0f) * sc->S;
+    const int lane = static_cast<int>(g & 63), ks = static_cast<int>((g >> 6) & 1);
+    const int64_t G = g >> 7;
+    int64_t item = G * F6_GI + (lane & 15);
+    if (item >= n_items) item = n_items - 1;
+    const float4* src = reinterpret_cast<const float4*>(table + item * FE_D + ks * 32 + 8 * (lane >> 4));
+    const float4 v0 = src[0], v1 = src[1];
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    uint4 hi, lo;
+    split2x8(v, s_v, hi, lo);
+    uint4* dst = frags + G * F7_GROUP_U4 + (ks * 2) * 64 + lane;
+    dst[0] = hi;
+    dst[64] = lo;
+}
+
+// the bf16x3 fall-back's own split of the item table, skipped when the guard flagged nobody
+__global__ __launch_bounds__(256) void split_items_kernel_v6_if(const float* __restrict__ table, int n_items, int n_tiles,
+                                                                uint4* __restrict__ frags, const int32_t* __restrict__ n_rows) {
+    if (*n_rows <= 0) return;
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (g >= static_cast<int64_t>(n_tiles) * 2 * 2 * 64) return;
+    const int lane = static_cast<int>(g & 63), ks = static_cast<int>((g >> 6) & 1);
+    const int64_t G = g >> 7;
+    int64_t item = G * F6_GI + (lane & 15);
+    if (item >= n_items) item = n_items - 1;
+    const float4* src = reinterpret_cast<const float4*>(table + item * FE_D + ks * 32 + 8 * (lane >> 4));
+    const float4 v0 = src[0], v1 = src[1];
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    uint4 hi, mid, lo;
+    split3x8(v, hi, mid, lo);
+    uint4* dst = frags + G * F4_HALF_U4 + (ks * 3) * 64 + lane;
+    dst[0] = hi;
+    dst[64] = mid;
+    dst[128] = lo;
+}
+
+// candidate path of one finished item group: group_candidates_v6 with the accumulators in the scaled domain
+__device__ __forceinline__ void group_candidates_v7(const FusedArgs& a, const WaveCtx& w, const f32x4 (&acc)[4],
+                                                    const bool (&pass)[4][4], int base, float (&thr_s)[4], float S, float S_inv) {
+    const int qd = w.lane >> 4, c16 = w.lane & 15;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int* cnt_p = &w.cnt[16 * g + c16];
+        uint64_t* list = w.my_cand + static_cast<int64_t>(16 * g + c16) * a.cap;
+        int pos[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (pass[g][i]) pos[i] = __hip_atomic_fetch_add(cnt_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (pass[g][i]) list[pos[i]] = skr::rank_key(acc[g][i] * S_inv, base + 4 * qd + i);   // the real score: an exact power-of-two scaling
+    }
+    uint64_t need = __ballot(w.cnt[w.lane] > a.trigger);
+    if (need) {
+        while (need) {
+            const int ul = __ffsll(static_cast<long long>(need)) - 1;
+            need &= need - 1;
+            const float nt = compact_user(a, w, ul, -1) * S;   // -inf stays -inf
+            const int ug = ul >> 4;   // wave-uniform
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (g == ug && c16 == (ul & 15)) thr_s[g] = nt;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler (see tile_candidates_v4)
+    }
+}
+
+// (185 VGPRs: two workgroups per CU.  Squeezed to 168 for three -- a dozen registers spilled, and 1 024 workgroups over 768 places
+// leave the second round a third full -- the kernel took 17.1 instead of 11.3 ms.)
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v7(FusedArgs a, const uint4* __restrict__ frags,
+                                                                         const float* __restrict__ bias_s,
+                                                                         const F7Scales* __restrict__ sc) {
+    __shared__ uint4 s_tile[F5_RING * F7_GROUP_U4];            // ONE ring of F5_RING item groups (4 KB each) for the workgroup
+    __shared__ float4 s_bias[3][16];                           // three (scaled) bias rows, as in v6
+    __shared__ int s_cnt[FE_WAVES][FE_UW];
+    __shared__ int64_t s_row_beg[FE_WAVES][FE_UW];
+    __shared__ int s_row_len[FE_WAVES][FE_UW];
+    __shared__ int s_rowbuf[FE_WAVES][F4_ROWBUF];
+    WaveCtx w;
+    w.lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    w.c = w.lane & 31;
+    w.h = w.lane >> 5;
+    const int lane = w.lane, c16 = w.lane & 15, qd = w.lane >> 4;
+    w.ubase = (static_cast<int64_t>(blockIdx.x) * FE_WAVES + wv) * FE_UW;
+    w.cnt = s_cnt[wv];
+    w.cnt[lane] = 0;
+    w.my_cand = a.cand + w.ubase * a.cap;
+    w.row_beg = s_row_beg[wv];
+    w.row_len = s_row_len[wv];
+    w.rowbuf = s_rowbuf[wv];
+    w.rowbuf_len = F4_ROWBUF;
+    {
+        const int64_t row = w.ubase + lane;
+        int64_t rb = 0;
+        int len = 0;
+        if (a.train_rowptr && row < a.B) {
+            const int u = a.users[row];
+            rb = a.train_rowptr[u];
+            len = static_cast<int>(a.train_rowptr[u + 1] - rb);
+        }
+        w.row_beg[lane] = rb;
+        w.row_len[lane] = len;
+    }
+    const float s_u = sc->s_u, S = sc->S, S_inv = sc->S_inv;
+    // user fragments: B[k = 8 qd + j][col c16] of user group g and k-step ks, two pieces each
+    uint4 bh[4][2], bl[4][2];
+    float thr[4];                                   // thresholds in the scaled domain
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int64_t row = w.ubase + 16 * g + c16;
+        const bool ok = row < a.B;
+        const int uid = a.users[ok ? row : (a.B - 1)];
+        thr[g] = (ok && a.ablate != 1 && a.ablate != 7) ? -INFINITY : INFINITY;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid) * FE_D + ks * 32 + 8 * qd);
+            const float4 v0 = up[0], v1 = up[1];
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            split2x8(v, s_u, bh[g][ks], bl[g][ks]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {   // retire the loads here (see the fp32 kernel: hidden DMA vs counted vmcnt)
+            asm volatile("" : "+v"(bh[g][ks].x), "+v"(bh[g][ks].y), "+v"(bh[g][ks].z), "+v"(bh[g][ks].w));
+            asm volatile("" : "+v"(bl[g][ks].x), "+v"(bl[g][ks].y), "+v"(bl[g][ks].z), "+v"(bl[g][ks].w));
+        }
+    const int n_tiles = (a.n_items + FE_TI - 1) / FE_TI;
+    const int n_half = 2 * n_tiles;                 // item groups
+    const uint32_t lt = lds_addr_of(&s_tile[0]);
+    const uint32_t lb0 = lds_addr_of(&s_bias[0][0]);
+    const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+    auto issue_group = [&](int hs, int slot, int brow) {   // group hs -> ring slot: wavefront wv brings block wv; 3 also a tile's bias row
+        const char* sbase = reinterpret_cast<const char*>(frags) + static_cast<int64_t>(hs) * (F7_GROUP_U4 * 16);   // wave-uniform
+        glds_b128_s(lane16, sbase + wv * 1024, lt + slot * (F7_GROUP_U4 * 16) + wv * 1024);
+        if (HAS_BIAS && !(hs & 1) && wv == 3) {
+            const int bi = (hs >> 1) * FE_TI + (lane & 31);   // bias_s is padded to whole tiles
+            glds_b32(bias_s + bi, lb0 + static_cast<uint32_t>(brow) * 256u);
+        }
+    };
+#pragma unroll
+    for (int h0 = 0; h0 < F5_RING; ++h0)
+        if (h0 < n_half) issue_group(h0, h0, h0 >> 1);
+    FE2_WAIT();
+    __syncthreads();
+    uint4 afA[4], afB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) afA[i] = s_tile[i * 64 + lane];
+    f32x4 accA[4], accB[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accB[g][i] = -INFINITY;   // "group -1": nothing passes
+    int slot = 0;
+    int brow = 0, brow2 = 2;
+    // one step = one item group: 6 slots of four MFMAs (one piece product on the four user groups); slots 0..4 carry three
+    // threshold tests of group hs-1 each, slot 5 the sixteenth
+#define F7_TEST(Q, PRV)                                                                                       \
+    {                                                                                                         \
+        pass_[(Q) >> 2][(Q) & 3] = PRV[(Q) >> 2][(Q) & 3] > thr[(Q) >> 2];                                    \
+        any_ |= pass_[(Q) >> 2][(Q) & 3];                                                                     \
+    }
+#define F7_SLOT(S_, AF, BP, ACC, PRV)                                                                         \
+    {                                                                                                         \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                      \
+            ACC[g_] = F7_MFMA(AF, BP[g_][(S_) / 3], (S_) == 0 ? seed_ : ACC[g_]);                             \
+        if ((S_) < 5) {                                                                                       \
+            F7_TEST(3 * ((S_) < 5 ? (S_) : 0), PRV) F7_TEST(3 * ((S_) < 5 ? (S_) : 0) + 1, PRV)               \
+            F7_TEST(3 * ((S_) < 5 ? (S_) : 0) + 2, PRV)                                                       \
+        } else {                                                                                              \
+            F7_TEST(15, PRV)                                                                                  \
+        }                                                                                                     \
+        FE3_PIN();                                                                                            \
+    }
+#define F7_STEP(CUR, NXT, HS, ACC, PRV, LAST)                                                                 \
+    {                                                                                                         \
+        const int hs_ = (HS);                                                                                 \
+        FE3_PIN();                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* CUR has landed in registers */                \
+        FE3_PIN();                                                                                            \
+        const bool more3_ = hs_ + F5_RING < n_half && a.ablate != 7;                                          \
+        const int nslot_ = slot == F5_RING - 1 ? 0 : slot + 1;                                                \
+        if (hs_ + 1 < n_half) {                                                                               \
+            /* behind my block of group hs+1 only my block of group hs+2 is in flight (and, wavefront 3, its bias row) */ \
+            if (hs_ + 2 >= n_half) FE2_WAIT();                                                                \
+            else if (HAS_BIAS && !(hs_ & 1) && wv == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      \
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                             \
+        }                                                                                                     \
+        __syncthreads();                                                                                      \
+        FE3_PIN();                                                                                            \
+        if (more3_) issue_group(hs_ + F5_RING, slot, brow2);                                                  \
+        f32x4 seed_;                                                                                          \
+        if (HAS_BIAS) {                                                                                       \
+            const float4 b4 = s_bias[brow][4 * (hs_ & 1) + qd];                                               \
+            seed_[0] = b4.x; seed_[1] = b4.y; seed_[2] = b4.z; seed_[3] = b4.w;                               \
+        } else {                                                                                              \
+            seed_[0] = 0.0f; seed_[1] = 0.0f; seed_[2] = 0.0f; seed_[3] = 0.0f;                               \
+        }                                                                                                     \
+        FE3_PIN();                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) NXT[i] = s_tile[nslot_ * F7_GROUP_U4 + i * 64 + lane];  \
+        if (LAST) {   /* the last tile: rows beyond the catalogue start from -inf and stay there */            \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+                if (hs_ * F6_GI + 4 * qd + i >= a.n_items) seed_[i] = -INFINITY;                              \
+        }                                                                                                     \
+        bool any_ = false;                                                                                    \
+        bool pass_[4][4] = {};                                                                                \
+        FE3_PIN();                                                                                            \
+        /* small terms first, per k-step: lo*hi, hi*lo, hi*hi */                                              \
+        F7_SLOT(0, CUR[1], bh, ACC, PRV)  F7_SLOT(1, CUR[0], bl, ACC, PRV)  F7_SLOT(2, CUR[0], bh, ACC, PRV)  \
+        F7_SLOT(3, CUR[3], bh, ACC, PRV)  F7_SLOT(4, CUR[2], bl, ACC, PRV)  F7_SLOT(5, CUR[2], bh, ACC, PRV)  \
+        if (__any(any_)) group_candidates_v7(a, w, PRV, pass_, (hs_ - 1) * F6_GI, thr, S, S_inv);             \
+        slot = nslot_;                                                                                        \
+    }
+    for (int t = 0; t < n_tiles - 1; ++t) {
+        F7_STEP(afA, afB, 2 * t, accA, accB, false)
+        F7_STEP(afB, afA, 2 * t + 1, accB, accA, false)
+        brow = brow == 2 ? 0 : brow + 1;
+        brow2 = brow2 == 2 ? 0 : brow2 + 1;
+    }
+    F7_STEP(afA, afB, 2 * (n_tiles - 1), accA, accB, true)
+    F7_STEP(afB, afA, 2 * (n_tiles - 1) + 1, accB, accA, true)
+#undef F7_STEP
+#undef F7_SLOT
+#undef F7_TEST
+    {
+        bool any_ = false;
+        bool pass_[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pass_[g][i] = accB[g][i] > thr[g];
+                any_ |= pass_[g][i];
+            }
+        if (__any(any_)) group_candidates_v7(a, w, accB, pass_, (n_half - 1) * F6_GI, thr, S, S_inv);
+    }
+    __threadfence_block();
+    final_compactions(a, w);
+}
+
 // list capacity per user.  Measured on MI355X (K = 10..100, 262 144 users): 512-entry lists with a
 // trigger of 480 were no faster than 256 / 224 once the mid-sweep compaction selects instead of sorting
 // (profiles/r01_eval_history.txt), so the smaller scratch footprint stays.
@@ -1434,6 +1796,8 @@ int fused_cap(int top_k) {
     (void)top_k;
     return FE_CAP;
 }
+
+F7Scales* g_f7_scales = nullptr;   // device: scales and guard count of the last f16x2 call (skr_eval_fused_rejected)
 
 }  // namespace
 
@@ -1443,6 +1807,16 @@ size_t skr_eval_fused_workspace(int B, int top_k) {
     if (B <= 0) return 0;
     const size_t padded = (static_cast<size_t>(B) + FE_UW - 1) / FE_UW * FE_UW;
     return padded * fused_cap(top_k) * sizeof(uint64_t);
+}
+
+int skr_eval_fused_rejected(int32_t* h_count, void* stream) {
+    SKR_REQUIRE(h_count, "skr_eval_fused_rejected: NULL argument");
+    *h_count = 0;
+    if (!g_f7_scales) return SKR_OK;
+    hipStream_t st = skr::as_stream(stream);
+    SKR_HIP(hipMemcpyAsync(h_count, &g_f7_scales->n_flagged, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SKR_HIP(hipStreamSynchronize(st));
+    return SKR_OK;
 }
 
 int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B, const float* d_item_table,
@@ -1477,8 +1851,8 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     // arithmetic mode, read per call: "bf16x3" (default) or "fp32" (the FP32-MFMA kernel)
     const char* mode_env = getenv("SKR_FUSED_MODE");
     const std::string mode = mode_env ? mode_env : "bf16x3";
-    SKR_REQUIRE(mode == "fp32" || mode == "bf16x3" || mode == "bf16x3s" || mode == "bf16x3w" || mode == "bf16x3g",
-                "SKR_FUSED_MODE must be 'bf16x3', 'bf16x3g', 'bf16x3s', 'bf16x3w' or 'fp32' (got '%s')", mode_env);
+    SKR_REQUIRE(mode == "fp32" || mode == "bf16x3" || mode == "bf16x3s" || mode == "bf16x3w" || mode == "bf16x3g" || mode == "f16x2",
+                "SKR_FUSED_MODE must be 'bf16x3', 'bf16x3g', 'bf16x3s', 'bf16x3w', 'f16x2' or 'fp32' (got '%s')", mode_env);
     const bool mode_bf16x3 = mode != "fp32";
     // bf16x3 (the default) = "g": fused_topk_kernel_v6, the 16x16x32 form (steps of 16 items, the threshold tests between the
     // next step's MFMAs).  Measured on 262 144 users x 100 k items, same box, against the two older kernels, which stay
@@ -1501,6 +1875,63 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
             frag_cap = 0;
             SKR_HIP(hipMalloc(&frag_buf, need));
             frag_cap = need;
+        }
+        if (mode == "f16x2") {
+            // the fp16x2 sweep, its guard, and the bf16x3 kernel over the rows the guard flagged (fused_topk_kernel_v7's header)
+            static void* f7_buf = nullptr;       // [scales | fp16 fragments | scaled bias | flagged rows]
+            static size_t f7_cap = 0;
+            const size_t frag16_bytes = static_cast<size_t>(n_tiles) * 2 * F7_GROUP_U4 * sizeof(uint4);
+            const size_t bias_bytes = static_cast<size_t>(n_tiles) * FE_TI * sizeof(float);
+            const size_t flag_bytes = (static_cast<size_t>(B) + 63) / 64 * 64 * sizeof(int32_t);
+            const size_t need7 = 256 + frag16_bytes + bias_bytes + flag_bytes;
+            if (need7 > f7_cap) {
+                if (f7_buf) {
+                    SKR_HIP(hipStreamSynchronize(st));
+                    SKR_HIP(hipFree(f7_buf));
+                }
+                f7_buf = nullptr;
+                f7_cap = 0;
+                SKR_HIP(hipMalloc(&f7_buf, need7));
+                f7_cap = need7;
+            }
+            char* base = static_cast<char*>(f7_buf);
+            F7Scales* sc = reinterpret_cast<F7Scales*>(base);
+            g_f7_scales = sc;
+            uint4* frag16 = reinterpret_cast<uint4*>(base + 256);
+            float* bias_s = reinterpret_cast<float*>(base + 256 + frag16_bytes);
+            int32_t* flags = reinterpret_cast<int32_t*>(base + 256 + frag16_bytes + bias_bytes);
+            SKR_HIP(hipMemsetAsync(sc, 0, sizeof(F7Scales), st));
+            const int64_t it_thr = static_cast<int64_t>(n_items) * (FE_D / 4), us_thr = static_cast<int64_t>(B) * (FE_D / 4);
+            hipLaunchKernelGGL(absmax_rows_kernel, dim3(static_cast<unsigned>((it_thr + 255) / 256)), dim3(256), 0, st, d_item_table,
+                               static_cast<const int32_t*>(nullptr), static_cast<int64_t>(n_items), &sc->max_v_bits);
+            hipLaunchKernelGGL(absmax_rows_kernel, dim3(static_cast<unsigned>((us_thr + 255) / 256)), dim3(256), 0, st, d_user_table,
+                               d_users, static_cast<int64_t>(B), &sc->max_u_bits);
+            hipLaunchKernelGGL(f7_scales_kernel, dim3(1), dim3(64), 0, st, sc);
+            const int64_t nthr7 = static_cast<int64_t>(n_tiles) * 256;
+            hipLaunchKernelGGL(split_items_kernel_v7, dim3(static_cast<unsigned>((nthr7 + 255) / 256)), dim3(256), 0, st, d_item_table,
+                               d_item_bias, n_items, n_tiles, sc, frag16, bias_s);
+            SKR_LAUNCH_CHECK();
+            FusedArgs a7 = a;
+            a7.guard_s_inv = &sc->S_inv;
+            a7.flag_list = flags;
+            a7.flag_count = &sc->n_flagged;
+            if (d_item_bias)
+                hipLaunchKernelGGL(fused_topk_kernel_v7<true>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a7, frag16, bias_s, sc);
+            else
+                hipLaunchKernelGGL(fused_topk_kernel_v7<false>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a7, frag16, bias_s, sc);
+            SKR_LAUNCH_CHECK();
+            // the rows the guard did not accept: the bf16x3 kernel, on the device's own count (an empty list returns at once)
+            hipLaunchKernelGGL(split_items_kernel_v6_if, dim3(static_cast<unsigned>((nthr7 + 255) / 256)), dim3(256), 0, st, d_item_table,
+                               n_items, n_tiles, frag_buf, &sc->n_flagged);
+            FusedArgs a6 = a;
+            a6.row_map = flags;
+            a6.n_rows_dev = &sc->n_flagged;
+            if (d_item_bias)
+                hipLaunchKernelGGL((fused_topk_kernel_v6<true, 0>), dim3(blocks), dim3(FE_WAVES * 64), 0, st, a6, frag_buf);
+            else
+                hipLaunchKernelGGL((fused_topk_kernel_v6<false, 0>), dim3(blocks), dim3(FE_WAVES * 64), 0, st, a6, frag_buf);
+            SKR_LAUNCH_CHECK();
+            return SKR_OK;
         }
         const int64_t nthr = static_cast<int64_t>(n_tiles) * 256;
         if (groups16)

@@ -71,6 +71,7 @@ SIGNATURES = {
     "skr_scatter_add_rows": (i32, [vp, vp, i32, i32, vp, f32, vp, vp, vp, vp]),
     "skr_eval_scores": (i32, [vp, i32, i32, i64, vp, vp, C.POINTER(i32), i32, i32, vp, vp, vp, vp]),
     "skr_eval_fused_workspace": (sz, [i32, i32]),
+    "skr_eval_fused_rejected": (i32, [vp, vp]),
     "skr_eval_fused_topk": (i32, [vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, sz, vp]),
     "skr_mask_train": (i32, [vp, i32, i32, i64, vp, vp, vp, vp]),
     "skr_score_matrix": (i32, [vp, vp, i32, vp, vp, i32, i32, vp, i64, vp]),

@@ -323,3 +323,67 @@ def test_eval_scores_is_deterministic_on_long_rows():
     host = sc[:64].cpu().numpy()
     for r in range(64):
         assert np.array_equal(outs[0][r].cpu().numpy(), O.topk_ids_heap(host[r], K))
+
+
+def _rejected():
+    import ctypes
+    from skrec import _hip
+    n = ctypes.c_int32(-1)
+    _hip.check(_hip.lib().skr_eval_fused_rejected(ctypes.byref(n), _hip.stream()))
+    return n.value
+
+
+def test_f16x2_guard_accepts_tables_of_one_magnitude_and_is_as_accurate_as_the_fp32_chain(monkeypatch):
+    """SKR_FUSED_MODE=f16x2 (fused_topk_kernel_v7): on factors of one magnitude -- any common scale, it is divided out by a
+    power of two -- the guard accepts every user, and the scores are as close to float64 as the FP32-MFMA kernel's"""
+    from gpu_utils import fused_topk
+    rng = np.random.default_rng(7)
+    B, I, K = 192, 6000, 20
+    for scale in (1e-3, 0.2, 30.0):
+        U = (rng.standard_normal((B, 64)) * scale).astype(np.float32)
+        V = (rng.standard_normal((I, 64)) * scale).astype(np.float32)
+        b = (rng.standard_normal(I) * scale * scale).astype(np.float32)
+        err = {}
+        for mode in ("f16x2", "fp32"):
+            monkeypatch.setenv("SKR_FUSED_MODE", mode)
+            ids, sc = fused_topk(U, np.arange(B, dtype=np.int32), V, b, None, np.zeros(0, np.int32), K)
+            if mode == "f16x2":
+                assert _rejected() == 0
+            exact = np.einsum("bkd,bd->bk", V.astype(np.float64)[ids], U.astype(np.float64)) + b.astype(np.float64)[ids]
+            denom = np.einsum("bkd,bd->bk", np.abs(V.astype(np.float64))[ids], np.abs(U.astype(np.float64))) + np.abs(b.astype(np.float64))[ids]
+            err[mode] = (np.abs(sc - exact) / denom).max()
+        assert err["f16x2"] < 4e-7 and err["f16x2"] < 2.0 * err["fp32"], err
+
+
+def test_f16x2_guard_hands_rows_it_cannot_vouch_for_to_bf16x3(monkeypatch):
+    """users (and items) far smaller than their table's largest element lose the low fp16 piece to denormals: the guard must
+    catch every such user -- its smallest returned score lies under the floor -- and the bf16x3 kernel recompute it inside the
+    same call; the result is then as good as bf16x3's for EVERY user.  Also: a table holding an inf is rejected whole."""
+    from gpu_utils import fused_topk
+    monkeypatch.setenv("SKR_FUSED_MODE", "f16x2")
+    rng = np.random.default_rng(11)
+    B, I, K = 160, 3000, 10
+    U = (rng.standard_normal((B, 64)) * 0.3).astype(np.float32)
+    V = (rng.standard_normal((I, 64)) * 0.3).astype(np.float32)
+    small = rng.permutation(B)[:37]
+    U[small] *= np.float32(2.0 ** -22)                    # rows 4 million times smaller than the table's largest
+    V[rng.permutation(I)[:500]] *= np.float32(2.0 ** -20)
+    ids, sc = fused_topk(U, np.arange(B, dtype=np.int32), V, None, None, np.zeros(0, np.int32), K)
+    n_rej = _rejected()
+    assert 37 <= n_rej < B
+    exact = np.einsum("bkd,bd->bk", V.astype(np.float64)[ids], U.astype(np.float64))
+    denom = np.einsum("bkd,bd->bk", np.abs(V.astype(np.float64))[ids], np.abs(U.astype(np.float64)))
+    assert (np.abs(sc - exact) / denom).max() < 4e-7      # the small users included: relative to THEIR scores
+    full = U.astype(np.float64) @ V.astype(np.float64).T
+    order = np.argsort(-full, axis=1, kind="stable")
+    want = order[:, :K]
+    gap = -np.diff(np.take_along_axis(full, order[:, :K + 1], axis=1), axis=1)
+    clear = (gap > 1e-5 * np.abs(np.take_along_axis(full, order[:, :1], axis=1))).all(axis=1)
+    assert clear.mean() > 0.5
+    assert np.array_equal(ids[clear], want[clear])
+    # an inf in the item table: nothing can be vouched for, every user goes to the bf16x3 kernel (non-finite scores are outside
+    # what either kernel promises -- skr_common.h: rank_key -- the point is that f16x2 does not pretend)
+    V2 = V.copy()
+    V2[5, 3] = np.inf
+    fused_topk(np.abs(U), np.arange(B, dtype=np.int32), V2, None, None, np.zeros(0, np.int32), K)
+    assert _rejected() == B
