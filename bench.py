@@ -614,31 +614,42 @@ def eval_leg(args, world, rank, dev, dist, U, V, bias, ds, nU, nI, out):
         hr = (sums.cpu().numpy() / ne).reshape(2, args.top_k)[:, -1]
         out["eval"] = {"users_per_sec": ne * world / te, "users": ne * world, "top_k": args.top_k, "seconds": te,
                        f"HR@{args.top_k}": float(hr[0]), f"NDCG@{args.top_k}": float(hr[1])}
-        mode = os.environ.get("SKR_FUSED_MODE", "bf16x3")
+        mode = os.environ.get("SKR_FUSED_MODE", "f16x2")
         if mode == "fp32":
             out["roofline_eval"] = {"kernel": "fused_topk_kernel_v3 (FP32 MFMA GEMM + mask + top-K)", "bound": "mfma",
                                     "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                                     "traffic": None, "avg_launch_ms": k_ms, "algorithmic_flop_per_launch": flops}
         else:
-            # every fp32 product is formed from six bf16 x bf16 MFMA products with fp32 accumulation, so the matrix
-            # pipe issues 6x the algorithmic flops: the peak for THIS arithmetic is the dense bf16 peak / 6
-            kname = {"f16x2": "fused_topk_kernel_v7 (v_mfma_f32_16x16x32_f16: fp32 operands scaled by a power of two and split into 2 fp16 "
-                              "pieces, 3 MFMAs per fp32 product; guarded, rejected rows recomputed by the bf16x3 kernel; the fraction "
-                              "below is still priced against the bf16x3 peak of 6 products; ",
+            # every fp32 product is formed from `products` half-precision MFMA products with fp32 accumulation (f16x2: three
+            # fp16 x fp16, bf16x3: six bf16 x bf16), so the matrix pipe issues that many times the algorithmic flops: the peak for
+            # THIS arithmetic is the dense 16-bit MFMA peak (the same for fp16 and bf16) / products
+            products = 3 if mode == "f16x2" else 6
+            kname = {"f16x2": "fused_topk_kernel_v7 (v_mfma_f32_16x16x32_f16, steps of 16 items, threshold tests between the MFMAs, one item "
+                              "ring per workgroup; fp32 operands scaled by a power of two per table and split into 2 fp16 pieces, 3 fp16 "
+                              "MFMAs per fp32 product, fp32 accumulate; per-user guard, rejected rows recomputed by the bf16x3 kernel in "
+                              "the same call; GEMM + mask + top-K)",
                      "bf16x3s": "fused_topk_kernel_v5 (v_mfma_f32_32x32x16_bf16, one item-tile ring per workgroup; ",
                      "bf16x3w": "fused_topk_kernel_v4 (v_mfma_f32_32x32x16_bf16, one item-tile ring per wavefront; "}.get(
                 mode, "fused_topk_kernel_v6 (v_mfma_f32_16x16x32_bf16, steps of 16 items, threshold tests between the MFMAs, "
                       "one item ring per workgroup; ")
-            out["roofline_eval"] = {"kernel": kname +
-                                              "fp32 operands split into 3 bf16 pieces, 6 bf16 MFMAs per "
-                                              "fp32 product, fp32 accumulate; GEMM + mask + top-K)", "bound": "mfma",
-                                    "achieved": tf, "peak": MFMA_BF16_PEAK_TF / 6.0, "unit": "TFLOP/s", "unit_note": "fp32-equivalent (algorithmic 2*B*I*64 flop)",
-                                    "frac": tf / (MFMA_BF16_PEAK_TF / 6.0), "traffic": None, "avg_launch_ms": k_ms,
-                                    "algorithmic_flop_per_launch": flops, "mfma_issued_tflops": 6.0 * tf,
-                                    "mfma_peak_tflops": MFMA_BF16_PEAK_TF,
-                                    "accuracy": "error vs float64 relative to sum|u_i v_i|: max 2.9e-7 (FP32-MFMA kernel: 3.5e-7), "
-                                                "tools/fused_accuracy.py"}
+            if mode != "f16x2":
+                kname += "fp32 operands split into 3 bf16 pieces, 6 bf16 MFMAs per fp32 product, fp32 accumulate; GEMM + mask + top-K)"
+            peak = MFMA_BF16_PEAK_TF / products
+            out["roofline_eval"] = {"kernel": kname, "bound": "mfma",
+                                    "achieved": tf, "peak": peak, "unit": "TFLOP/s", "unit_note": "fp32-equivalent (algorithmic 2*B*I*64 flop)",
+                                    "frac": tf / peak, "traffic": None, "avg_launch_ms": k_ms,
+                                    "algorithmic_flop_per_launch": flops, "mfma_products_per_fp32_product": products,
+                                    "mfma_issued_tflops": products * tf, "mfma_peak_tflops": MFMA_BF16_PEAK_TF,
+                                    "frac_if_priced_as_bf16x3": tf / (MFMA_BF16_PEAK_TF / 6.0),
+                                    "accuracy": "error vs float64 relative to sum|u_i v_i| (tools/fused_accuracy.py): f16x2 max 2.1e-7 / "
+                                                "mean 2.8e-8, bf16x3 2.6e-7 / 3.1e-8, FP32-MFMA kernel 3.5e-7 / 5.1e-8"}
+            if mode == "f16x2":
+                import ctypes
+                n_rej = ctypes.c_int32(-1)
+                _hip.check(_hip.lib().skr_eval_fused_rejected(ctypes.byref(n_rej), _hip.stream()))
+                out["roofline_eval"]["rows_rejected_by_the_guard_in_the_last_call"] = n_rej.value
             if world == 1:   # the FP32-MFMA kernel on the same inputs, for comparison
+                mode_was = os.environ.get("SKR_FUSED_MODE")
                 os.environ["SKR_FUSED_MODE"] = "fp32"
                 f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ids_bf = ids.clone()
@@ -646,13 +657,16 @@ def eval_leg(args, world, rank, dev, dist, U, V, bias, ds, nU, nI, out):
                 eval_once()
                 f1.record()
                 torch.cuda.synchronize()
-                del os.environ["SKR_FUSED_MODE"]
+                if mode_was is None:
+                    del os.environ["SKR_FUSED_MODE"]
+                else:
+                    os.environ["SKR_FUSED_MODE"] = mode_was
                 ms32 = f0.elapsed_time(f1)
                 tf32 = flops / (ms32 * 1e-3) / 1e12
                 out["roofline_eval_fp32"] = {"kernel": "fused_topk_kernel_v3 (FP32 MFMA)", "bound": "mfma", "achieved": tf32,
                                              "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf32 / MFMA_F32_PEAK_TF,
                                              "avg_launch_ms": ms32,
-                                             "top_k_lists_identical_to_bf16x3": float((ids_bf == ids).all(dim=1).float().mean())}
+                                             "top_k_lists_identical_to_the_default_kernel": float((ids_bf == ids).all(dim=1).float().mean())}
 
 
 

@@ -164,15 +164,15 @@ int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
  *   d_train_rowptr/d_train_items  CSR over ALL users, items sorted ascending (may be NULL: no mask)
  *   d_topk_ids int32[B, top_k], d_topk_scores float[B, top_k] (may be NULL)
  *   d_work / work_bytes   scratch from skr_eval_fused_workspace(B, top_k)
- * Arithmetic (environment SKR_FUSED_MODE, read per call): "bf16x3" (default) forms every fp32 product from six
- * bf16 x bf16 MFMA products of the exactly split operands with fp32 accumulation -- measured error vs float64
- * below the plain chain's -- and keeps a library-owned device buffer of n_items*64*6 bytes for the split item
- * table; "fp32" runs exact fp32 FMA chains on the FP32 MFMA.  ("bf16x3" is fused_topk_kernel_v6, 16-item steps on
- * v_mfma_f32_16x16x32_bf16; "bf16x3s" / "bf16x3w" select the two older 32x32x16 kernels, same arithmetic.)
- * "f16x2": every operand, scaled by a power of two per table, is split into TWO fp16 pieces and a product formed from
- * three fp16 MFMA products (half the matrix work of bf16x3); fp32-level accuracy holds while the scores that decide
- * a list lie well above an absolute floor set by the largest elements of the two tables -- checked per user on the
- * device, and every user that fails is recomputed by the bf16x3 kernel inside the same call.
+ * Arithmetic (environment SKR_FUSED_MODE, read per call).  "f16x2" (default): every operand, scaled by a power of two
+ * per table, is split into TWO fp16 pieces and a product formed from three fp16 MFMA products with fp32 accumulation;
+ * fp32-level accuracy (measured error vs float64 below the plain chain's) holds while the scores that decide a list
+ * lie well above an absolute floor set by the largest elements of the two tables -- checked per user on the device,
+ * and every user that fails is recomputed by the bf16x3 kernel inside the same call (skr_eval_fused_rejected counts
+ * them).  "bf16x3": three bf16 pieces, six MFMA products, no condition on the operands (fused_topk_kernel_v6, 16-item
+ * steps on v_mfma_f32_16x16x32_bf16; "bf16x3s" / "bf16x3w" select the two older 32x32x16 kernels, same arithmetic).
+ * "fp32": exact fp32 FMA chains on the FP32 MFMA.  The split modes keep library-owned device buffers for the split
+ * item table (n_items*64*6 bytes, f16x2: + n_items*64*4).
  * Requires n_items - max train row length >= top_k (else SKR_EINVAL: use skr_eval_scores). */
 size_t skr_eval_fused_workspace(int B, int top_k);
 /* SKR_FUSED_MODE=f16x2 only: how many rows of the LAST skr_eval_fused_topk call on `stream` its guard did not accept and

@@ -41,7 +41,8 @@ def tiny_dir(tmp_path, golden):
 
 @pytest.fixture(params=["bf16x3", "f16x2", "bf16x3s", "bf16x3w", "fp32"])
 def fused_mode(request, monkeypatch):
-    """the modes of skr_eval_fused_topk (read per call from SKR_FUSED_MODE): bf16x3 (the default = bf16x3g: 16-item steps on the
-    16x16x32 MFMA), f16x2 (two fp16 pieces per operand behind a guard, the rows it rejects recomputed by bf16x3), bf16x3s / bf16x3w (the older kernels forced: one tile ring per workgroup / a ring per wavefront), fp32"""
+    """the modes of skr_eval_fused_topk (read per call from SKR_FUSED_MODE): f16x2 (the default: two fp16 pieces per operand
+    behind a guard, the rows it rejects recomputed by bf16x3), bf16x3 (16-item steps on the 16x16x32 bf16 MFMA), bf16x3s /
+    bf16x3w (the older kernels forced: one tile ring per workgroup / a ring per wavefront), fp32"""
     monkeypatch.setenv("SKR_FUSED_MODE", request.param)
     return request.param

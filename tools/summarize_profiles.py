@@ -65,7 +65,7 @@ for k in ("adam_cold_rows_kernel<4>", "adam_cold_kernel<2>", "adam_hot_kernel", 
         ent["l2_hit_rate"] = h / max(h + m_, 1.0)
     summary["kernels"][k] = ent
 
-# 3. eval kernel PMC (MFMA utilisation, clock): the largest launch of each fused kernel (v6 = bf16x3, the default;
+# 3. eval kernel PMC (MFMA utilisation, clock): the largest launch of each fused kernel (v7 = f16x2, the default; v6 = bf16x3;
 #    v3 = FP32 MFMA, run by bench.py for comparison)
 p = f"{src}/evalpmc_counter_collection.csv"
 if os.path.exists(p):
@@ -77,9 +77,9 @@ if os.path.exists(p):
             d["dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             d["grid_threads"] = int(r["Grid_Size"])
             kn = r["Kernel_Name"]
-            d["kernel"] = ("v6_bf16x3" if "topk_kernel_v6" in kn else "v5_bf16x3" if "topk_kernel_v5" in kn else
+            d["kernel"] = ("v7_f16x2" if "topk_kernel_v7" in kn else "v6_bf16x3" if "topk_kernel_v6" in kn else "v5_bf16x3" if "topk_kernel_v5" in kn else
                            "v4_bf16x3" if "topk_kernel_v4" in kn else "v3_fp32")
-    for tagk in ("v6_bf16x3", "v5_bf16x3", "v4_bf16x3", "v3_fp32"):
+    for tagk in ("v7_f16x2", "v6_bf16x3", "v5_bf16x3", "v4_bf16x3", "v3_fp32"):
         cand = [d for d in agg.values() if d["kernel"] == tagk]
         if not cand:
             continue
