@@ -12,7 +12,7 @@ import csv, collections
 rows=list(csv.DictReader(open("$R/gpurun_out/prof_evalpmc_${mode}_$abl/evalpmc_counter_collection.csv")))
 agg=collections.defaultdict(dict)
 for r in rows:
-    if "fused_topk" in r["Kernel_Name"]:
+    if ("fused_topk_kernel_v7" if "$mode" == "f16x2" else "fused_topk_kernel_v3" if "$mode" == "fp32" else "fused_topk_kernel_v") in r["Kernel_Name"] and not ("$mode" != "fp32" and "kernel_v3" in r["Kernel_Name"]):
         d=agg[r["Dispatch_Id"]]
         d[r["Counter_Name"]]=float(r["Counter_Value"]); d["dur_us"]=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3; d["grid"]=int(r["Grid_Size"])
 big=max(agg.values(), key=lambda d:(d["grid"], d["dur_us"]))
