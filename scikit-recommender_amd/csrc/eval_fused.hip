@@ -320,6 +320,10 @@ __device__ __forceinline__ float compact_select_n(const FusedArgs& a, const Wave
     }
     mask_train_lockstep<NR>(a, w, ul, k, rr);
     if (a.ablate == 6) mask_train_lockstep<NR>(a, w, ul, k, rr);
+    // every load of this compaction has been consumed: a wait the compiler can SEE costs nothing here and tells its waitcnt pass
+    // that only stores are in flight from now on (see tile_candidates_v4 for what happens without: it drains the DMA ring in
+    // front of every tile); fused_topk_kernel_v7 relies on this one and does not wait for the survivors' stores to be acknowledged
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), gfx9 encoding
     const int K = a.top_k;
     int valid = 0;
 #pragma unroll
@@ -1595,17 +1599,21 @@ __global__ __launch_bounds__(256) void split_items_kernel_v6_if(const float* __r
 __device__ __forceinline__ void group_candidates_v7(const FusedArgs& a, const WaveCtx& w, const f32x4 (&acc)[4],
                                                     const bool (&pass)[4][4], int base, float (&thr_s)[4], float S, float S_inv) {
     const int qd = w.lane >> 4, c16 = w.lane & 15;
+    // all reservations first, then all stores: ONE LDS round trip per step with events (this kernel has the 16 registers)
+    int pos[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         int* cnt_p = &w.cnt[16 * g + c16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (pass[g][i]) pos[g][i] = __hip_atomic_fetch_add(cnt_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
         uint64_t* list = w.my_cand + static_cast<int64_t>(16 * g + c16) * a.cap;
-        int pos[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (pass[g][i]) pos[i] = __hip_atomic_fetch_add(cnt_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (pass[g][i]) list[pos[i]] = skr::rank_key(acc[g][i] * S_inv, base + 4 * qd + i);   // the real score: an exact power-of-two scaling
+            if (pass[g][i]) list[pos[g][i]] = skr::rank_key(acc[g][i] * S_inv, base + 4 * qd + i);   // the real score: an exact power-of-two scaling
     }
     uint64_t need = __ballot(w.cnt[w.lane] > a.trigger);
     if (need) {
@@ -1618,7 +1626,7 @@ __device__ __forceinline__ void group_candidates_v7(const FusedArgs& a, const Wa
             for (int g = 0; g < 4; ++g)
                 if (g == ug && c16 == (ul & 15)) thr_s[g] = nt;
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler (see tile_candidates_v4)
+        // (no wait for the survivors' stores here: compact_select_n has told the compiler that its loads are done)
     }
 }
 
