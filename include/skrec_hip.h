@@ -172,7 +172,8 @@ int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
  * them).  "bf16x3": three bf16 pieces, six MFMA products, no condition on the operands (fused_topk_kernel_v6, 16-item
  * steps on v_mfma_f32_16x16x32_bf16; "bf16x3s" / "bf16x3w" select the two older 32x32x16 kernels, same arithmetic).
  * "fp32": exact fp32 FMA chains on the FP32 MFMA.  The split modes keep library-owned device buffers for the split
- * item table (n_items*64*6 bytes, f16x2: + n_items*64*4).
+ * item table (n_items*64*6 bytes, f16x2: + n_items*64*4), one set per process: calls in a split mode must be issued
+ * on ONE stream at a time (calls on the same stream queue behind each other, which is what the evaluator does).
  * Requires n_items - max train row length >= top_k (else SKR_EINVAL: use skr_eval_scores). */
 size_t skr_eval_fused_workspace(int B, int top_k);
 /* SKR_FUSED_MODE=f16x2 only: how many rows of the LAST skr_eval_fused_topk call on `stream` its guard did not accept and
