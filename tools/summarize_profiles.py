@@ -83,7 +83,9 @@ if os.path.exists(p):
         cand = [d for d in agg.values() if d["kernel"] == tagk]
         if not cand:
             continue
-        big = max(cand, key=lambda d: d["grid_threads"])
+        big = max(cand, key=lambda d: (d["grid_threads"], d["dur_us"]))
+        if big["dur_us"] < 100.0:     # the guard's fall-back launch over an empty list: not a measurement
+            continue
         clk = big["GRBM_GUI_ACTIVE"] / 8 / (big["dur_us"] * 1e-6)
         simd_cycles = big["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024
         big["effective_clock_GHz"] = clk / 1e9
