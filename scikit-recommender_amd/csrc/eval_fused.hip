@@ -1858,6 +1858,9 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     static const int trig_env = [] { const char* e = getenv("SKR_FUSED_TRIGGER"); return e ? atoi(e) : 0; }();
     // measured on MI355X (profiles/r01_eval_history.txt): K=10 is best around K+48, K>=50 at the cap
     a.trigger = trig_env > 0 ? trig_env : 30 + 3 * top_k;
+    // a list of at most 128 entries is compacted in two registers per lane, a longer one in four: between top-31 and top-53 the
+    // rule above lands just beyond that step and pays for it (top-40 on 262 144 users: 14.7 ms at 150, 13.5 at 112-120)
+    if (trig_env <= 0 && a.trigger > 120 && a.trigger < 190) a.trigger = 120;
     if (a.trigger < top_k) a.trigger = top_k;
     if (a.trigger > a.cap - FE_TI) a.trigger = a.cap - FE_TI;
     static const int ablate = [] { const char* e = getenv("SKR_FUSED_ABLATE"); return e ? atoi(e) : 0; }();
