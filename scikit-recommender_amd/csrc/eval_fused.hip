@@ -1814,7 +1814,7 @@ int fused_cap(int top_k) {
     return FE_CAP;
 }
 
-F7Scales* g_f7_scales = nullptr;   // device: scales and guard count of the last f16x2 call (skr_eval_fused_rejected)
+F7Scales* g_f7_scales = nullptr;   // device: scales and guard count of the last call, if it ran in f16x2 (skr_eval_fused_rejected)
 
 }  // namespace
 
@@ -1848,6 +1848,7 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     SKR_REQUIRE((d_train_rowptr == nullptr) == (d_train_items == nullptr), "train CSR: both pointers or neither");
     SKR_REQUIRE(((reinterpret_cast<uintptr_t>(d_user_table) | reinterpret_cast<uintptr_t>(d_item_table) |
                   reinterpret_cast<uintptr_t>(d_item_bias)) & 15) == 0, "tables must be 16-byte aligned");
+    g_f7_scales = nullptr;             // set again below if this call runs the fp16x2 sweep
     if (B == 0) return SKR_OK;
     if (work_bytes < skr_eval_fused_workspace(B, top_k) || !d_work)
         return skr::fail(SKR_ENOMEM, "workspace too small: need %zu bytes", skr_eval_fused_workspace(B, top_k));
