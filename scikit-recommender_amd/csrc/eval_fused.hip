@@ -378,7 +378,7 @@ __device__ __forceinline__ float compact_select_n(const FusedArgs& a, const Wave
 
 // mid-sweep compaction of one list; returns the user's new threshold
 __device__ __forceinline__ float compact_user(const FusedArgs& a, const WaveCtx& w, int ul, int64_t /*unused: mid-sweep only*/) {
-    __threadfence_block();  // this wave's earlier appends are re-read below by other lanes of the same wave (same CU, same L1: in order)
+    if (a.ablate != 20) __threadfence_block();  // this wave's earlier appends are re-read below by other lanes of the same wave (same CU, same L1: in order); 20: timing experiment without it
     const int n = w.cnt[ul];   // wave-uniform
     float thr;
     if (n <= 64) thr = compact_select_n<1>(a, w, ul, n);
@@ -1238,10 +1238,10 @@ __device__ __forceinline__ void group_candidates_v6(const FusedArgs& a, const Wa
     for (int g = 0; g < 4; ++g) {
         int* cnt_p = &w.cnt[16 * g + c16];
         uint64_t* list = w.my_cand + static_cast<int64_t>(16 * g + c16) * a.cap;
-        int pos[4];
+        unsigned pos[4];   // unsigned: see group_candidates_v7
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (pass[g][i]) pos[i] = __hip_atomic_fetch_add(cnt_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (pass[g][i]) pos[i] = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(cnt_p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (pass[g][i]) list[pos[i]] = skr::rank_key(acc[g][i], base + 4 * qd + i);   // pos < trigger + 16 <= cap by the compaction rule
@@ -1597,17 +1597,35 @@ __global__ __launch_bounds__(256) void split_items_kernel_v6_if(const float* __r
 
 // candidate path of one finished item group: group_candidates_v6 with the accumulators in the scaled domain
 __device__ __forceinline__ void group_candidates_v7(const FusedArgs& a, const WaveCtx& w, const f32x4 (&acc)[4],
-                                                    const bool (&pass)[4][4], int base, float (&thr_s)[4], float S, float S_inv) {
+                                                    const bool (&pass)[4][4], const uint64_t (&mask)[4][4], int base,
+                                                    float (&thr_s)[4], float S, float S_inv) {
     const int qd = w.lane >> 4, c16 = w.lane & 15;
-    // all reservations first, then all stores: ONE LDS round trip per step with events (this kernel has the 16 registers)
-    int pos[4][4];
+    // All reservations first, then ONE wait, then all stores: one LDS round trip per step with events (this kernel has the
+    // 16 registers).  The atomics are issued from inline asm under the lane mask of their test, without a branch: written
+    // with the builtin inside `if (pass)`, hipcc copies every result into its merge register in the same masked block and
+    // waits for the LDS there -- one round trip per EVENT.  The wait below names every position as an operand, so no use of
+    // one can be scheduled in front of it (the compiler does not know these registers are in flight).
+    unsigned pos[4][4];
+    const unsigned one = 1u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        int* cnt_p = &w.cnt[16 * g + c16];
+        const uint32_t cnt_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_ptr_t)&w.cnt[16 * g + c16]));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (pass[g][i]) pos[g][i] = __hip_atomic_fetch_add(cnt_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int i = 0; i < 4; ++i) {
+            pos[g][i] = 0u;
+            uint64_t saved;
+            asm volatile("s_and_saveexec_b64 %1, %2\n\tds_add_rtn_u32 %0, %3, %4\n\ts_mov_b64 exec, %1"
+                         : "+v"(pos[g][i]), "=&s"(saved)
+                         : "s"(mask[g][i]), "v"(cnt_addr), "v"(one)
+                         : "memory");
+        }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(pos[0][0]), "+v"(pos[0][1]), "+v"(pos[0][2]), "+v"(pos[0][3]), "+v"(pos[1][0]), "+v"(pos[1][1]),
+                   "+v"(pos[1][2]), "+v"(pos[1][3]), "+v"(pos[2][0]), "+v"(pos[2][1]), "+v"(pos[2][2]), "+v"(pos[2][3]),
+                   "+v"(pos[3][0]), "+v"(pos[3][1]), "+v"(pos[3][2]), "+v"(pos[3][3])
+                 :
+                 : "memory");
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         uint64_t* list = w.my_cand + static_cast<int64_t>(16 * g + c16) * a.cap;
@@ -1721,24 +1739,24 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v7(FusedAr
         for (int i = 0; i < 4; ++i) accB[g][i] = -INFINITY;   // "group -1": nothing passes
     int slot = 0;
     int brow = 0, brow2 = 2;
-    // one step = one item group: 6 slots of four MFMAs (one piece product on the four user groups); slots 0..4 carry three
-    // threshold tests of group hs-1 each, slot 5 the sixteenth
-#define F7_TEST(Q, PRV)                                                                                       \
+    // one step = one item group: 6 slots of four MFMAs (one piece product on the four user groups); each of the first sixteen
+    // MFMAs is followed by one threshold test of group hs-1
+#define F7_TEST(Q, PRV)   /* the sixteen lane masks are OR-ed behind the step's last MFMA: a scalar OR right behind its       \
+                             v_cmp would make the next MFMA wait for the compare's result to reach the scalar unit */ \
     {                                                                                                         \
         pass_[(Q) >> 2][(Q) & 3] = PRV[(Q) >> 2][(Q) & 3] > thr[(Q) >> 2];                                    \
-        any_ |= pass_[(Q) >> 2][(Q) & 3];                                                                     \
+        mask_[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_ballot_w64(PRV[(Q) >> 2][(Q) & 3] > thr[(Q) >> 2]);      \
     }
 #define F7_SLOT(S_, AF, BP, ACC, PRV)                                                                         \
     {                                                                                                         \
-        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                      \
+        /* ONE threshold test behind each of the step's first sixteen MFMAs: a 16x16x32 MFMA holds the vector issue for 8 of    \
+           its 16 cycles, so a single 4-cycle instruction per gap is nearly free and a cluster of three is not               \
+           (MI355X_MICROARCH.md, vector-instruction issue cost) */                                            \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                    \
             ACC[g_] = F7_MFMA(AF, BP[g_][(S_) / 3], (S_) == 0 ? seed_ : ACC[g_]);                             \
-        if ((S_) < 5) {                                                                                       \
-            F7_TEST(3 * ((S_) < 5 ? (S_) : 0), PRV) F7_TEST(3 * ((S_) < 5 ? (S_) : 0) + 1, PRV)               \
-            F7_TEST(3 * ((S_) < 5 ? (S_) : 0) + 2, PRV)                                                       \
-        } else {                                                                                              \
-            F7_TEST(15, PRV)                                                                                  \
+            if ((S_) < 4) F7_TEST(4 * ((S_) & 3) + g_, PRV)                                                   \
+            FE3_PIN();                                                                                        \
         }                                                                                                     \
-        FE3_PIN();                                                                                            \
     }
 #define F7_STEP(CUR, NXT, HS, ACC, PRV, LAST)                                                                 \
     {                                                                                                         \
@@ -1772,11 +1790,14 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v7(FusedAr
         }                                                                                                     \
         bool any_ = false;                                                                                    \
         bool pass_[4][4] = {};                                                                                \
+        uint64_t mask_[4][4] = {};                                                                            \
         FE3_PIN();                                                                                            \
         /* small terms first, per k-step: lo*hi, hi*lo, hi*hi */                                              \
         F7_SLOT(0, CUR[1], bh, ACC, PRV)  F7_SLOT(1, CUR[0], bl, ACC, PRV)  F7_SLOT(2, CUR[0], bh, ACC, PRV)  \
         F7_SLOT(3, CUR[3], bh, ACC, PRV)  F7_SLOT(4, CUR[2], bl, ACC, PRV)  F7_SLOT(5, CUR[2], bh, ACC, PRV)  \
-        if (__any(any_)) group_candidates_v7(a, w, PRV, pass_, (hs_ - 1) * F6_GI, thr, S, S_inv);             \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                      \
+            any_ |= (pass_[g_][0] | pass_[g_][1]) | (pass_[g_][2] | pass_[g_][3]);                            \
+        if (__any(any_)) group_candidates_v7(a, w, PRV, pass_, mask_, (hs_ - 1) * F6_GI, thr, S, S_inv);      \
         slot = nslot_;                                                                                        \
     }
     for (int t = 0; t < n_tiles - 1; ++t) {
@@ -1793,14 +1814,16 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v7(FusedAr
     {
         bool any_ = false;
         bool pass_[4][4];
+        uint64_t mask_[4][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 pass_[g][i] = accB[g][i] > thr[g];
+                mask_[g][i] = __builtin_amdgcn_ballot_w64(accB[g][i] > thr[g]);
                 any_ |= pass_[g][i];
             }
-        if (__any(any_)) group_candidates_v7(a, w, accB, pass_, (n_half - 1) * F6_GI, thr, S, S_inv);
+        if (__any(any_)) group_candidates_v7(a, w, accB, pass_, mask_, (n_half - 1) * F6_GI, thr, S, S_inv);
     }
     __threadfence_block();
     final_compactions(a, w);
@@ -1811,7 +1834,9 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v7(FusedAr
 // (profiles/r01_eval_history.txt), so the smaller scratch footprint stays.
 int fused_cap(int top_k) {
     (void)top_k;
-    return FE_CAP;
+    // SKR_FUSED_CAP (64 / 128 / 256; experiments on the scratch lists' footprint -- the trigger must leave 32 free slots)
+    static const int cap_env = [] { const char* e = getenv("SKR_FUSED_CAP"); return e ? atoi(e) : 0; }();
+    return (cap_env == 64 || cap_env == 128) ? cap_env : FE_CAP;
 }
 
 F7Scales* g_f7_scales = nullptr;   // device: scales and guard count of the last call, if it ran in f16x2 (skr_eval_fused_rejected)
