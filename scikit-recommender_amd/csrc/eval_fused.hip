@@ -1772,7 +1772,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v7(FusedAr
             else if (HAS_BIAS && !(hs_ & 1) && wv == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      \
             else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                             \
         }                                                                                                     \
-        __syncthreads();                                                                                      \
+        if (a.ablate != 19) __syncthreads();   /* 19: timing experiment without the barrier (results unreliable) */ \
         FE3_PIN();                                                                                            \
         if (more3_) issue_group(hs_ + F5_RING, slot, brow2);                                                  \
         f32x4 seed_;                                                                                          \
