@@ -1042,9 +1042,13 @@ __global__ __launch_bounds__(BPR_WAVES * 64) void bpr_fused_step_kernel(
     const int32_t* __restrict__ meta, int n, int64_t ublk0, int64_t iblk0, int64_t bblk0, int s_now, AdamBlockArgs a,
     float reg, float* __restrict__ loss, int loss_slots, int dbg, const float* __restrict__ pre) {
     __shared__ float s_loss[BPR_WAVES], s_l2[BPR_WAVES];
-    // dbg & 16: issue priority over the cold pass that shares the SIMDs (side stream).  Measured (bench.py, 200 steps): the
-    // step +6 % (42.2 -> 44.9 M interactions/s) but the cold pass 0.47 -> 0.57 ms, which then bounds the block; off
-    if (dbg & 16) __builtin_amdgcn_s_setprio(3);
+    // Issue priority over the cold pass that shares the SIMDs (side stream); dbg & 16 switches it off.  Round 2 measured it
+    // alone (the step +6 %, but the cold pass 0.47 -> 0.57 ms, which then bounded the block) and left it off; round 3 pairs it
+    // with one more cold-pass workgroup per CU (SKR_COLD_BPC 4 -> 5), which gives the pass back what the priority takes:
+    // step launch 18.7 -> 15.3 us, cold pass 0.56 -> 0.54 ms, epoch 1.083 -> 1.010 s, the 20-step slice 36.2 -> 40.2 M
+    // interactions/s on the same box (tools/cold_bpc_sweep.sh; 6 per CU: epoch 0.965 s but the short slice scatters 32-40 M,
+    // 7 and more: the step kernel finds no room, 21.5 us)
+    if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float acc_loss = 0.0f, acc_l2 = 0.0f;
     for (int b = blockIdx.x * BPR_WAVES + wv; b < n; b += gridDim.x * BPR_WAVES) {
@@ -1844,7 +1848,7 @@ static int adam_block_cold_impl(float* d_p, float* d_m, float* d_v, int64_t n, f
     a.eps = eps;
     a.k = k;
     adam_block_scalars(a, lr, beta1, beta2, step_t0, k, tf);
-    static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // workgroups per CU.  The pass is off the critical path (it runs beside the k-step block's small launches): 4 leaves them more of the chip than 8 and is still done in time (tools/cold_bpc_sweep.sh, 960 timed steps: 24.9 / 31.3 / 30.3 / 28.1 M interactions/s at 2 / 3 / 4 / 8; at 200 timed steps 3 and 4 are level, and 3 makes the pass itself 15 % slower)
+    static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 5; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // workgroups per CU.  The pass runs beside the k-step block's small launches: round 2 settled on 4 (960 timed steps: 24.9 / 31.3 / 30.3 / 28.1 M interactions/s at 2 / 3 / 4 / 8); round 3: 5, together with the step kernel's issue priority (see bpr_fused_step_kernel)
     // SKR_COLD_REST=0 keeps every cold block on the full update (the float4 kernel): the A/B switch of tools/microbench.py
     static const bool rest = [] { const char* e = getenv("SKR_COLD_REST"); return !(e && atoi(e) == 0); }();
     adam_block_thresholds(a, lr, beta1, beta2, eps, k);
