@@ -231,11 +231,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_rows_kernel(int n_rows, i
                                                                    const float* __restrict__ X, const skr_spmm_epilogue ep,
                                                                    const uint8_t* __restrict__ row_mask,
                                                                    const uint8_t* __restrict__ col_mask,
-                                                                   const int64_t* __restrict__ split, int n_win, int win_prio) {
-    // win_prio = window | issue priority << 16 (SKR_SPMM_PRIO=rows: this kernel at priority 3 against the long-row tasks that run
-    // beside it on the plan's second stream -- an experiment)
-    if ((win_prio >> 16) == 3) __builtin_amdgcn_s_setprio(3);
-    const int win = win_prio & 0xffff;
+                                                                   const int64_t* __restrict__ split, int n_win, int win) {
     // split / n_win / win: the columns are cut into n_win WINDOWS (X is far larger than the Infinity Cache: each launch
     // gathers from one window of it); split[r * (n_win - 1) + w] = first entry of row r in window w + 1.  Launch `win`
     // takes the row's entries of its window; the first writes Y, the later ones add to it, the last applies the epilogue.
@@ -296,8 +292,6 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
                                                                     const uint8_t* __restrict__ row_mask,
                                                                     const uint8_t* __restrict__ col_mask, int ld4,
                                                                     const uint8_t* __restrict__ hot_flag) {
-    if ((group >> 16) == 3) __builtin_amdgcn_s_setprio(3);   // SKR_SPMM_PRIO=tasks
-    group &= 0xffff;
     const int b = group * 8 + (blockIdx.x & 7);
     if (b >= n_blocks) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -957,15 +951,13 @@ int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, c
     int64_t wgs = (static_cast<int64_t>(plan->n_rows) + ROW_WAVES - 1) / ROW_WAVES;
     if (wgs > 8192) wgs = 8192;
     const dim3 rgrid(static_cast<unsigned>(wgs)), blk(ROW_WAVES * 64), tgrid(8 * BLK_WGS_PER_XCD);
-    static const int prio_who = [] { const char* e = getenv("SKR_SPMM_PRIO"); return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 't' ? 2 : 0)); }();
-    const int rows_prio = prio_who == 1 ? (3 << 16) : 0, tasks_prio = prio_who == 2 ? (3 << 16) : 0;
     for (int w = 0; w < plan->n_win; ++w) {
         if (d_col_mask)
             hipLaunchKernelGGL(spmm_rows_kernel<true>, rgrid, blk, 0, st, plan->n_rows, plan->long_thr, plan->rowptr, plan->col, plan->val,
-                               d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w | rows_prio);
+                               d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w);
         else
             hipLaunchKernelGGL(spmm_rows_kernel<false>, rgrid, blk, 0, st, plan->n_rows, plan->long_thr, plan->rowptr, plan->col, plan->val,
-                               d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w | rows_prio);
+                               d_X, ep, d_row_mask, d_col_mask, plan->split, plan->n_win, w);
     }
     SKR_LAUNCH_CHECK();
     // the densest rows through LDS -- unless the call says that most of X is zero (col_mask: the first backward hop), where
@@ -994,10 +986,10 @@ int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, c
             //  item side: the gather path, not the task's fixed cost, is the limit.  profiles/r02_spmm_lab.txt, run 7)
             for (int g = 0; g < groups; ++g) {
                 if (d_col_mask)
-                    hipLaunchKernelGGL(spmm_tasks_kernel<true>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g | tasks_prio, plan->tasks,
+                    hipLaunchKernelGGL(spmm_tasks_kernel<true>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
                                        plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask, ld >> 2, hot_flag);
                 else
-                    hipLaunchKernelGGL(spmm_tasks_kernel<false>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g | tasks_prio, plan->tasks,
+                    hipLaunchKernelGGL(spmm_tasks_kernel<false>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
                                        plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask, ld >> 2, hot_flag);
             }
             SKR_LAUNCH_CHECK();
