@@ -628,8 +628,7 @@ def eval_leg(args, world, rank, dev, dist, U, V, bias, ds, nU, nI, out):
                               "ring per workgroup; fp32 operands scaled by a power of two per table and split into 2 fp16 pieces, 3 fp16 "
                               "MFMAs per fp32 product, fp32 accumulate; per-user guard, rejected rows recomputed by the bf16x3 kernel in "
                               "the same call; GEMM + mask + top-K)",
-                     "bf16x3s": "fused_topk_kernel_v5 (v_mfma_f32_32x32x16_bf16, one item-tile ring per workgroup; ",
-                     "bf16x3w": "fused_topk_kernel_v4 (v_mfma_f32_32x32x16_bf16, one item-tile ring per wavefront; "}.get(
+                     }.get(
                 mode, "fused_topk_kernel_v6 (v_mfma_f32_16x16x32_bf16, steps of 16 items, threshold tests between the MFMAs, "
                       "one item ring per workgroup; ")
             if mode != "f16x2":

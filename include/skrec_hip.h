@@ -170,7 +170,7 @@ int skr_eval_scores(const float* d_scores, int n_users, int n_items, int64_t ld,
  * lie well above an absolute floor set by the largest elements of the two tables -- checked per user on the device,
  * and every user that fails is recomputed by the bf16x3 kernel inside the same call (skr_eval_fused_rejected counts
  * them).  "bf16x3": three bf16 pieces, six MFMA products, no condition on the operands (fused_topk_kernel_v6, 16-item
- * steps on v_mfma_f32_16x16x32_bf16; "bf16x3s" / "bf16x3w" select the two older 32x32x16 kernels, same arithmetic).
+ * steps on v_mfma_f32_16x16x32_bf16).
  * "fp32": exact fp32 FMA chains on the FP32 MFMA.  The split modes keep library-owned device buffers for the split
  * item table (n_items*64*6 bytes, f16x2: + n_items*64*4), one set per process: calls in a split mode must be issued
  * on ONE stream at a time (calls on the same stream queue behind each other, which is what the evaluator does).

@@ -321,7 +321,7 @@ __device__ __forceinline__ float compact_select_n(const FusedArgs& a, const Wave
     mask_train_lockstep<NR>(a, w, ul, k, rr);
     if (a.ablate == 6) mask_train_lockstep<NR>(a, w, ul, k, rr);
     // every load of this compaction has been consumed: a wait the compiler can SEE costs nothing here and tells its waitcnt pass
-    // that only stores are in flight from now on (see tile_candidates_v4 for what happens without: it drains the DMA ring in
+    // that only stores are in flight from now on (without it hipcc's waitcnt pass carries the loads around the sweep loop and drains the DMA ring in
     // front of every tile); fused_topk_kernel_v7 relies on this one and does not wait for the survivors' stores to be acknowledged
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), gfx9 encoding
     const int K = a.top_k;
@@ -687,22 +687,22 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v3(FusedAr
 }
 
 // ================================================================================================
-// bf16x3 sweep (the default; SKR_FUSED_MODE=fp32 selects the kernel above): the same sweep with every fp32 operand split into three
-// bf16 pieces x = hi + mid + lo (exact: 3 x 8 significand bits) and the product formed from the six piece
-// products of weight >= 2^-16 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped mid*lo, lo*mid,
-// lo*lo are <= 2^-23 relative) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Six bf16 MFMAs of
-// 16x the fp32 MFMA rate replace one fp32 MFMA chain: 2.7x less matrix-pipe time per tile at fp32-level
-// accuracy (products are exact in fp32; the error is the dropped terms plus fp32 accumulation).  Measured
-// against float64 (tools/fused_accuracy.py, error / sum|u_i v_i| over the returned top-50 scores of 512 users x
-// 20 000 items, factor scales 1e-3 .. 30): max 2.9e-7 / mean 3.8e-8, the FP32-MFMA kernel: max 3.5e-7 / mean
-// 5.1e-8 -- the split form rounds 24 times per dot product (once per MFMA), the fp32 chain 64 times.
-//   * split_items_kernel writes the item table once per call in FRAGMENT order: tile (32 items) x chunk
-//     (16 dims) x piece -> 1 KB blocks in which lane l's 16 bytes are the 8 bf16 the MFMA wants from it
-//     (A[row l&31][k = 8 (l>>5) + j]), so LDS-DMA copies blocks verbatim and ds_read_b128 at lane*16 is
-//     conflict-free without a swizzle;
-//   * the user fragments are split in registers at kernel start (96 VGPRs);
-//   * one 12 KB LDS buffer per wave: the 12 A fragments of a tile are read into registers at the top of the
-//     step, after which the buffer is free and the next tile's DMA is issued behind the MFMAs.
+// The split arithmetics (SKR_FUSED_MODE=bf16x3 / f16x2; fp32 selects the kernel above): the same sweep with every fp32 operand
+// split into 16-bit pieces and a product formed from half-precision MFMA products with fp32 accumulation.
+// bf16x3: x = hi + mid + lo in bf16 (exact: 3 x 8 significand bits), the six piece products of weight >= 2^-16 (hi*hi, hi*mid,
+// mid*hi, mid*mid, hi*lo, lo*hi; the dropped mid*lo, lo*mid, lo*lo are <= 2^-23 relative): six bf16 MFMAs of 16x the fp32 MFMA
+// rate replace one fp32 MFMA chain, at fp32-level accuracy for ANY operands (products are exact in fp32; the error is the dropped
+// terms plus fp32 accumulation: 24 roundings per dot product, the fp32 chain has 64).  f16x2 (fused_topk_kernel_v7 below): two fp16
+// pieces of the operands scaled by a power of two per table, three products, behind a guard.  Measured against float64
+// (tools/fused_accuracy.py, error / sum|u_i v_i| over the returned top-50 scores of 512 users x 20 000 items, factor scales
+// 1e-3 .. 30): f16x2 max 2.1e-7 / mean 2.8e-8, bf16x3 2.6e-7 / 3.1e-8, the FP32-MFMA kernel 3.5e-7 / 5.1e-8.
+// Common mechanics: a split kernel writes the item table once per call in FRAGMENT order -- 1 KB blocks in which lane l's 16
+// bytes are the 8 pieces the MFMA wants from it -- so LDS-DMA copies blocks verbatim and ds_read_b128 at lane*16 is
+// conflict-free without a swizzle; the user fragments are split in registers at kernel start.
+// History (profiles/r01_eval_history.txt): rounds 1 and 2 ran bf16x3 on v_mfma_f32_32x32x16_bf16 -- fused_topk_kernel_v4
+// (a ring of half tiles per wavefront, no barriers: 18.1 ms per 262 144 users at top-10) and fused_topk_kernel_v5 (one ring per
+// workgroup, a barrier per half-tile step: 17.3 ms); fused_topk_kernel_v6 (16x16x32, 16.3 ms) is faster at every top_k, and the
+// two were taken out in round 3 (git history has them).
 // ================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -730,468 +730,33 @@ __device__ __forceinline__ void split3x8(const float* v, uint4& hi, uint4& mid, 
 constexpr int F4_FRAGS = 12;                 // 4 chunks of 16 dims x 3 pieces
 constexpr int F4_TILE_U4 = F4_FRAGS * 64;    // uint4 per tile (12 KB): fragments q*3+p, i.e. two 6 KB halves
 
-__global__ __launch_bounds__(256) void split_items_kernel(const float* __restrict__ table, int n_items, int n_tiles,
-                                                          uint4* __restrict__ frags) {
-    const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;   // (tile, chunk, lane)
-    if (g >= static_cast<int64_t>(n_tiles) * 4 * 64) return;
-    const int lane = static_cast<int>(g & 63), q = static_cast<int>((g >> 6) & 3);
-    const int64_t T = g >> 8;
-    int64_t item = T * FE_TI + (lane & 31);
-    if (item >= n_items) item = n_items - 1;
-    const float4* src = reinterpret_cast<const float4*>(table + item * FE_D + q * 16 + 8 * (lane >> 5));
-    const float4 v0 = src[0], v1 = src[1];
-    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    uint4 hi, mid, lo;
-    split3x8(v, hi, mid, lo);
-    uint4* dst = frags + T * F4_TILE_U4 + (q * 3) * 64 + lane;
-    dst[0] = hi;
-    dst[64] = mid;
-    dst[128] = lo;
-}
-
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4& u) {
     union { uint4 u; bf16x8 b; } c;
     c.u = u;
     return c.b;
 }
-#define F4_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(A), as_bf16x8(B), C, 0, 0, 0)
-
-// Candidate path of the bf16x3 sweep.  With the matrix work 2.7x shorter the fp32 kernel's append path (LDS
-// atomics, a 16-iteration predicated store loop per fragment) would dominate, so here the list lengths of a
-// wave's 64 users live in REGISTERS (replicated in lanes c and c+32, which hold the two row halves of user c),
-// a lane walks only its own passing rows, and LDS / the compaction code are involved only when a list
-// actually crosses the trigger.
-struct CandRegs {
-    int cnt[2];
-};
-
-__device__ __forceinline__ float select16(const f32x16& v, int r) {
-    const float a0 = (r & 1) ? v[1] : v[0], a1 = (r & 1) ? v[3] : v[2], a2 = (r & 1) ? v[5] : v[4], a3 = (r & 1) ? v[7] : v[6];
-    const float a4 = (r & 1) ? v[9] : v[8], a5 = (r & 1) ? v[11] : v[10], a6 = (r & 1) ? v[13] : v[12], a7 = (r & 1) ? v[15] : v[14];
-    const float b0 = (r & 2) ? a1 : a0, b1 = (r & 2) ? a3 : a2, b2 = (r & 2) ? a5 : a4, b3 = (r & 2) ? a7 : a6;
-    const float c0 = (r & 4) ? b1 : b0, c1 = (r & 4) ? b3 : b2;
-    return (r & 8) ? c1 : c0;
-}
-
-__device__ __forceinline__ void cand_sync_to_lds(const WaveCtx& w, const CandRegs& cr) {
-    if (w.h == 0) {
-        w.cnt[w.c] = cr.cnt[0];
-        w.cnt[32 + w.c] = cr.cnt[1];
-    }
-    __threadfence_block();
-}
-
-__device__ __forceinline__ void tile_candidates_v4(const FusedArgs& a, const WaveCtx& w, const f32x16& acc0,
-                                                   const f32x16& acc1, int tile_base, float (&thr)[2], CandRegs& cr) {
-    // m = 2*m + (score > threshold), rows 15..0: one compare and one add-with-carry per row
-    uint32_t m0, m1;
-    // Row 15 in plain C: hipcc's hazard recogniser then inserts the wait states an MFMA result needs before a
-    // VALU may read it (it does not look inside inline asm; without this the asm below read accumulators that
-    // the last MFMAs had not written yet).  Rows 14..1 in asm, two rows of both fragments interleaved so that
-    // every carry consumer sits three instructions behind its producer (VALU write of VCC / an SGPR pair ->
-    // VALU carry-in needs two wait states; hipcc puts `s_nop 1` there), row 0 in C again.
-    m0 = (acc0[15] > thr[0]) ? 1u : 0u;
-    m1 = (acc1[15] > thr[1]) ? 1u : 0u;
-#pragma unroll
-    for (int r = 14; r >= 2; r -= 2) {
-        uint64_t c1, c2, c3;
-        asm volatile("v_cmp_gt_f32 vcc, %5, %6\n\t"
-                     "v_cmp_gt_f32 %2, %7, %8\n\t"
-                     "v_cmp_gt_f32 %3, %9, %6\n\t"
-                     "v_cmp_gt_f32 %4, %10, %8\n\t"
-                     "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-                     "v_addc_co_u32 %1, %2, %1, %1, %2\n\t"
-                     "v_addc_co_u32 %0, %3, %0, %0, %3\n\t"
-                     "v_addc_co_u32 %1, %4, %1, %1, %4"
-                     : "+v"(m0), "+v"(m1), "=&s"(c1), "=&s"(c2), "=&s"(c3)
-                     : "v"(acc0[r]), "v"(thr[0]), "v"(acc1[r]), "v"(thr[1]), "v"(acc0[r - 1]), "v"(acc1[r - 1])
-                     : "vcc");
-    }
-    m0 = 2u * m0 + ((acc0[0] > thr[0]) ? 1u : 0u);
-    m1 = 2u * m1 + ((acc1[0] > thr[1]) ? 1u : 0u);
-    if (tile_base + FE_TI > a.n_items) {   // only the last, partial tile has rows that are not items
-        uint32_t valid = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (tile_base + (r & 3) + 8 * (r >> 2) + 4 * w.h < a.n_items) valid |= 1u << r;
-        m0 &= valid;
-        m1 &= valid;
-    }
-    if (!__any((m0 | m1) != 0u)) return;
-    // both fragments' counts in one register, exchanged between lanes c and c+32 by v_permlane32_swap (no LDS trip)
-    const uint32_t packed = static_cast<uint32_t>(__popc(m0)) | (static_cast<uint32_t>(__popc(m1)) << 16);
-    const auto sw = __builtin_amdgcn_permlane32_swap(packed, packed, false, false);   // [0]: lower half's value, [1]: upper half's
-    const uint32_t lo_cnt = sw[0], hi_cnt = sw[1];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        uint32_t mm = f ? m1 : m0;
-        const f32x16& acc = f ? acc1 : acc0;
-        const int n_lo = static_cast<int>((lo_cnt >> (16 * f)) & 0xffffu), n_hi = static_cast<int>((hi_cnt >> (16 * f)) & 0xffffu);
-        uint64_t* list = w.my_cand + static_cast<int64_t>(32 * f + w.c) * a.cap + cr.cnt[f] + (w.h ? n_lo : 0);
-        cr.cnt[f] += n_lo + n_hi;        // <= trigger + 32 <= cap by the compaction rule
-        while (mm) {
-            const int r = __ffs(static_cast<int>(mm)) - 1;
-            mm &= mm - 1;
-            *list++ = skr::rank_key(select16(acc, r), tile_base + (r & 3) + 8 * (r >> 2) + 4 * w.h);
-        }
-    }
-    uint64_t need = (__ballot(cr.cnt[0] > a.trigger) & 0xffffffffull) | (__ballot(cr.cnt[1] > a.trigger) << 32);
-    if (need) {
-        cand_sync_to_lds(w, cr);
-        while (need) {
-            const int ul = __ffsll(static_cast<long long>(need)) - 1;
-            need &= need - 1;
-            const float nt = compact_user(a, w, ul, -1);
-            if (w.c == (ul & 31)) {
-                if (ul >> 5) thr[1] = nt; else thr[0] = nt;
-            }
-        }
-        cr.cnt[0] = w.cnt[w.c];
-        cr.cnt[1] = w.cnt[32 + w.c];
-        // A wait the COMPILER can see: without it hipcc's waitcnt pass carries the compaction's loads as
-        // "possibly outstanding" around the loop and puts an s_waitcnt vmcnt(0) in front of the first MFMA of
-        // every tile, which also drains the hand-issued LDS-DMA ring (measured: +2.5 ms per 262 144 users).
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), gfx9 encoding
-    }
-}
-
 constexpr int F4_HALF_U4 = 6 * 64;      // uint4 per half tile (two 16-dim chunks x 3 pieces = 6 KB)
-constexpr int F4_RING = 3;              // half tiles resident per wave (18 KB)
 constexpr int F4_ROWBUF = 128;
 
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v4(FusedArgs a, const uint4* __restrict__ frags) {
-    __shared__ uint4 s_tile[FE_WAVES][F4_RING * F4_HALF_U4];   // wave-private ring of three half tiles
-    __shared__ float4 s_bias[FE_WAVES][2][16];                 // the bias DMA writes 4 B for each of the 64 lanes
-    __shared__ int s_cnt[FE_WAVES][FE_UW];
-    __shared__ int64_t s_row_beg[FE_WAVES][FE_UW];
-    __shared__ int s_row_len[FE_WAVES][FE_UW];
-    __shared__ int s_rowbuf[FE_WAVES][F4_ROWBUF];
-    WaveCtx w;
-    w.lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    w.c = w.lane & 31;
-    w.h = w.lane >> 5;
-    const int lane = w.lane, c = w.c, h = w.h;
-    w.ubase = (static_cast<int64_t>(blockIdx.x) * FE_WAVES + wv) * FE_UW;
-    if (w.ubase >= a.B) return;
-    w.cnt = s_cnt[wv];
-    w.cnt[lane] = 0;
-    w.my_cand = a.cand + w.ubase * a.cap;
-    w.row_beg = s_row_beg[wv];
-    w.row_len = s_row_len[wv];
-    w.rowbuf = s_rowbuf[wv];
-    w.rowbuf_len = F4_ROWBUF;
-    {
-        const int64_t row = w.ubase + lane;
-        int64_t rb = 0;
-        int len = 0;
-        if (a.train_rowptr && row < a.B) {
-            const int u = a.users[row];
-            rb = a.train_rowptr[u];
-            len = static_cast<int>(a.train_rowptr[u + 1] - rb);
-        }
-        w.row_beg[lane] = rb;
-        w.row_len[lane] = len;
-    }
-    // user fragments: B[k = 8h + j][col c] of chunk q, three pieces each
-    uint4 bh[2][4], bm[2][4], bl[2][4];
-    float thr[2];
-    int uid[2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int64_t row = w.ubase + 32 * f + c;
-        const bool ok = row < a.B;
-        uid[f] = a.users[ok ? row : (a.B - 1)];
-        thr[f] = (ok && a.ablate != 1 && a.ablate != 7) ? -INFINITY : INFINITY;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid[f]) * FE_D + q * 16 + 8 * h);
-            const float4 v0 = up[0], v1 = up[1];
-            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            split3x8(v, bh[f][q], bm[f][q], bl[f][q]);
-        }
-    }
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {   // retire the loads here (see the fp32 kernel: hidden DMA vs counted vmcnt)
-            asm volatile("" : "+v"(bh[f][q].x), "+v"(bh[f][q].y), "+v"(bh[f][q].z), "+v"(bh[f][q].w));
-            asm volatile("" : "+v"(bm[f][q].x), "+v"(bm[f][q].y), "+v"(bm[f][q].z), "+v"(bm[f][q].w));
-            asm volatile("" : "+v"(bl[f][q].x), "+v"(bl[f][q].y), "+v"(bl[f][q].z), "+v"(bl[f][q].w));
-        }
-    const int n_tiles = (a.n_items + FE_TI - 1) / FE_TI;
-    const int n_half = 2 * n_tiles;
-    const uint32_t lt = lds_addr_of(&s_tile[wv][0]);
-    const uint32_t lb0 = lds_addr_of(&s_bias[wv][0][0]), lb1 = lds_addr_of(&s_bias[wv][1][0]);
-    // half tile `hs` (tile hs>>1, chunks 2*(hs&1) and 2*(hs&1)+1) -> ring slot `slot`; with the first half of a
-    // tile travels its bias row.  7 (6) DMA instructions per even (odd) half with a bias, 6 without.
-    const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
-    auto issue_half = [&](int hs, int slot) {
-        const char* sbase = reinterpret_cast<const char*>(frags) + static_cast<int64_t>(hs) * (F4_HALF_U4 * 16);   // wave-uniform
-        const uint32_t dst = lt + slot * (F4_HALF_U4 * 16);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) glds_b128_s(lane16, sbase + i * 1024, dst + i * 1024);
-        if (HAS_BIAS && !(hs & 1)) {
-            int bi = (hs >> 1) * FE_TI + (lane & 31);
-            bi = bi < a.n_items ? bi : a.n_items - 1;
-            glds_b32(a.item_bias + bi, ((hs >> 1) & 1) ? lb1 : lb0);
-        }
-    };
-    issue_half(0, 0);
-    issue_half(1, 1);                               // n_half >= 2 always
-    if (n_half > 2) issue_half(2, 2);
-    FE2_WAIT();
-    uint4 afA[6], afB[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) afA[i] = s_tile[wv][i * 64 + lane];
-    f32x16 acc0, acc1;
-    CandRegs cr{{0, 0}};
-    int slot = 0;                                   // ring slot of the half held in afA at an even step
-    // one step = one half tile.  At its start the fragments of half hs are in registers, so its ring slot
-    // is free: the DMA of half hs+3 goes there, then the fragments of half hs+1 are fetched (its DMA was
-    // issued two steps ago: a counted wait leaves the two younger DMAs in flight) while the 24 MFMAs run.
-#define F4_STEP(CUR, NXT, HS, EVEN)                                                                           \
-    {                                                                                                         \
-        const int hs_ = (HS);                                                                                 \
-        /* pinned: left to itself hipcc hoists this wait above the previous step's MFMAs (an asm volatile is  \
-           only ordered against memory operations), i.e. right behind the reads it waits for */               \
-        FE3_PIN();                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* CUR has landed in registers */                \
-        FE3_PIN();                                                                                            \
-        const bool more3_ = hs_ + 3 < n_half && a.ablate != 7;                                                \
-        if (more3_) issue_half(a.ablate == 8 ? ((hs_ + 3) & 31) : hs_ + 3, slot);                             \
-        const int nslot_ = slot == 2 ? 0 : slot + 1;                                                          \
-        if (hs_ + 1 < n_half) {                                                                               \
-            /* younger DMAs: half hs+2 (if it exists) and half hs+3 (if just issued) */                       \
-            if (hs_ + 2 >= n_half) FE2_WAIT();                                                                \
-            else if (!more3_) { if (HAS_BIAS && (EVEN)) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");      \
-                                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }                       \
-            else if (HAS_BIAS) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");                              \
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                            \
-            _Pragma("unroll") for (int i = 0; i < 6; ++i) NXT[i] = s_tile[wv][nslot_ * F4_HALF_U4 + i * 64 + lane]; \
-        }                                                                                                     \
-        FE3_PIN();                                                                                            \
-        if (EVEN) {                                                                                           \
-            if (HAS_BIAS) {                                                                                   \
-                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
-                    const float4 b4 = s_bias[wv][(hs_ >> 1) & 1][2 * g + h];                                  \
-                    acc0[4 * g + 0] = b4.x; acc0[4 * g + 1] = b4.y; acc0[4 * g + 2] = b4.z; acc0[4 * g + 3] = b4.w; \
-                }                                                                                             \
-            } else {                                                                                          \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;                                \
-            }                                                                                                 \
-            acc1 = acc0;                                                                                      \
-        }                                                                                                     \
-        _Pragma("unroll") for (int qq = 0; qq < 2; ++qq) {   /* small terms first */                          \
-            const int q = ((EVEN) ? 0 : 2) + qq;                                                              \
-            const uint4 &ah = CUR[3 * qq], &am = CUR[3 * qq + 1], &al = CUR[3 * qq + 2];                      \
-            acc0 = F4_MFMA(al, bh[0][q], acc0);  acc1 = F4_MFMA(al, bh[1][q], acc1);                          \
-            acc0 = F4_MFMA(ah, bl[0][q], acc0);  acc1 = F4_MFMA(ah, bl[1][q], acc1);                          \
-            acc0 = F4_MFMA(am, bm[0][q], acc0);  acc1 = F4_MFMA(am, bm[1][q], acc1);                          \
-            acc0 = F4_MFMA(am, bh[0][q], acc0);  acc1 = F4_MFMA(am, bh[1][q], acc1);                          \
-            acc0 = F4_MFMA(ah, bm[0][q], acc0);  acc1 = F4_MFMA(ah, bm[1][q], acc1);                          \
-            acc0 = F4_MFMA(ah, bh[0][q], acc0);  acc1 = F4_MFMA(ah, bh[1][q], acc1);                          \
-        }                                                                                                     \
-        if (!(EVEN)) {                                                                                        \
-            tile_candidates_v4(a, w, acc0, acc1, (hs_ >> 1) * FE_TI, thr, cr);                                \
-        }                                                                                                     \
-        slot = nslot_;                                                                                        \
-    }
-    for (int t = 0; t < n_tiles; ++t) {
-        F4_STEP(afA, afB, 2 * t, true)
-        F4_STEP(afB, afA, 2 * t + 1, false)
-    }
-#undef F4_STEP
-    cand_sync_to_lds(w, cr);
-    final_compactions(a, w);
-}
-
-constexpr int F5_RING = 3;              // half tiles resident per WORKGROUP (the counted waits and the two bias rows assume 3)
-
-// ================================================================================================
-// The same bf16x3 sweep with the item tile SHARED by the four wavefronts of a workgroup (the default up to top-32): in
-// fused_topk_kernel_v4 every wavefront streams the whole split item table through a ring of its own -- 8 wavefronts per CU
-// each write 12 KB per tile into LDS and read it back (the LDS-DMA stream costs 5 of the kernel's 19 ms, by ablation).
-// Here a half tile's six 1 KB blocks are brought by the four wavefronts together (2 + 2 + 1 + 1) into ONE ring, and a
-// workgroup barrier per half-tile step orders "all blocks of half hs+1 have landed" and "everybody holds half hs in
-// registers, its slot is free".  A quarter of the DMA instructions and of the LDS write traffic (a ring of six half tiles, the
-// DMA 2.5 tile times ahead of its use, was no faster: 17.6 ms); the wavefronts of a
-// workgroup advance in lock-step, so one that compacts a candidate list holds the other three at the next barrier.
-// ================================================================================================
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v5(FusedArgs a, const uint4* __restrict__ frags) {
-    __shared__ uint4 s_tile[F5_RING * F4_HALF_U4];             // ONE ring of F5_RING half tiles for the workgroup's four wavefronts
-    __shared__ float4 s_bias[2][16];                           // the bias DMA writes 4 B for each of the 64 lanes
-    __shared__ int s_cnt[FE_WAVES][FE_UW];
-    __shared__ int64_t s_row_beg[FE_WAVES][FE_UW];
-    __shared__ int s_row_len[FE_WAVES][FE_UW];
-    __shared__ int s_rowbuf[FE_WAVES][F4_ROWBUF];
-    WaveCtx w;
-    w.lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: it selects DMA blocks (scalar operands)
-    w.c = w.lane & 31;
-    w.h = w.lane >> 5;
-    const int lane = w.lane, c = w.c, h = w.h;
-    w.ubase = (static_cast<int64_t>(blockIdx.x) * FE_WAVES + wv) * FE_UW;
-    // a wavefront whose users lie beyond B stays: it carries its share of the tile DMA and of the workgroup barriers
-    // (its thresholds are +inf and it writes nothing)
-    w.cnt = s_cnt[wv];
-    w.cnt[lane] = 0;
-    w.my_cand = a.cand + w.ubase * a.cap;
-    w.row_beg = s_row_beg[wv];
-    w.row_len = s_row_len[wv];
-    w.rowbuf = s_rowbuf[wv];
-    w.rowbuf_len = F4_ROWBUF;
-    {
-        const int64_t row = w.ubase + lane;
-        int64_t rb = 0;
-        int len = 0;
-        if (a.train_rowptr && row < a.B) {
-            const int u = a.users[row];
-            rb = a.train_rowptr[u];
-            len = static_cast<int>(a.train_rowptr[u + 1] - rb);
-        }
-        w.row_beg[lane] = rb;
-        w.row_len[lane] = len;
-    }
-    // user fragments: B[k = 8h + j][col c] of chunk q, three pieces each
-    uint4 bh[2][4], bm[2][4], bl[2][4];
-    float thr[2];
-    int uid[2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int64_t row = w.ubase + 32 * f + c;
-        const bool ok = row < a.B;
-        uid[f] = a.users[ok ? row : (a.B - 1)];
-        thr[f] = (ok && a.ablate != 1 && a.ablate != 7) ? -INFINITY : INFINITY;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid[f]) * FE_D + q * 16 + 8 * h);
-            const float4 v0 = up[0], v1 = up[1];
-            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            split3x8(v, bh[f][q], bm[f][q], bl[f][q]);
-        }
-    }
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {   // retire the loads here (see the fp32 kernel: hidden DMA vs counted vmcnt)
-            asm volatile("" : "+v"(bh[f][q].x), "+v"(bh[f][q].y), "+v"(bh[f][q].z), "+v"(bh[f][q].w));
-            asm volatile("" : "+v"(bm[f][q].x), "+v"(bm[f][q].y), "+v"(bm[f][q].z), "+v"(bm[f][q].w));
-            asm volatile("" : "+v"(bl[f][q].x), "+v"(bl[f][q].y), "+v"(bl[f][q].z), "+v"(bl[f][q].w));
-        }
-    const int n_tiles = (a.n_items + FE_TI - 1) / FE_TI;
-    const int n_half = 2 * n_tiles;
-    const uint32_t lt = lds_addr_of(&s_tile[0]);
-    const uint32_t lb0 = lds_addr_of(&s_bias[0][0]), lb1 = lds_addr_of(&s_bias[1][0]);
-    // half tile `hs` (tile hs>>1, chunks 2*(hs&1) and 2*(hs&1)+1) -> ring slot `slot`; with the first half of a
-    // tile travels its bias row.  7 (6) DMA instructions per even (odd) half with a bias, 6 without.
-    const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
-    auto issue_half = [&](int hs, int slot) {
-        const char* sbase = reinterpret_cast<const char*>(frags) + static_cast<int64_t>(hs) * (F4_HALF_U4 * 16);   // wave-uniform
-        const uint32_t dst = lt + slot * (F4_HALF_U4 * 16);
-        // the half tile's six 1 KB blocks are shared out: wavefronts 0 and 1 bring two each, 2 and 3 one each (3 also the bias)
-        glds_b128_s(lane16, sbase + wv * 1024, dst + wv * 1024);
-        if (wv < 2) glds_b128_s(lane16, sbase + (4 + wv) * 1024, dst + (4 + wv) * 1024);
-        if (HAS_BIAS && !(hs & 1) && wv == 3) {
-            int bi = (hs >> 1) * FE_TI + (lane & 31);
-            bi = bi < a.n_items ? bi : a.n_items - 1;
-            glds_b32(a.item_bias + bi, ((hs >> 1) & 1) ? lb1 : lb0);
-        }
-    };
-#pragma unroll
-    for (int h0 = 0; h0 < F5_RING; ++h0)
-        if (h0 < n_half) issue_half(h0, h0);        // n_half >= 2 always
-    FE2_WAIT();
-    __syncthreads();                                // every wavefront's blocks have landed
-    uint4 afA[6], afB[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) afA[i] = s_tile[i * 64 + lane];
-    f32x16 acc0, acc1;
-    CandRegs cr{{0, 0}};
-    int slot = 0;                                   // ring slot of the half held in afA at an even step
-    // one step = one half tile.  At its start the fragments of half hs are in registers, so its ring slot
-    // is free: the DMA of half hs+3 goes there, then the fragments of half hs+1 are fetched (its DMA was
-    // issued two steps ago: a counted wait leaves the two younger DMAs in flight) while the 24 MFMAs run.
-#define F5_STEP(CUR, NXT, HS, EVEN)                                                                           \
-    {                                                                                                         \
-        const int hs_ = (HS);                                                                                 \
-        /* pinned: left to itself hipcc hoists this wait above the previous step's MFMAs (an asm volatile is  \
-           only ordered against memory operations), i.e. right behind the reads it waits for */               \
-        FE3_PIN();                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* CUR has landed in registers */                \
-        FE3_PIN();                                                                                            \
-        const bool more3_ = hs_ + F5_RING < n_half && a.ablate != 7;                                          \
-        const int nslot_ = slot == F5_RING - 1 ? 0 : slot + 1;                                                \
-        if (hs_ + 1 < n_half) {                                                                               \
-            /* my blocks of half hs+1 have landed once at most my blocks of half hs+2 are in flight (those of */  \
-            /* half hs+3 are issued below): two for wavefronts 0, 1 (and 3 with a bias row), else one         */  \
-            if (hs_ + 2 >= n_half) FE2_WAIT();                                                                \
-            else if (wv < 2 || (HAS_BIAS && (EVEN) && wv == 3)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); \
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                             \
-        }                                                                                                     \
-        /* ONE workgroup barrier per half-tile step: behind it every wavefront's blocks of half hs+1 have     */  \
-        /* landed, and every wavefront holds half hs in registers -- its ring slot is free for half hs+3     */  \
-        __syncthreads();                                                                                      \
-        FE3_PIN();                                                                                            \
-        if (more3_) issue_half(a.ablate == 8 ? ((hs_ + F5_RING) & 31) : hs_ + F5_RING, slot);                 \
-        if (hs_ + 1 < n_half) {                                                                               \
-            _Pragma("unroll") for (int i = 0; i < 6; ++i) NXT[i] = s_tile[nslot_ * F4_HALF_U4 + i * 64 + lane]; \
-        }                                                                                                     \
-        FE3_PIN();                                                                                            \
-        if (EVEN) {                                                                                           \
-            if (HAS_BIAS) {                                                                                   \
-                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
-                    const float4 b4 = s_bias[(hs_ >> 1) & 1][2 * g + h];                                  \
-                    acc0[4 * g + 0] = b4.x; acc0[4 * g + 1] = b4.y; acc0[4 * g + 2] = b4.z; acc0[4 * g + 3] = b4.w; \
-                }                                                                                             \
-            } else {                                                                                          \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;                                \
-            }                                                                                                 \
-            acc1 = acc0;                                                                                      \
-        }                                                                                                     \
-        _Pragma("unroll") for (int qq = 0; qq < 2; ++qq) {   /* small terms first */                          \
-            const int q = ((EVEN) ? 0 : 2) + qq;                                                              \
-            const uint4 &ah = CUR[3 * qq], &am = CUR[3 * qq + 1], &al = CUR[3 * qq + 2];                      \
-            acc0 = F4_MFMA(al, bh[0][q], acc0);  acc1 = F4_MFMA(al, bh[1][q], acc1);                          \
-            acc0 = F4_MFMA(ah, bl[0][q], acc0);  acc1 = F4_MFMA(ah, bl[1][q], acc1);                          \
-            acc0 = F4_MFMA(am, bm[0][q], acc0);  acc1 = F4_MFMA(am, bm[1][q], acc1);                          \
-            acc0 = F4_MFMA(am, bh[0][q], acc0);  acc1 = F4_MFMA(am, bh[1][q], acc1);                          \
-            acc0 = F4_MFMA(ah, bm[0][q], acc0);  acc1 = F4_MFMA(ah, bm[1][q], acc1);                          \
-            acc0 = F4_MFMA(ah, bh[0][q], acc0);  acc1 = F4_MFMA(ah, bh[1][q], acc1);                          \
-        }                                                                                                     \
-        if (!(EVEN)) {                                                                                        \
-            tile_candidates_v4(a, w, acc0, acc1, (hs_ >> 1) * FE_TI, thr, cr);                                \
-        }                                                                                                     \
-        slot = nslot_;                                                                                        \
-    }
-    for (int t = 0; t < n_tiles; ++t) {
-        F5_STEP(afA, afB, 2 * t, true)
-        F5_STEP(afB, afA, 2 * t + 1, false)
-    }
-#undef F5_STEP
-    cand_sync_to_lds(w, cr);
-    final_compactions(a, w);
-}
+constexpr int F5_RING = 3;              // item groups resident per WORKGROUP (the counted waits and the bias rows assume 3)
 
 // ================================================================================================
 // fused_topk_kernel_v6 (round 3): the bf16x3 sweep on v_mfma_f32_16x16x32_bf16, one step = a GROUP of 16 items over all 64
-// dims.  Why another shape: under bf16 MFMA load the chip holds its clock down (1.7 GHz in v5's loop, MFMA pipe busy 75 %
+// dims.  Why another shape: under bf16 MFMA load the chip holds its clock down (1.7 GHz in the 32x32x16 kernels' loop, MFMA pipe busy 75 %
 // of it), so cycles are not what the wall time is made of; MI355X_MICROARCH.md ("DVFS give-back", item 7) measures the
 // 16x16x32 form at 1.12-1.15 x the FLOP/s of the 32x32x16 form at equal cycles on random data.  The shape also turns the
 // schedule round:
 //   * an output tile is 16 items x 16 users with FOUR accumulator registers; a wavefront's 64 users are four user groups,
 //     so a step (16 items x 64 users x 64 dims = 2 k-steps x 6 piece products x 4 user groups = 48 MFMAs of 16 cycles, the
-//     same matrix-pipe time as v5's half tile) FINISHES 16 accumulator registers, and two such sets alternate in the 32
-//     registers v5's one tile needs.  The threshold tests of step hs-1 therefore issue between the MFMAs of step hs
+//     same matrix-pipe time as a 32-item half tile of the 32x32x16 form) FINISHES 16 accumulator registers, and two such sets
+//     alternate in the 32 registers one 32-item tile needs.  The threshold tests of step hs-1 therefore issue between the MFMAs of step hs
 //     (one v_cmp + one scalar OR per accumulator register, pinned two per slot), with no second accumulator pair: what
 //     VERDICT round 2, item 4 asked for without the 32 VGPRs it was priced at;
 //   * lane l holds, per user group g, the scores of user 16 g + (l & 15) against items 4 (l >> 4) + i, i < 4: a user's
 //     16 scores of a step sit in four lanes; the list lengths live in LDS and a passing lane reserves its slot with one
 //     LDS atomic (group_candidates_v6; a first form carried the lengths in registers and crossed the four lanes' counts
 //     by v_permlane16_swap / v_permlane32_swap: correct, ~4x the vector instructions per event);
-//   * everything outside the arithmetic is v5's: ONE ring of three 6 KB blocks per workgroup (a block = one item group:
+//   * around the arithmetic: ONE ring of three 6 KB blocks per workgroup (a block = one item group:
 //     2 k-steps x 3 pieces), brought by the four wavefronts together, one workgroup barrier per step, candidate lists in
 //     HBM scratch, the same compaction code.
 // split_items_kernel_v6 writes the table in this kernel's fragment order: group (16 items) x k-step (32 dims) x piece ->
@@ -1258,13 +823,11 @@ __device__ __forceinline__ void group_candidates_v6(const FusedArgs& a, const Wa
             for (int g = 0; g < 4; ++g)
                 if (g == ug && c16 == (ul & 15)) thr[g] = nt;
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler (see tile_candidates_v4)
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler (see compact_select_n)
     }
 }
 
-// VAR: timing experiments on the bare loop (SKR_FUSED_ABLATE 13..15; results are wrong by construction): 1 = no threshold
-// tests between the MFMAs, 2 = no fragment reads (the first group's fragments are reused), 3 = both
-template <bool HAS_BIAS, int VAR = 0>
+template <bool HAS_BIAS>
 __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedArgs a, const uint4* __restrict__ frags) {
     __shared__ uint4 s_tile[F5_RING * F4_HALF_U4];             // ONE ring of F5_RING item groups for the workgroup's four wavefronts
     __shared__ float4 s_bias[3][16];                           // a tile's bias row (the DMA writes 4 B for each of the 64 lanes: 32 items, twice);
@@ -1310,7 +873,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
         const int64_t row = w.ubase + 16 * g + c16;
         const bool ok = row < nB;
         const int uid = a.users[src_row(a, ok ? row : (nB - 1))];
-        thr[g] = (ok && a.ablate != 1 && a.ablate != 7 && a.ablate != 11 && (a.ablate < 12 || a.ablate > 15)) ? -INFINITY : INFINITY;
+        thr[g] = (ok && a.ablate != 1 && a.ablate != 7 && a.ablate != 11 && a.ablate != 12) ? -INFINITY : INFINITY;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float4* up = reinterpret_cast<const float4*>(a.user_table + static_cast<int64_t>(uid) * FE_D + ks * 32 + 8 * qd);
@@ -1351,10 +914,6 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
     uint4 afA[6], afB[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) afA[i] = s_tile[i * 64 + lane];
-    if (VAR & 2) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) afB[i] = afA[i];
-    }
     f32x4 accA[4], accB[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -1371,12 +930,9 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
             ACC[g_] = F6_MFMA(AF, BP[g_][(S) / 6], (S) == 0 ? seed_ : ACC[g_]);                               \
         if ((S) < 8) {                                                                                        \
             const int i_ = (S) & 3, gp_ = (((S) & 7) >> 2) * 2;                                               \
-            if (!(VAR & 1)) {                                                                                 \
-                pass_[gp_][i_] = PRV[gp_][i_] > thr[gp_];                                                     \
-                pass_[gp_ + 1][i_] = PRV[gp_ + 1][i_] > thr[gp_ + 1];                                         \
-                any_ |= pass_[gp_][i_] | pass_[gp_ + 1][i_];                                                  \
-            }                                                                                                 \
-            else asm volatile("" :: "v"(PRV[gp_][i_]), "v"(PRV[gp_ + 1][i_]));   /* keeps the MFMAs alive */  \
+            pass_[gp_][i_] = PRV[gp_][i_] > thr[gp_];                                                         \
+            pass_[gp_ + 1][i_] = PRV[gp_ + 1][i_] > thr[gp_ + 1];                                             \
+            any_ |= pass_[gp_][i_] | pass_[gp_ + 1][i_];                                                      \
         }                                                                                                     \
         FE3_PIN();                                                                                            \
     }
@@ -1386,7 +942,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
         FE3_PIN();                                                                                            \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* CUR has landed in registers */                \
         FE3_PIN();                                                                                            \
-        const bool more3_ = hs_ + F5_RING < n_half && a.ablate != 7 && a.ablate != 11 && (a.ablate < 12 || a.ablate > 15); \
+        const bool more3_ = hs_ + F5_RING < n_half && a.ablate != 7 && a.ablate != 11 && a.ablate != 12; \
         const int nslot_ = slot == F5_RING - 1 ? 0 : slot + 1;                                                \
         if (hs_ + 1 < n_half) {                                                                               \
             if (hs_ + 2 >= n_half) FE2_WAIT();                                                                \
@@ -1407,11 +963,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
         FE3_PIN();                                                                                            \
         /* unconditional (behind the last group it fetches a stale slot that nobody uses): a branch here would make  \
            hipcc wait for ALL LDS reads in front of the first MFMA */                                         \
-        if (!(VAR & 2)) {                                                                                     \
-            _Pragma("unroll") for (int i = 0; i < 6; ++i) NXT[i] = s_tile[nslot_ * F4_HALF_U4 + i * 64 + lane]; \
-        } else {                                                                                              \
-            _Pragma("unroll") for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(NXT[i].x), "+v"(NXT[i].y), "+v"(NXT[i].z), "+v"(NXT[i].w)); \
-        }                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) NXT[i] = s_tile[nslot_ * F4_HALF_U4 + i * 64 + lane];   \
         if (LAST) {   /* the last tile: rows beyond the catalogue start from -inf and stay there */            \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
                 if (hs_ * F6_GI + 4 * qd + i >= a.n_items) seed_[i] = -INFINITY;                              \
@@ -1450,7 +1002,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void fused_topk_kernel_v6(FusedAr
         if (__any(any_)) group_candidates_v6(a, w, accB, pass_, (n_half - 1) * F6_GI, thr);
     }
     __threadfence_block();
-    if (a.ablate >= 12 && a.ablate <= 15) return;   // timing experiment: bare loop without the final compactions
+    if (a.ablate == 12) return;   // timing experiment: bare loop without the final compactions
     final_compactions(a, w);
 }
 
@@ -1898,16 +1450,10 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     // "bf16x3" (three bf16 pieces, no guard needed) or "fp32" (the FP32-MFMA kernel)
     const char* mode_env = getenv("SKR_FUSED_MODE");
     const std::string mode = mode_env ? mode_env : "f16x2";
-    SKR_REQUIRE(mode == "fp32" || mode == "bf16x3" || mode == "bf16x3s" || mode == "bf16x3w" || mode == "bf16x3g" || mode == "f16x2",
-                "SKR_FUSED_MODE must be 'bf16x3', 'bf16x3g', 'bf16x3s', 'bf16x3w', 'f16x2' or 'fp32' (got '%s')", mode_env);
-    const bool mode_bf16x3 = mode != "fp32";
-    // bf16x3 (the default) = "g": fused_topk_kernel_v6, the 16x16x32 form (steps of 16 items, the threshold tests between the
-    // next step's MFMAs).  Measured on 262 144 users x 100 k items, same box, against the two older kernels, which stay
-    // selectable -- "s": fused_topk_kernel_v5 (32x32x16, one tile ring per workgroup), "w": fused_topk_kernel_v4 (a ring per
-    // wavefront, no barriers): top-10 16.3 vs 17.6 (s) ms, top-20 17.7 vs 19.4 (s), top-50 21.0 vs 21.9 (w), top-100 25.1 vs 25.4 (w)
-    const bool shared_ring = mode == "bf16x3s";
-    const bool groups16 = mode == "bf16x3g" || mode == "bf16x3";
-    if (mode_bf16x3) {
+    SKR_REQUIRE(mode == "fp32" || mode == "bf16x3" || mode == "f16x2",
+                "SKR_FUSED_MODE must be 'f16x2', 'bf16x3' or 'fp32' (got '%s')", mode_env);
+    const bool mode_split = mode != "fp32";
+    if (mode_split) {
         // library-owned scratch for the split item table (38 MB at 100 k items), grown on demand
         static uint4* frag_buf = nullptr;
         static size_t frag_cap = 0;
@@ -1978,40 +1524,21 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
             a6.row_map = flags;
             a6.n_rows_dev = &sc->n_flagged;
             if (d_item_bias)
-                hipLaunchKernelGGL((fused_topk_kernel_v6<true, 0>), dim3(blocks), dim3(FE_WAVES * 64), 0, st, a6, frag_buf);
+                hipLaunchKernelGGL(fused_topk_kernel_v6<true>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a6, frag_buf);
             else
-                hipLaunchKernelGGL((fused_topk_kernel_v6<false, 0>), dim3(blocks), dim3(FE_WAVES * 64), 0, st, a6, frag_buf);
+                hipLaunchKernelGGL(fused_topk_kernel_v6<false>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a6, frag_buf);
             SKR_LAUNCH_CHECK();
             return SKR_OK;
         }
+        // bf16x3: fused_topk_kernel_v6 (16-item steps on v_mfma_f32_16x16x32_bf16)
         const int64_t nthr = static_cast<int64_t>(n_tiles) * 256;
-        if (groups16)
-            hipLaunchKernelGGL(split_items_kernel_v6, dim3(static_cast<unsigned>((nthr + 255) / 256)), dim3(256), 0, st, d_item_table,
-                               n_items, n_tiles, frag_buf);
-        else
-            hipLaunchKernelGGL(split_items_kernel, dim3(static_cast<unsigned>((nthr + 255) / 256)), dim3(256), 0, st, d_item_table,
-                               n_items, n_tiles, frag_buf);
+        hipLaunchKernelGGL(split_items_kernel_v6, dim3(static_cast<unsigned>((nthr + 255) / 256)), dim3(256), 0, st, d_item_table,
+                           n_items, n_tiles, frag_buf);
         SKR_LAUNCH_CHECK();
-        static const unsigned dyn_lds = [] { const char* e = getenv("SKR_FUSED_DYN_LDS"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();   // occupancy experiments
-        if (groups16) {
-            if (d_item_bias)
-                switch (ablate) {
-                    case 13: hipLaunchKernelGGL((fused_topk_kernel_v6<true, 1>), dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf); break;
-                    case 14: hipLaunchKernelGGL((fused_topk_kernel_v6<true, 2>), dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf); break;
-                    case 15: hipLaunchKernelGGL((fused_topk_kernel_v6<true, 3>), dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf); break;
-                    default: hipLaunchKernelGGL((fused_topk_kernel_v6<true, 0>), dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
-                }
-            else
-                hipLaunchKernelGGL((fused_topk_kernel_v6<false, 0>), dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
-        } else if (shared_ring) {
-            if (d_item_bias)
-                hipLaunchKernelGGL(fused_topk_kernel_v5<true>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
-            else
-                hipLaunchKernelGGL(fused_topk_kernel_v5<false>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
-        } else if (d_item_bias)
-            hipLaunchKernelGGL(fused_topk_kernel_v4<true>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
+        if (d_item_bias)
+            hipLaunchKernelGGL(fused_topk_kernel_v6<true>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a, frag_buf);
         else
-            hipLaunchKernelGGL(fused_topk_kernel_v4<false>, dim3(blocks), dim3(FE_WAVES * 64), dyn_lds, st, a, frag_buf);
+            hipLaunchKernelGGL(fused_topk_kernel_v6<false>, dim3(blocks), dim3(FE_WAVES * 64), 0, st, a, frag_buf);
         SKR_LAUNCH_CHECK();
         return SKR_OK;
     }

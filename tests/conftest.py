@@ -39,10 +39,9 @@ def tiny_dir(tmp_path, golden):
     return str(root)
 
 
-@pytest.fixture(params=["bf16x3", "f16x2", "bf16x3s", "bf16x3w", "fp32"])
+@pytest.fixture(params=["f16x2", "bf16x3", "fp32"])
 def fused_mode(request, monkeypatch):
-    """the modes of skr_eval_fused_topk (read per call from SKR_FUSED_MODE): f16x2 (the default: two fp16 pieces per operand
-    behind a guard, the rows it rejects recomputed by bf16x3), bf16x3 (16-item steps on the 16x16x32 bf16 MFMA), bf16x3s /
-    bf16x3w (the older kernels forced: one tile ring per workgroup / a ring per wavefront), fp32"""
+    """the arithmetics of skr_eval_fused_topk (read per call from SKR_FUSED_MODE): f16x2 (the default: two fp16 pieces per operand
+    behind a guard, the rows it rejects recomputed by bf16x3), bf16x3 (three bf16 pieces, no condition on the operands), fp32"""
     monkeypatch.setenv("SKR_FUSED_MODE", request.param)
     return request.param
