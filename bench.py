@@ -131,6 +131,8 @@ def lightgcn_leg(args, world, rank, dev, dist, full, K, W, cpu_baseline):
     need = (W + K + 8) * gb
     if world == 1 and args.large_batches:
         need = max(need, 4 * max(int(x) for x in args.large_batches.split(",") if x))
+    if world == 1 and not getattr(args, "no_layergcn", False):
+        need = max(need, (3 + max(3, min(K, 10))) * 2048)          # the LayerGCN steps at the end of the leg
     end_user = min(int(torch.searchsorted(full["rowptr"], torch.tensor(need, device=dev))) + 1, nU)
     nnz = int(full["rowptr"][end_user])
     assert nnz >= need, "dataset too small for the LightGCN leg"
@@ -245,6 +247,35 @@ def lightgcn_leg(args, world, rank, dev, dist, full, K, W, cpu_baseline):
                     "note": "steps per epoch x the measured time per step (every step is the same full-graph work)"}
     del eng
     torch.cuda.empty_cache()
+    # LayerGCN on the same graph, the reference's defaults (LayerGCN.py:25-33: 4 layers, batch 2048, reg 1e-2,
+    # dropout 0): full-graph propagation with the cosine layer refinement, forward and backward per mini-batch, dense Adam
+    if world == 1 and not getattr(args, "no_layergcn", False):
+        from skrec.parallel import ShardedLayerGCN
+        bl_, Kl, Wl = 2048, max(3, min(K, 10)), 3
+        if (Kl + Wl) * bl_ <= nnz:
+            item0_l = (torch.rand(nI, D, generator=torch.Generator().manual_seed(8)) * 2 - 1) * (6.0 / (nI + D)) ** 0.5
+            eng_l = ShardedLayerGCN(ctx, full["users"].long(), full["items"].long(), nU, nI, user0, item0_l, 4, 1e-3, 1e-2, device=dev)
+            sampler.sample_epoch_exact(nI, end_user, rp, cols_src[1], nnz, 1, neg)
+            uu_l, ii_l, jj_l = _hip.shuffle_gather(cols_src, None, seed=4242, n_out=(Kl + Wl) * bl_)
+
+            def run_layer(lo, hi):
+                for s_ in range(lo, hi):
+                    sl = slice(s_ * bl_, (s_ + 1) * bl_)
+                    eng_l.train_step(uu_l[sl], ii_l[sl], jj_l[sl])
+            run_layer(0, Wl)
+            barrier()
+            t0 = time.perf_counter()
+            run_layer(Wl, Wl + Kl)
+            barrier()
+            dtl = time.perf_counter() - t0
+            leg["layergcn"] = {"value": Kl * bl_ / dtl, "unit": "train interactions/s", "steps": Kl, "warmup": Wl, "global_batch": bl_,
+                               "ms_per_step": dtl / Kl * 1e3,
+                               "config": {"workload": "LayerGCN 4-layer d=64 on the same graph, batch 2048, reg 1e-2, dropout 0 (the reference's "
+                                                      "defaults): full-graph propagation + cosine layer refinement fwd+bwd per mini-batch, "
+                                                      "dense Adam"},
+                               "loss": [float(x) for x in eng_l.loss.tolist()]}
+            del eng_l
+            torch.cuda.empty_cache()
     return leg
 
 
@@ -914,6 +945,7 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the same job (global batch = --batch) on more GPUs; weak = --batch per GPU")
     ap.add_argument("--no-lightgcn", action="store_true", help="skip the secondary LightGCN leg")
+    ap.add_argument("--no-layergcn", action="store_true", help="skip the LayerGCN steps at the end of the LightGCN leg")
     ap.add_argument("--lightgcn-steps", type=int, default=10)
     ap.add_argument("--lightgcn-warmup", type=int, default=2)
     ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are run this many times (fresh slices of the epoch each "

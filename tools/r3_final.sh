@@ -12,7 +12,7 @@ r = d["roofline"]; print("roofline", r["frac"], r["avg_launch_ms"], r["traffic"]
 r = d["roofline_step"]; print("step", r["avg_launch_us"], r["alone"]["avg_launch_us"], r["traffic"])
 print("large", {k: (v["value"], v["form"]) for k, v in d.get("large_batch", {}).items()})
 print("eval", d.get("eval", {}).get("users_per_sec"), d.get("roofline_eval", {}).get("frac"))
-lg = d.get("lightgcn", {}); print("lightgcn", lg.get("ms_per_step"), lg.get("roofline", {}).get("avg_launch_ms"), {k: v["ms_per_step"] for k, v in lg.get("large_batch", {}).items()})
+lg = d.get("lightgcn", {}); print("lightgcn", lg.get("ms_per_step"), lg.get("roofline", {}).get("avg_launch_ms"), {k: v["ms_per_step"] for k, v in lg.get("large_batch", {}).items()}, "layergcn", lg.get("layergcn", {}).get("ms_per_step"))
 g = d.get("gru4rec", {}); print("gru", g.get("ms_per_step"), g.get("value"))
 PY
 env -u WORLD_SIZE -u RANK -u LOCAL_RANK SKR_DIST_BACKEND=gloo timeout -k 10 900 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-epoch > gpurun_out/r3_bench_n2_gloo.json 2> gpurun_out/r3_bench_n2_gloo.err; echo "n2 exit $?"
