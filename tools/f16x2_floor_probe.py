@@ -34,4 +34,4 @@ for e in (8, 12, 16, 18, 20, 22, 24):
     S = scale_of(np.abs(U).max()) * scale_of(np.abs(V).max())
     err = np.abs(sc - exact)
     print(f"small items 2^-{e}: max |error| = {err.max() * S / 2.0 ** -3:.3g} floors, {(err / np.abs(exact)).max():.3g} of the score; "
-          f"scores * S = 2^{np.log2(np.abs(exact).min() * S):.1f} .. 2^{np.log2(np.abs(exact).max() * S):.1f} (guard: 2^21)")
+          f"scores * S = 2^{np.log2(np.abs(exact).min() * S):.1f} .. 2^{np.log2(np.abs(exact).max() * S):.1f} (guard: 2^19)")
