@@ -1,5 +1,7 @@
 """GPU parity, E rows: skr_eval_scores (drop-in for cpp_evaluate_matrix), skr_rank_metrics,
 skr_eval_fused_topk and the RankingEvaluator host mirror, against the oracle and the golden vectors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,7 @@ from helpers import lists_from_csr, random_csr
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
 ALL = [1, 2, 3, 4, 5]
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_eval_scores_golden_cases(golden):
@@ -387,3 +390,16 @@ def test_f16x2_guard_hands_rows_it_cannot_vouch_for_to_bf16x3(monkeypatch):
     V2[5, 3] = np.inf
     fused_topk(np.abs(U), np.arange(B, dtype=np.int32), V2, None, None, np.zeros(0, np.int32), K)
     assert _rejected() == B
+
+
+def test_fused_default_arithmetic_on_random_cases():
+    """tools/f16x2_stress.py, 30 cases: random shapes, top_k 1..128, scales over seven decades, rows and elements of mixed magnitude,
+    bias, train masks -- in the evaluator's DEFAULT arithmetic (SKR_FUSED_MODE unset): scores within 1e-6 of float64's relative to
+    sum |u v| + |bias|, no masked item returned, id lists equal to float64's wherever every rank gap is clear of the noise"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("f16x2_stress", os.path.join(REPO, "tools", "f16x2_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n_rows, n_id_rows, worst, n_rej = mod.run(30, seed=7, verbose=False)
+    assert n_id_rows > 0.6 * n_rows and worst < 1e-6
+    assert 0 < n_rej < n_rows          # both the guarded kernel and its fall-back were exercised
