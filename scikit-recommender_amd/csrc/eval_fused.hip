@@ -1442,7 +1442,6 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     // rule above lands just beyond that step and pays for it (top-40 on 262 144 users: 14.7 ms at 150, 13.5 at 112-120)
     if (trig_env <= 0 && a.trigger > 120 && a.trigger < 190) a.trigger = 120;
     if (a.trigger < top_k) a.trigger = top_k;
-    if (a.trigger > a.cap - FE_TI) a.trigger = a.cap - FE_TI;
     static const int ablate = [] { const char* e = getenv("SKR_FUSED_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate;
     const int64_t waves = (static_cast<int64_t>(B) + FE_UW - 1) / FE_UW;
@@ -1455,6 +1454,13 @@ int skr_eval_fused_topk(const float* d_user_table, const int32_t* d_users, int B
     SKR_REQUIRE(mode == "fp32" || mode == "bf16x3" || mode == "f16x2",
                 "SKR_FUSED_MODE must be 'f16x2', 'bf16x3' or 'fp32' (got '%s')", mode_env);
     const bool mode_split = mode != "fp32";
+    // a list must hold what one step can add on top of the trigger: 32 entries per user in the fp32 kernel (tiles of 32
+    // items), 16 in the split kernels (groups of 16) -- at large top_k, where the rule above asks for more than fits, the
+    // split kernels compact that much later
+    {
+        const int step_items = mode_split ? F6_GI : FE_TI;
+        if (a.trigger > a.cap - step_items) a.trigger = a.cap - step_items;
+    }
     if (mode_split) {
         // library-owned scratch for the split item table (38 MB at 100 k items), grown on demand
         static uint4* frag_buf = nullptr;
