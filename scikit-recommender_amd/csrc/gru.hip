@@ -154,6 +154,94 @@ __global__ __launch_bounds__(G_T) void gru_fwd_kernel(GruIn g, const uint8_t* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward for a TRAINING batch at the benchmarked shape (in_dim = hid = 128, a few hundred sessions): gru_fwd_kernel's thread
+// walks all 256 k of its column -- sixteen batches of 32 weight loads one behind the other, ~1.2 us of L2 latency each: 22 us
+// for 25 MFLOP.  Here 1 024 threads share the same 4 rows: the k range is cut in four (gates: 256 columns x 4 segments of
+// 64 k) and eight (candidate: 128 columns x 8 segments of 32 k), every thread has two / one batch in flight, and the partial
+// sums meet in LDS, added in segment order (a fixed order: results are reproducible; they differ from gru_fwd_kernel's
+// k-ascending chain in the last bits).
+// ------------------------------------------------------------------------------------------------
+constexpr int GS_T = 1024, GS_ROWS = 4, GS_H = 128, GS_K = 256;
+__global__ __launch_bounds__(GS_T) void gru_fwd_split_kernel(GruIn g, const uint8_t* __restrict__ active,
+                                                             const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                             const float* __restrict__ Wc, const float* __restrict__ bc, int act,
+                                                             float* __restrict__ r_out, float* __restrict__ u_out,
+                                                             float* __restrict__ c_out, float* __restrict__ h_new) {
+    __shared__ float a[GS_ROWS][GS_K];            // [x | h], later [x | r*h]
+    __shared__ float ho[GS_ROWS][GS_H];           // the old state
+    __shared__ float us[GS_ROWS][GS_H];
+    __shared__ float part[8][GS_ROWS][GS_K];      // partial sums: 4 segments x 256 columns, then 8 x 128 (32 KB)
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * GS_ROWS;
+    {
+        const int r = tid >> 8, k = tid & 255, row = row0 + r;
+        float v = 0.0f;
+        if (row < g.B) v = (k < GS_H) ? x_row(g, row)[k] : g.h[static_cast<int64_t>(row) * GS_H + (k - GS_H)];
+        a[r][k] = v;
+        if (k >= GS_H) ho[r][k - GS_H] = v;
+    }
+    __syncthreads();
+    {   // gates: column j of 256, k segment ks of 4
+        const int j = tid & 255, ks = tid >> 8, k0 = ks * 64;
+        float acc[GS_ROWS] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float w[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) w[q] = Wg[static_cast<int64_t>(k0 + 32 * c + q) * (2 * GS_H) + j];
+#pragma unroll
+            for (int q = 0; q < 32; ++q)
+#pragma unroll
+                for (int r = 0; r < GS_ROWS; ++r) acc[r] = fmaf(a[r][k0 + 32 * c + q], w[q], acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < GS_ROWS; ++r) part[ks][r][j] = acc[r];
+    }
+    __syncthreads();
+    {   // (row, column) of the gates: the four segments in order, the activation, r*h in place of h
+        const int r = tid >> 8, j = tid & 255, row = row0 + r;
+        const float s = sigmoidf_(((part[0][r][j] + part[1][r][j]) + part[2][r][j]) + part[3][r][j] + bg[j]);
+        if (j < GS_H) {
+            if (r_out && row < g.B) r_out[static_cast<int64_t>(row) * GS_H + j] = s;
+        } else {
+            us[r][j - GS_H] = s;
+            if (u_out && row < g.B) u_out[static_cast<int64_t>(row) * GS_H + (j - GS_H)] = s;
+        }
+        __syncthreads();                       // every thread has read its partial sums and the old h before they are replaced
+        if (j < GS_H) a[r][GS_H + j] = s * ho[r][j];
+    }
+    __syncthreads();
+    {   // candidate: column j of 128, k segment ks of 8 (segments 0..3: x, 4..7: r*h)
+        const int j = tid & 127, ks = tid >> 7, k0 = ks * 32;
+        float acc[GS_ROWS] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float w[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) w[q] = Wc[static_cast<int64_t>(k0 + q) * GS_H + j];
+#pragma unroll
+        for (int q = 0; q < 32; ++q)
+#pragma unroll
+            for (int r = 0; r < GS_ROWS; ++r) acc[r] = fmaf(a[r][k0 + q], w[q], acc[r]);
+#pragma unroll
+        for (int r = 0; r < GS_ROWS; ++r) part[ks][r][j] = acc[r];
+    }
+    __syncthreads();
+    if (tid < GS_ROWS * GS_H) {
+        const int r = tid >> 7, j = tid & 127, row = row0 + r;
+        if (row < g.B) {
+            float sum = part[0][r][j];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) sum += part[q][r][j];
+            const float c = hidden_act(sum + bc[j], act);
+            const float u = us[r][j];
+            float hn = u * ho[r][j] + (1.0f - u) * c;
+            if (active && !active[row]) hn = ho[r][j];        // finished history: the state is carried
+            if (c_out) c_out[static_cast<int64_t>(row) * GS_H + j] = c;
+            h_new[static_cast<int64_t>(row) * GS_H + j] = hn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward for MANY sessions (the inference sweep `_get_user_embeddings`, GRU4RecPlus.py:256-302, advances every user at
 // once): the two products [x, h] Wg and [x, r*h] Wc on the matrix cores, v_mfma_f32_32x32x2_f32 (fp32 operands, fp32
 // accumulation).  A workgroup takes 32 sessions: their [x, h] rows sit in LDS (row stride K + 1: the 32 rows of a column then
@@ -763,7 +851,15 @@ int skr_gru_cell_fwd(const float* d_x, const int32_t* d_x_index, const float* d_
         else
             hipLaunchKernelGGL(gru_fwd_mfma_kernel<128>, grid, wg, 0, skr::as_stream(stream), g, d_active, d_Wg, d_bg, d_Wc, d_bc,
                                hidden_act_kind, d_r, d_u, d_c, d_h_new);
-    } else if (B <= G_SMALL_B) by_hid(std::integral_constant<int, 4>{}); else by_hid(std::integral_constant<int, G_ROWS>{});
+    } else if (B <= G_SMALL_B) {
+        // SKR_GRU_SPLIT=0 keeps gru_fwd_kernel at the benchmarked shape too
+        static const bool split = [] { const char* e = getenv("SKR_GRU_SPLIT"); return !(e && atoi(e) == 0); }();
+        if (split && in_dim == GS_H && hid == GS_H)
+            hipLaunchKernelGGL(gru_fwd_split_kernel, dim3((B + GS_ROWS - 1) / GS_ROWS), dim3(GS_T), 0, skr::as_stream(stream), g, d_active,
+                               d_Wg, d_bg, d_Wc, d_bc, hidden_act_kind, d_r, d_u, d_c, d_h_new);
+        else
+            by_hid(std::integral_constant<int, 4>{});
+    } else by_hid(std::integral_constant<int, G_ROWS>{});
     SKR_LAUNCH_CHECK();
     return SKR_OK;
 }
