@@ -391,8 +391,10 @@ __device__ __forceinline__ float reduce16(float (&v)[16], int lane) {
 // The two products with TRANSPOSED weights are taken a weight row per wavefront, lanes along the row (coalesced reads, 16 / ROWS
 // rows in flight), partial products of all ROWS sessions reduced across the lanes by reduce16.  (A thread per (session,
 // output) walking along its weight row reads 64 different cache lines per wave instruction: 31 us per call at B = 128.)
-template <int ROWS, int H>
-__global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float* __restrict__ Wg,
+// T threads: 256, or (a training batch: few workgroups, each wavefront walking its weight rows one group behind the other) 1 024 --
+// sixteen wavefronts share the same 4 rows and take a quarter of the weight rows each
+template <int ROWS, int H, int T = G_T>
+__global__ __launch_bounds__(T) void gru_bwd_rows_kernel(GruIn g, const float* __restrict__ Wg,
                                                            const float* __restrict__ Wc, int act,
                                                            const float* __restrict__ r_in, const float* __restrict__ u_in,
                                                            const float* __restrict__ c_in, const float* __restrict__ dh_new,
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float*
     const int tid = threadIdx.x;
     const int IN = g.in_dim;
     const int row0 = blockIdx.x * ROWS;
-    for (int idx = tid; idx < ROWS * H; idx += G_T) {
+    for (int idx = tid; idx < ROWS * H; idx += T) {
         const int r = idx / H, j = idx - r * H, row = row0 + r;
         float vdc = 0.0f, vdu = 0.0f, vh = 0.0f, vr = 0.0f;
         if (row < g.B) {
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float*
     constexpr int QN = 16 / ROWS;                      // weight rows per reduction group (ROWS is 4 or 16)
     constexpr int EH = (H + 63) / 64, EG = (2 * H + 63) / 64;
     const int vq = ((lane >> 2) & 15) / ROWS, vr_ = ((lane >> 2) & 15) % ROWS;     // the value this lane ends up holding
-    for (int k0 = wv * QN; k0 < H; k0 += (G_T / 64) * QN) {      // d(rh) = dc~ Wc[in:, :]^T ; dr~ = d(rh) h r (1 - r)
+    for (int k0 = wv * QN; k0 < H; k0 += (T / 64) * QN) {      // d(rh) = dc~ Wc[in:, :]^T ; dr~ = d(rh) h r (1 - r)
         float v[16];
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float*
         }
     }
     __syncthreads();
-    for (int i0 = wv * QN; i0 < IN; i0 += (G_T / 64) * QN) {      // dx = dc~ Wc[:in, :]^T + [dr~ | du~] Wg[:in, :]^T
+    for (int i0 = wv * QN; i0 < IN; i0 += (T / 64) * QN) {      // dx = dc~ Wc[:in, :]^T + [dr~ | du~] Wg[:in, :]^T
         float v[16];
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(G_T) void gru_bwd_rows_kernel(GruIn g, const float*
         const int i = i0 + vq, row = row0 + vr_;
         if ((lane & 3) == 0 && i < IN && row < g.B) dx_out[static_cast<int64_t>(row) * IN + i] = total;
     }
-    for (int idx = tid; idx < ROWS * H; idx += G_T) {
+    for (int idx = tid; idx < ROWS * H; idx += T) {
         const int r = idx / H, j = idx - r * H, row = row0 + r;
         if (row >= g.B) continue;
         dcp_out[static_cast<int64_t>(row) * H + j] = dcp[r][j];
@@ -878,10 +880,15 @@ int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_
     GruIn g{d_x, d_x_index, d_h, B, in_dim, hid};
     float* dcp = d_work;                                   // [B, hid]
     float* dgp = d_work + static_cast<int64_t>(B) * hid;   // [B, 2 hid]
+    static const bool wide = [] { const char* e = getenv("SKR_GRU_SPLIT"); return !(e && atoi(e) == 0); }();
     auto rows = [&](auto rows_c, auto hid_c) {
         constexpr int R = decltype(rows_c)::value, HH = decltype(hid_c)::value;
-        hipLaunchKernelGGL((gru_bwd_rows_kernel<R, HH>), dim3((B + R - 1) / R), dim3(G_T), 0, st, g, d_Wg, d_Wc, hidden_act_kind, d_r,
-                           d_u, d_c, d_dh_new, dcp, dgp, d_dx);
+        if (R == 4 && wide)
+            hipLaunchKernelGGL((gru_bwd_rows_kernel<R, HH, 1024>), dim3((B + R - 1) / R), dim3(1024), 0, st, g, d_Wg, d_Wc, hidden_act_kind,
+                               d_r, d_u, d_c, d_dh_new, dcp, dgp, d_dx);
+        else
+            hipLaunchKernelGGL((gru_bwd_rows_kernel<R, HH>), dim3((B + R - 1) / R), dim3(G_T), 0, st, g, d_Wg, d_Wc, hidden_act_kind, d_r,
+                               d_u, d_c, d_dh_new, dcp, dgp, d_dx);
     };
     auto by_hid = [&](auto rows_c) {
         if (hid == 32) rows(rows_c, std::integral_constant<int, 32>{});
