@@ -1,4 +1,4 @@
-"""CPU suite, part 4: the N > 1 path of bench.py on two gloo ranks -- user sharding u % N, the
+"""CPU suite, part 4: the N > 1 path of bench.py on two, three and four gloo ranks -- user sharding u % N, the
 re-indexing of the shard's CSR, and the one exchange step (all-reduce of the replicated item
 table's gradient) reproduce the single-process gradients.  Kernels are replaced by the oracle's
 explicit-gradient maths here (no GPU); the collective and the sharding code are the real ones."""
@@ -60,8 +60,13 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process():
-    world, port = 2, _free_port()
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_step_equals_single_process(world):
+    """two ranks, and -- users 40 do not divide by 3: ragged shards -- three and four"""
+    port = _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
@@ -80,7 +85,8 @@ def test_two_rank_step_equals_single_process():
     for r in range(world):
         np.testing.assert_allclose(res[r][2], want_item, rtol=1e-5, atol=1e-7)      # replicas agree
         np.testing.assert_allclose(res[r][1], gU[res[r][0]], rtol=1e-5, atol=1e-7)  # user rows are local
-    assert np.array_equal(res[0][2], res[1][2])                                       # bit-identical replicas
+    for r in range(1, world):
+        assert np.array_equal(res[0][2], res[r][2])                                   # bit-identical replicas
 
 
 def test_fast_sampler_twin_is_shard_invariant():
