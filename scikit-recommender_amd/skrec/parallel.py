@@ -97,6 +97,12 @@ def init_from_env():
     return DistContext(rank, world)
 
 
+def _pipelined():
+    """several ranks: the next item-side partial product is queued before the wait for the current exchange (default);
+    SKR_DIST_PIPELINE=0 keeps the products of a layer behind that layer's exchange (for A / B runs on a real node)"""
+    return os.environ.get("SKR_DIST_PIPELINE", "1") != "0"
+
+
 def unique_padded_rows(ids):
     """[S, C] integer ids -> int32 [S, C]: every row's distinct non-negative ids in ascending order, then -1 (an empty
     slot of skr_pack_grad_rows) -- the layout skr_unpack_grad_rows_sorted needs"""
@@ -216,36 +222,56 @@ class ShardedLightGCN(object):
         xu, xi = self.ego[:nl], self.ego[nl:]
         if active:      # the item half of the mean starts from its E0 term; the user half gets it in the first product's epilogue
             _hip.check(_hip.lib().skr_scale_copy(scale, _hip.ptr(xi), _hip.ptr(fi), xi.numel(), _hip.stream()))
+        pipelined = _pipelined()
+        ni = mi = None
         for k in range(K):
-            nu, ni = self._xu[k & 1], self._xi[k & 1]
-            mu, mi = last_rows if (last_rows is not None and k == K - 1) else (None, None)
+            nu = self._xu[k & 1]
+            mu = last_rows[0] if (last_rows is not None and k == K - 1) else None
             au, ai = last_rows if last_rows is not None else (None, None)    # the mean is only needed on the rows that are read
             base_u, base_i = (self.ego[:nl], self.ego[nl:]) if k == 0 else (None, None)
             if not active:
                 # one rank: nothing is exchanged, so the layer mean (with its E0 term) rides in both products' row epilogues
+                ni, mi = self._xi[k & 1], (last_rows[1] if (last_rows is not None and k == K - 1) else None)
                 self.a_iu.spmm(xu, ni, accum=fi, accum_scale=scale, accum_base=base_i, row_mask=mi, accum_mask=ai)
                 self.a_ui.spmm(xi, nu, accum=fu, accum_scale=scale, accum_base=base_u, row_mask=mu, accum_mask=au)
                 xu, xi = nu, ni
                 continue
-            if mi is not None:
-                ni.zero_()                                                # rows that are skipped must not carry old sums
-            self.a_iu.spmm(xu, ni, row_mask=mi)                                # partial items <- local users
-            # the exchange step of this layer, beside the user-side product.  In the masked last layer only the GLOBAL
-            # batch's item rows carry anything: they travel as a compact [2 * batch, 64] block instead of the [I, 64] one
+            # several ranks, software-pipelined (SKR_DIST_PIPELINE=0: layer by layer): layer k's exchange runs beside the
+            # user-side product of layer k AND the item-side partial product of layer k + 1 -- that one only needs the user
+            # rows the user-side product has just written, not the summed item rows -- so a layer's critical path is
+            # max(exchange, both products) instead of item product + max(exchange, user product).  Same launches on the
+            # same operands, hence the same bits.
+            if k == 0 or not pipelined:
+                ni, mi = self._item_partial(k, xu, last_rows)
             compact = self._batch_item_ids if mi is not None else None
+            # In the masked last layer only the GLOBAL batch's item rows carry anything: they travel as a compact
+            # [2 * batch, 64] block instead of the [I, 64] one
             if compact is not None:
                 work = self._rows_exchange_begin(ni, compact)
             else:
                 work = self.ctx.all_reduce_begin(ni)
             self.a_ui.spmm(xi, nu, accum=fu, accum_scale=scale, accum_base=base_u, row_mask=mu, accum_mask=au)   # local users <- replicated items
+            ahead = self._item_partial(k + 1, nu, last_rows) if (pipelined and k + 1 < K) else None
             if compact is not None:
                 self._rows_exchange_end(work, compact, ni)
             else:
                 self.ctx.all_reduce_end(work)
             self._axpy(scale, ni, fi)
             xu, xi = nu, ni
+            if ahead is not None:
+                ni, mi = ahead
         self._final_whole = last_rows is None
         return self.final
+
+    def _item_partial(self, k, xu, last_rows):
+        """this rank's part of layer k's item rows <- its users' rows ``xu`` (the summands of the layer's exchange); in the
+        masked last layer only the batch's rows.  Returns (buffer, row mask)."""
+        ni = self._xi[k & 1]
+        mi = last_rows[1] if (last_rows is not None and k == self.n_layers - 1) else None
+        if mi is not None:
+            ni.zero_()                                                    # rows that are skipped must not carry old sums
+        self.a_iu.spmm(xu, ni, row_mask=mi)
+        return ni, mi
 
     def _batch_rows(self, users, pos, neg, grad_rows=None):
         """(uint8 [n_local], uint8 [I]) for a GLOBAL batch (global user ids): the rows it touches -- this rank's users,
@@ -342,18 +368,34 @@ class ShardedLightGCN(object):
         gu, gi = hu, hi
         gEu, gEi = gE[:nl], gE[nl:]
         hm_u, hm_i = masks if masks is not None else (None, None)      # H is zero outside the batch's rows
+        scatter_ok = os.environ.get("SKR_FIRST_HOP_SCATTER", "1") != "0"
+
+        def item_hop(k, gu_k):
+            """several ranks: this rank's part of hop k's item rows (the summands of the hop's exchange)"""
+            ni = self._gi[k & 1]
+            cu = masks[0] if (masks is not None and k == 0) else None
+            if cu is not None and k != K - 1 and scatter_ok:
+                ni.zero_()
+                self.a_ui.scatter_marked_rows(cu, gu_k, ni)
+            else:
+                self.a_iu.spmm(gu_k, ni, col_mask=cu)
+            if k == K - 1:
+                self._axpy(1.0, gEi, ni)           # this rank's regulariser part of the item gradient
+            return ni
+        pipelined = _pipelined()
+        ni = None
         for k in range(K):
             last = (k == K - 1)
-            nu, ni = self._gu[k & 1], self._gi[k & 1]
+            nu = self._gu[k & 1]
             cu, ci = masks if (masks is not None and k == 0) else (None, None)
             # The item side of the FIRST hop multiplies dL/dE-bar's user rows, which are zero outside the batch's <= batch users:
             # instead of every item row scanning its users for marked ones, the batch users' own rows of the user-side block
             # (the same non-zeros) are walked and scattered -- ~50 k entries instead of 48 M looked at
-            transposed = cu is not None and not last and os.environ.get("SKR_FIRST_HOP_SCATTER", "1") != "0"
             if not active:
                 # one rank: g_{k+1} = A g_k + H in both epilogues; the last hop adds into the ego gradient (which holds the
                 # regulariser's part) directly
-                if transposed:
+                ni = self._gi[k & 1]
+                if cu is not None and not last and scatter_ok:
                     ni.copy_(hi)
                     self.a_ui.scatter_marked_rows(cu, gu, ni)
                 else:
@@ -361,18 +403,18 @@ class ShardedLightGCN(object):
                 self.a_ui.spmm(gi, nu, addend=hu, accum=gEu if last else None, accum_scale=1.0, col_mask=ci, addend_mask=hm_u)
                 gu, gi = nu, ni
                 continue
-            if transposed:
-                ni.zero_()
-                self.a_ui.scatter_marked_rows(cu, gu, ni)
-            else:
-                self.a_iu.spmm(gu, ni, col_mask=cu)
-            if last:
-                self._axpy(1.0, gEi, ni)           # this rank's regulariser part of the item gradient
+            # several ranks, software-pipelined as the forward pass: hop k's exchange runs beside its user-side product and
+            # the item-side partial product of hop k + 1 (which needs only the user rows just written)
+            if k == 0 or not pipelined:
+                ni = item_hop(k, gu)
             work = self.ctx.all_reduce_begin(ni)   # summed over the ranks beside the user-side product of the same hop
             self.a_ui.spmm(gi, nu, addend=hu, accum=gEu if last else None, accum_scale=1.0, col_mask=ci, addend_mask=hm_u)
+            ahead = item_hop(k + 1, nu) if (pipelined and not last) else None
             self.ctx.all_reduce_end(work)
             self._axpy(1.0, hi, ni)
             gu, gi = nu, ni
+            if ahead is not None:
+                ni = ahead
         if active:
             gEi.copy_(gi)                          # identical on every rank -> identical Adam update
         self.optimizer.step()
@@ -456,6 +498,7 @@ class ShardedLayerGCN(object):
         active = self.ctx.active
         x = self.ego
         K = self.n_layers
+        pipelined = _pipelined()
         for k in range(K):
             y, zk, wk = self._y[k], self._z[k & 1], self._w[k]
             mu, mi = last_rows if (last_rows is not None and k == K - 1) else (None, None)
@@ -469,8 +512,11 @@ class ShardedLayerGCN(object):
                           refine_fwd=(self.ego[:nl], wk[:nl], zk[:nl]), accum_mask=au)
                 x = zk
                 continue
-            a_iu.spmm(x[:nl], y[nl:], row_mask=mi)                # partial items <- local users
-            # the exchange of this layer runs beside the user-side product (whose refinement rides in its row epilogue)
+            # several ranks, software-pipelined (as ShardedLightGCN.propagate): layer k's exchange runs beside the user-side
+            # product of layer k (whose refinement rides in its row epilogue) and the item-side partial product of layer
+            # k + 1, which reads only the user rows of z_k that epilogue has just written
+            if k == 0 or not pipelined:
+                a_iu.spmm(x[:nl], y[nl:], row_mask=mi)            # partial items <- local users
             compact = self._batch_item_ids if mi is not None else None
             if compact is not None:
                 work = ShardedLightGCN._rows_exchange_begin(self, y[nl:], compact)
@@ -478,6 +524,9 @@ class ShardedLayerGCN(object):
                 work = self.ctx.all_reduce_begin(y[nl:])
             a_ui.spmm(x[nl:], y[:nl], row_mask=mu, accum=self.out[:nl], accum_init=first,
                       refine_fwd=(self.ego[:nl], wk[:nl], zk[:nl]), accum_mask=au)
+            if pipelined and k + 1 < K:
+                mi_next = last_rows[1] if (last_rows is not None and k + 1 == K - 1) else None
+                a_iu.spmm(zk[:nl], self._y[k + 1][nl:], row_mask=mi_next)
             if compact is not None:
                 ShardedLightGCN._rows_exchange_end(self, work, compact, y[nl:])
             else:
@@ -546,6 +595,20 @@ class ShardedLayerGCN(object):
                                                  _hip.ptr(dy[:nl]), _hip.ptr(gE[:nl]), _hip.ptr(mk_u), zs, st))
         _hip.check(L.skr_layer_refine_bwd_masked(_hip.ptr(yK[nl:]), _hip.ptr(self.ego[nl:]), _hip.ptr(wK[nl:]), _hip.ptr(gO[nl:]),
                                                  self.num_items, 64, _hip.ptr(dy[nl:]), _hip.ptr(gE[nl:]), _hip.ptr(mk_i), zs, st))
+        scatter_ok = os.environ.get("SKR_FIRST_HOP_SCATTER", "1") != "0"
+        pipelined = _pipelined()
+
+        def item_hop(k, dyu, slot):
+            """several ranks: this rank's part of hop k's item rows <- its users' rows of dY (the summands of the hop's exchange)"""
+            t = self._tmp_items(slot)
+            cu = masks[0] if (masks is not None and k == K - 1) else None
+            if cu is not None and k > 0 and scatter_ok:
+                t.zero_()
+                a_ui.scatter_marked_rows(cu, dyu, t)
+            else:
+                a_iu.spmm(dyu, t, col_mask=cu)
+            return t
+        tmp_i = None           # several ranks: the hop's item-side partial sums when they were queued ahead
         for k in range(K - 1, -1, -1):
             cu, ci = masks if (masks is not None and k == K - 1) else (None, None)
             if k > 0:
@@ -554,48 +617,51 @@ class ShardedLayerGCN(object):
                 rb_i = (self.ego[nl:], wb[nl:], yb[nl:], gE[nl:])
                 # (the item side of the FIRST hop -- dY_K's user rows are zero outside the batch's users: the batch users' own rows
                 #  are scattered instead of every item row scanning its users, as in ShardedLightGCN.train_step)
-                transposed = cu is not None and os.environ.get("SKR_FIRST_HOP_SCATTER", "1") != "0"
+                transposed = cu is not None and scatter_ok
                 if not active:
                     if transposed:
-                        tmp_i = self._tmp_items()
-                        tmp_i.copy_(gO[nl:])
-                        a_ui.scatter_marked_rows(cu, dy[:nl], tmp_i)
-                        _hip.check(L.skr_layer_refine_bwd(_hip.ptr(yb[nl:]), _hip.ptr(self.ego[nl:]), _hip.ptr(wb[nl:]), _hip.ptr(tmp_i),
+                        t1 = self._tmp_items()
+                        t1.copy_(gO[nl:])
+                        a_ui.scatter_marked_rows(cu, dy[:nl], t1)
+                        _hip.check(L.skr_layer_refine_bwd(_hip.ptr(yb[nl:]), _hip.ptr(self.ego[nl:]), _hip.ptr(wb[nl:]), _hip.ptr(t1),
                                                           self.num_items, 64, _hip.ptr(nxt[nl:]), _hip.ptr(gE[nl:]), st))
                     else:
                         a_iu.spmm(dy[:nl], nxt[nl:], addend=gO[nl:], col_mask=cu, refine_bwd=rb_i, addend_mask=mk_i)
                     a_ui.spmm(dy[nl:], nxt[:nl], addend=gO[:nl], col_mask=ci, refine_bwd=rb_u, addend_mask=mk_u)
                 else:
-                    tmp_i = self._tmp_items()
-                    if transposed:
-                        tmp_i.zero_()
-                        a_ui.scatter_marked_rows(cu, dy[:nl], tmp_i)
-                    else:
-                        a_iu.spmm(dy[:nl], tmp_i, col_mask=cu)     # item side first, its exchange beside the user side
+                    # several ranks, software-pipelined: the item side first, its exchange beside the user side AND beside the
+                    # item-side partial product of the hop below, which reads only the user rows that product has just written
+                    if tmp_i is None:
+                        tmp_i = item_hop(k, dy[:nl], k & 1)
                     work = self.ctx.all_reduce_begin(tmp_i)
                     a_ui.spmm(dy[nl:], nxt[:nl], addend=gO[:nl], col_mask=ci, refine_bwd=rb_u, addend_mask=mk_u)
+                    ahead = item_hop(k - 1, nxt[:nl], (k - 1) & 1) if pipelined else None
                     self.ctx.all_reduce_end(work)
                     self._axpy(1.0, gO[nl:], tmp_i)
                     _hip.check(L.skr_layer_refine_bwd(_hip.ptr(yb[nl:]), _hip.ptr(self.ego[nl:]), _hip.ptr(wb[nl:]), _hip.ptr(tmp_i),
                                                       self.num_items, 64, _hip.ptr(nxt[nl:]), _hip.ptr(gE[nl:]), st))
+                    tmp_i = ahead
                 dy, nxt = nxt, dy
             else:
                 if not active:
                     a_iu.spmm(dy[:nl], None, accum=gE[nl:], accum_scale=1.0, col_mask=cu)
                     a_ui.spmm(dy[nl:], None, accum=gE[:nl], accum_scale=1.0, col_mask=ci)
                 else:
-                    tmp_i = self._tmp_items()
-                    a_iu.spmm(dy[:nl], tmp_i, col_mask=cu)
+                    if tmp_i is None:
+                        tmp_i = item_hop(0, dy[:nl], 0)
                     work = self.ctx.all_reduce_begin(tmp_i)
                     a_ui.spmm(dy[nl:], None, accum=gE[:nl], accum_scale=1.0, col_mask=ci)
                     self.ctx.all_reduce_end(work)
                     self._axpy(1.0, tmp_i, gE[nl:])
         self.optimizer.step()
 
-    def _tmp_items(self):
+    def _tmp_items(self, slot=0):
+        """[I, 64] scratch; two slots, so that a hop's partial sums can be queued while the previous hop's are being exchanged"""
         if getattr(self, "_tmp_i", None) is None:
-            self._tmp_i = torch.zeros((self.num_items, 64), dtype=torch.float32, device=self.device)
-        return self._tmp_i
+            self._tmp_i = [None, None]
+        if self._tmp_i[slot] is None:
+            self._tmp_i[slot] = torch.zeros((self.num_items, 64), dtype=torch.float32, device=self.device)
+        return self._tmp_i[slot]
 
     def gather_user_rows(self, local_rows):
         """[U, 64] on every rank from each rank's [U_local, 64] block"""

@@ -380,3 +380,57 @@ def test_fit_on_a_single_rank_rccl_group(model, tiny_dir, tmp_path, monkeypatch)
             total = r["losses"][:, 0] + np.float32(1e-2) * r["losses"][:, 1]
             np.testing.assert_allclose(total, g["loss"], rtol=1e-5)
             np.testing.assert_allclose(r["V1"], g["V1"], rtol=0, atol=3e-6)
+
+
+def _order_worker(rank, world, port, model, ret):
+    """a few steps of a sharded engine on batches whose rows are all distinct (every gradient row is written once, so nothing
+    depends on the order of float atomics), then an unmasked propagation"""
+    import torch.distributed as dist
+    from skrec.parallel import DistContext, ShardedLayerGCN, ShardedLightGCN
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(GOLDEN, "golden_lightgcn.npz"))
+    U, I = g["U0"].shape[0], g["V0"].shape[0]
+    ctx = DistContext(rank, world)
+    if model == "lightgcn":
+        adj = sp.csr_matrix((g["adj_val"], (g["adj_idx"][0], g["adj_idx"][1])), shape=(U + I, U + I))
+        eng = ShardedLightGCN(ctx, adj, g["U0"], g["V0"], n_layers=3, lr=1e-3, reg=1e-3, batch_size_cfg=32)
+    else:
+        d = np.load(os.path.join(GOLDEN, "tiny_dataset.npz"))
+        pairs = np.unique(d["train"][:, :2].astype(np.int64), axis=0)
+        eng = ShardedLayerGCN(ctx, torch.from_numpy(pairs[:, 0].copy()), torch.from_numpy(pairs[:, 1].copy()), U, I,
+                              g["U0"], g["V0"], n_layers=4, lr=1e-3, reg=1e-2)
+    dev = eng.device
+    rng = np.random.RandomState(5)
+    for _ in range(4):
+        u = rng.permutation(U)[:32].astype(np.int32)
+        i = rng.permutation(I // 2)[:32].astype(np.int32)
+        j = (I // 2 + rng.permutation(I // 2)[:32]).astype(np.int32)
+        eng.train_step(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev), torch.from_numpy(j).to(dev))
+    whole = eng.propagate()
+    ret[rank] = dict(ego=eng.ego.cpu().numpy(), whole=whole.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["lightgcn", "layergcn"])
+def test_pipelined_exchange_order_is_bit_identical(model, monkeypatch):
+    """several ranks: the next item-side partial product queued BEFORE the wait for the current layer's exchange (the default,
+    skrec.parallel._pipelined) runs the same launches on the same operands as the layer-by-layer order (SKR_DIST_PIPELINE=0):
+    same bits, forward and backward, masked layers and compact exchanges included.  (The first hop's scatter adds with
+    float atomics, whose order is not fixed: it is switched off here, and the batches name every row once, so that both
+    runs are deterministic; a repeat of the first run checks that they are.)"""
+    monkeypatch.setenv("SKR_SPMM_PLAN", "1")
+    monkeypatch.setenv("SKR_FIRST_HOP_SCATTER", "0")
+    runs = []
+    for flag in ("1", "1", "0"):
+        monkeypatch.setenv("SKR_DIST_PIPELINE", flag)
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_order_worker, args=(2, _free_port(), model, ret), nprocs=2, join=True)
+            runs.append({k: ret[k] for k in range(2)})
+    for rank in range(2):
+        for key in ("ego", "whole"):
+            assert np.array_equal(runs[0][rank][key], runs[1][rank][key]), ("not deterministic", model, rank, key)
+            assert np.array_equal(runs[0][rank][key], runs[2][rank][key]), (model, rank, key)
+    assert np.isfinite(runs[0][0]["ego"]).all() and not np.array_equal(runs[0][0]["ego"][-96:], np.load(os.path.join(GOLDEN, "golden_lightgcn.npz"))["V0"])
