@@ -72,10 +72,11 @@ class BPRMF(AbstractRecommender):
         # one process per GPU (torchrun): users sharded, item table replicated -- skrec/parallel.py
         from ..parallel import init_from_env, ShardedBPRMF
         self.dist = init_from_env()
-        if self.dist.active and self.config.n_dim != 64:
-            raise NotImplementedError("one process per GPU: the sharded engines are built for n_dim=64")
-        self.engine = ShardedBPRMF(self.dist, U, V, b, self.config.lr, self.config.reg, self.device) if self.dist.active \
-            else None
+        if self.dist.active and self.dp != 64:
+            raise NotImplementedError("one process per GPU: the sharded engines take n_dim <= 64 (rows of 64 floats)")
+        # (narrower embeddings live in zero-padded 64-float rows, as on one GPU)
+        self.engine = ShardedBPRMF(self.dist, pad_columns(U, 64), pad_columns(V, 64), b, self.config.lr, self.config.reg,
+                                   self.device) if self.dist.active else None
         if self.engine is not None:
             self._full_users = None
             return

@@ -94,16 +94,17 @@ class LayerGCN(AbstractRecommender):
         self.step_losses = None
         self.sampler_mode = getattr(run_config, "sampler_mode", None)
         self.engine = None
-        if self.dist.active and cfg.embed_dim != 64:
-            raise NotImplementedError("one process per GPU: the sharded engines are built for embed_dim=64")
+        if self.dist.active and cfg.embed_dim > 64:
+            raise NotImplementedError("one process per GPU: the sharded engines take embed_dim <= 64 (rows of 64 floats)")
         if self.dist.active:
             # user-sharded rows, replicated item rows (skrec/parallel.py); duplicate pairs collapse to one edge
             pairs = np.unique(np.stack([inter.row, inter.col], 1).astype(np.int64), axis=0)
             self._edge_u = torch.from_numpy(pairs[:, 0].copy()).to(self.device)
             self._edge_i = torch.from_numpy(pairs[:, 1].copy()).to(self.device)
             self._edge_values = self._normalize_edges(self._edge_u, self._edge_i)
-            self.engine = ShardedLayerGCN(self.dist, self._edge_u, self._edge_i, self.num_users, self.num_items, ue, ie,
-                                          cfg.n_layers, cfg.lr, cfg.reg, self.device)
+            # narrower embeddings live in zero-padded 64-float rows, as on one GPU (LightGCN.padded_width)
+            self.engine = ShardedLayerGCN(self.dist, self._edge_u, self._edge_i, self.num_users, self.num_items,
+                                          pad_columns(ue, 64), pad_columns(ie, 64), cfg.n_layers, cfg.lr, cfg.reg, self.device)
             self._full_user_out = None
             return
         if inter.nnz >= DEVICE_ADJ_MIN_PAIRS:     # large graph: no scipy pass (same values: float64 degrees, fp32 result)
@@ -132,13 +133,13 @@ class LayerGCN(AbstractRecommender):
     @property
     def user_embeddings(self):
         if self.engine is not None:
-            return self.engine.gather_user_table()
+            return self.engine.gather_user_table()[:, :self.config.embed_dim]
         return self.ego[:self.num_users, :self.config.embed_dim]
 
     @property
     def item_embeddings(self):
         if self.engine is not None:
-            return self.engine.item_rows
+            return self.engine.item_rows[:, :self.config.embed_dim]
         return self.ego[self.num_users:, :self.config.embed_dim]
 
     def _device_adjacency(self, inter):

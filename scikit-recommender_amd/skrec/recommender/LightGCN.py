@@ -333,13 +333,14 @@ class LightGCN(AbstractRecommender):
         self.sampler_mode = getattr(run_config, "sampler_mode", None)
         self.step_losses = None
         if self.dist.active:
-            if self.dp != 64 or cfg.embed_size != 64:
-                raise NotImplementedError("one process per GPU: the sharded engines are built for embed_size=64")
+            if self.dp != 64:
+                raise NotImplementedError("one process per GPU: the sharded engines take embed_size <= 64 (rows of 64 floats)")
             ue, ie = nn.Embedding(self.num_users, cfg.embed_size), nn.Embedding(self.num_items, cfg.embed_size)
             get_initializer("xavier_uniform")(ue.weight)
             get_initializer("xavier_uniform")(ie.weight)
-            self.engine = ShardedLightGCN(self.dist, adj, ue.weight.detach(), ie.weight.detach(), cfg.n_layers, cfg.lr,
-                                          cfg.reg, cfg.batch_size, self.device)
+            # narrower embeddings live in zero-padded 64-float rows, as on one GPU (padded_width)
+            self.engine = ShardedLightGCN(self.dist, adj, pad_columns(ue.weight.detach(), 64), pad_columns(ie.weight.detach(), 64),
+                                          cfg.n_layers, cfg.lr, cfg.reg, cfg.batch_size, self.device)
             self._full_user_final = None
             return
         self.engine = None
@@ -372,13 +373,13 @@ class LightGCN(AbstractRecommender):
     @property
     def user_embeddings(self):
         if self.engine is not None:
-            return self.engine.gather_user_table()
+            return self.engine.gather_user_table()[:, :self.config.embed_size]
         return self.ego[:self.num_users, :self.config.embed_size]
 
     @property
     def item_embeddings(self):
         if self.engine is not None:
-            return self.engine.item_rows
+            return self.engine.item_rows[:, :self.config.embed_size]
         return self.ego[self.num_users:, :self.config.embed_size]
 
     def _load_adj_mat(self, adj_type):

@@ -434,3 +434,75 @@ def test_pipelined_exchange_order_is_bit_identical(model, monkeypatch):
             assert np.array_equal(runs[0][rank][key], runs[1][rank][key]), ("not deterministic", model, rank, key)
             assert np.array_equal(runs[0][rank][key], runs[2][rank][key]), (model, rank, key)
     assert np.isfinite(runs[0][0]["ego"]).all() and not np.array_equal(runs[0][0]["ego"][-96:], np.load(os.path.join(GOLDEN, "golden_lightgcn.npz"))["V0"])
+
+
+def _width_worker(rank, world, port, model, dim, data_dir, workdir, ret):
+    """fit() through the drop-in API at an embedding width below 64, on one process (the one-GPU path) or on `world` gloo ranks"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), SKR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.chdir(workdir)
+    import random
+    from skrec import RunConfig
+    from skrec.utils.py.random import reset_global_sampler
+    reset_global_sampler(2020)
+    np.random.seed(2021); random.seed(2021); torch.manual_seed(2021)
+    rc = RunConfig(recommender=model, data_dir=data_dir, file_column="UIRT", sep="\t",
+                   metric=("Precision", "Recall", "MAP", "NDCG", "MRR"), top_k=(5, 10, 20), test_batch_size=16, seed=2021)
+    if model == "BPRMF":
+        from skrec.recommender.BPRMF import BPRMF
+        m = BPRMF(rc, dict(lr=1e-3, reg=1e-3, n_dim=dim, batch_size=256, epochs=2))
+    elif model == "LightGCN":
+        from skrec.recommender.LightGCN import LightGCN
+        m = LightGCN(rc, dict(lr=1e-3, reg=1e-3, embed_size=dim, n_layers=3, adj_type="pre", batch_size=256, epochs=2))
+    else:
+        from skrec.recommender.LayerGCN import LayerGCN
+        m = LayerGCN(rc, dict(lr=1e-3, reg=1e-2, embed_dim=dim, n_layers=4, dropout=0.0, batch_size=256, epochs=2))
+    assert (m.engine is not None) == (world > 1)
+    reports, losses = [], []
+    ev, te = m.evaluate, m.train_epoch
+
+    def evaluate(test_users=None):
+        r = ev(test_users)
+        reports.append(np.array(list(r.values()), np.float32))
+        return r
+
+    def train_epoch(it):
+        te(it)
+        losses.append(m.step_losses.cpu().numpy().copy())
+    m.evaluate, m.train_epoch = evaluate, train_epoch
+    m.fit()
+    if model == "BPRMF" and world > 1:
+        U1, V1 = m.engine.gather_user_table()[:, :dim], m.engine.item_rows[:, :dim]
+        assert float(m.engine.item_rows[:, dim:].abs().max()) == 0.0      # the padding stays zero
+    else:
+        U1, V1 = m.user_embeddings, m.item_embeddings
+    assert U1.shape[1] == dim and V1.shape[1] == dim
+    pred = m.predict([0, 3, 9, 63]) if model != "LightGCN" else np.zeros(1, np.float32)   # (LightGCN.predict needs eval mode)
+    ret[rank] = dict(reports=np.stack(reports), losses=np.concatenate(losses, 0), U1=U1.cpu().numpy(), V1=V1.cpu().numpy(), pred=pred)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,dim", [("BPRMF", 32), ("LightGCN", 50), ("LayerGCN", 32)])
+def test_sharded_fit_at_a_narrower_width_equals_the_one_gpu_fit(model, dim, tiny_dir, tmp_path, monkeypatch):
+    """n_dim / embed_size / embed_dim below 64 on several ranks: zero-padded 64-float rows in the sharded engines, as on one GPU
+    (whose fit at these widths replays the oracle: tests/test_gpu_config0.py) -- same losses, reports and tables"""
+    monkeypatch.setenv("SKR_SPMM_PLAN", "1")
+    res = {}
+    for world in (1, 2):
+        wd = tmp_path / str(world)
+        wd.mkdir()
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_width_worker, args=(world, _free_port(), model, dim, tiny_dir, str(wd), ret), nprocs=world, join=True)
+            res[world] = {k: ret[k] for k in range(world)}
+    one = res[1][0]
+    for r in res[2].values():
+        np.testing.assert_allclose(r["losses"], one["losses"], rtol=1e-5)
+        np.testing.assert_allclose(r["reports"], one["reports"], rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(r["U1"], one["U1"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(r["V1"], one["V1"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(r["pred"], one["pred"], rtol=1e-4, atol=2e-6)
+    assert np.array_equal(res[2][0]["V1"], res[2][1]["V1"])
