@@ -186,6 +186,19 @@ def lightgcn_leg(args, world, rank, dev, dist, full, K, W, cpu_baseline):
         return csr.nnz * 8 + (csr.shape[0] + 1) * 8 + n_x * 256 + csr.shape[0] * 256
     alg = spmm_bytes(eng.a_ui, nI) + spmm_bytes(eng.a_iu, eng.n_local)
     ach = alg / ((ui_ms + iu_ms) * 1e-3) / 1e9
+    # counter bytes of ONE layer (both products), recorded: the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command average
+    # every launch of a kernel over the whole run; a layer is two spmm_rows_kernel launches plus the long rows' task / reduce
+    # launches in the proportion that run made them (the LDS-streamed densest rows' kernel is not in the counter passes)
+    _, pmc_source = pmc_lookup()
+    e_rows, e_tasks, e_red = (pmc_lookup.entry(n) for n in ("spmm_rows_kernel<false>", "spmm_tasks_kernel<false>", "spmm_reduce_kernel"))
+    layer_traffic = traffic_note = None
+    if world == 1 and e_rows and e_tasks and e_red and e_rows.get("calls"):
+        pairs = e_rows["calls"] / 2.0
+        layer_traffic = (2 * e_rows["hbm_bytes_per_launch"] + e_tasks["calls"] / pairs * e_tasks["hbm_bytes_per_launch"]
+                         + e_red["calls"] / pairs * e_red["hbm_bytes_per_launch"])
+        traffic_note = (f"{pmc_source}: 2 x spmm_rows_kernel + {e_tasks['calls'] / pairs:.1f} x spmm_tasks_kernel + {e_red['calls'] / pairs:.1f} x "
+                        "spmm_reduce_kernel launches per layer, bytes that enter or leave the L2s (fills from Infinity Cache or HBM): the "
+                        "row gathers that miss an XCD's L2")
     leg = {
         "value": K * gb / dt, "unit": "train interactions/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
         "scaling": "strong" if strong else "weak", "dtype": "f32", "global_batch": gb,
@@ -200,7 +213,9 @@ def lightgcn_leg(args, world, rank, dev, dist, full, K, W, cpu_baseline):
                                    "(tests/test_gpu_fullsize.py); SKR_LIGHTGCN_DENSE=1 computes them"},
         "roofline": {"kernel": "skr_spmm_plan_run: spmm_rows_kernel (short rows, 16 B per lane) + spmm_tasks_kernel (long rows, column-"
                                "blocked tasks) + spmm_reduce_kernel; ONE layer = user-side product + item-side product",
-                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": layer_traffic,
+                     "traffic_source": traffic_note,
+                     "traffic_over_algorithmic": (layer_traffic / alg) if layer_traffic else None,
                      "avg_launch_ms": ui_ms + iu_ms, "user_side_ms": ui_ms, "item_side_ms": iu_ms, "launches_averaged": len(pair_events),
                      "algorithmic_bytes_per_launch": alg, "local_nnz": eng.a_ui.nnz,
                      "row_gather_TBps": 2 * eng.a_ui.nnz * 256 / ((ui_ms + iu_ms) * 1e-3) / 1e12,
@@ -433,6 +448,10 @@ def pmc_lookup():
         source = f"{os.path.relpath(latest, REPO)} (recorded; command: {doc.get('command', 'bench.py, see tools/profile_bench.sh')})"
     except Exception:
         pmc, source = {}, None
+
+    def entry(name):
+        return pmc.get(name)
+    pmc_lookup.entry = entry
 
     def lookup(key):
         """`kernel` or `kernel@state` (e.g. @epoch3: the launches of the third whole epoch)"""
