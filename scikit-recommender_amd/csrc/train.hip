@@ -1851,11 +1851,20 @@ static int adam_block_cold_impl(float* d_p, float* d_m, float* d_v, int64_t n, f
     static const int bpc = [] { const char* e = getenv("SKR_COLD_BPC"); const int v = e ? atoi(e) : 5; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // workgroups per CU.  The pass runs beside the k-step block's small launches: round 2 settled on 4 (960 timed steps: 24.9 / 31.3 / 30.3 / 28.1 M interactions/s at 2 / 3 / 4 / 8); round 3: 5, together with the step kernel's issue priority (see bpr_fused_step_kernel)
     // SKR_COLD_REST=0 keeps every cold block on the full update (the float4 kernel): the A/B switch of tools/microbench.py
     static const bool rest = [] { const char* e = getenv("SKR_COLD_REST"); return !(e && atoi(e) == 0); }();
+    // A pass over a WHOLE block of the default length (32 steps and more) of the BPR tables takes six workgroups per CU
+    // (SKR_COLD_BPC_FULL; 0: SKR_COLD_BPC for every pass): in the steady state of an epoch the pass and the step stream are
+    // balanced (0.53 ms against 32 x 15 us + the write-back), and the sixth workgroup takes 0.04 ms off the pass for 0.4 us per
+    // step launch -- an epoch 0.997 -> 0.956 s on the same box (tools/r3_bpc_full.sh).  Shorter blocks (the 20-step slice of
+    // the bench line, an epoch's ragged last block) leave the step stream less work to hide the pass behind and keep five: with
+    // six for every pass the short slice scatters (34.5-39.5 M interactions/s against 39.4-41.0).  GRU4RecPlus's pass (TF
+    // arithmetic) keeps SKR_COLD_BPC: its step is a chain of eight small launches that was measured with five.
+    static const int bpc_full = [] { const char* e = getenv("SKR_COLD_BPC_FULL"); const int v = e ? atoi(e) : 6; return v < 1 ? 0 : (v > 8 ? 8 : v); }();
+    const int bpc_k = (bpc_full && k >= 32 && !tf) ? bpc_full : bpc;
     adam_block_thresholds(a, lr, beta1, beta2, eps, k);
     a.stats = cold_stats_buffer();
     if (rest) {
         int64_t blocks = ((n >> 6) + 4 * 4 - 1) / (4 * 4);
-        if (blocks > 256 * bpc) blocks = 256 * bpc;
+        if (blocks > 256 * bpc_k) blocks = 256 * bpc_k;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(adam_cold_rows_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, skr::as_stream(stream),
                            d_p, d_m, d_v, n, a, d_tag, hot_value);
