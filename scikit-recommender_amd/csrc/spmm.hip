@@ -28,7 +28,21 @@ namespace {
 
 constexpr int D = 64;
 constexpr int SPMM_LONG = 512;       // rows with at least this many entries are cut into column-blocked tasks
-constexpr int SPMM_CBLK = 16384;     // columns per block: 16 384 rows of X = 4 MB
+constexpr int SPMM_CBLK = 16384;     // columns per block of matrices too narrow to choose (see plan_default_cblk)
+// Columns per block of a plan.  The task launches walk the blocks in groups of 8 (launch g: the workgroups that share XCD x
+// take block 8g + x), so a block count that is NOT a multiple of 8 leaves XCDs idle in the last launch, and blocks of
+// ~30 k columns (7.5 MB of X per XCD and launch) beat the 16 384 of round 2 now that the densest rows no longer go this
+// way.  Measured on the item side of the 1 M-user graph, LightGCN step / item side (tools/r3_spmm_params.sh, same box):
+// 15 680 (64 blocks) 10.82 / 1.309 ms, 16 384 (62) 10.80 / 1.303, 20 864 (48) 10.58 / 1.255, 25 024 (40) 10.43 / 1.217,
+// 31 296 (32) 10.36 / 1.210, 32 768 (31) 10.52 / 1.25, 36 864 (28) 10.85 / 1.339, 41 728 (24) 10.65 / 1.278, 65 536 (16)
+// 11.02 / 1.377.  Hence: 8 * round(n_cols / (8 * 28 672)) blocks, at least 8, of equal width (a multiple of 64).
+inline int plan_default_cblk(int n_cols) {
+    if (n_cols < 8 * 256) return SPMM_CBLK;
+    const int64_t groups = std::max<int64_t>(1, (static_cast<int64_t>(n_cols) + 4 * 28672) / (8 * 28672));
+    const int64_t nb = 8 * groups;
+    const int64_t w = ((static_cast<int64_t>(n_cols) + nb - 1) / nb + 63) / 64 * 64;
+    return static_cast<int>(std::max<int64_t>(w, 2048));     // (narrow matrices: fewer, not thinner, blocks)
+}
 constexpr int SPMM_TASK = 256;       // entries per task at most
 constexpr int ROW_WAVES = 4;         // wavefronts per workgroup, both kernels
 constexpr int ROW_NF = 4;            // 16-byte gathers in flight per lane
@@ -725,7 +739,8 @@ int skr_spmm_plan_create(int n_rows, int n_cols, const int64_t* d_rowptr, const 
     p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = nnz;
     p->rowptr = d_rowptr; p->col = d_col; p->val = d_val;
     if (long_rows_from) p->long_thr = long_rows_from;
-    if (const char* e = getenv("SKR_SPMM_CBLK")) {       // tuning switch: columns per block (default 16 384 = 4 MB of X)
+    p->cblk = plan_default_cblk(n_cols);
+    if (const char* e = getenv("SKR_SPMM_CBLK")) {       // tuning switch: columns per block (default: plan_default_cblk)
         const int v = atoi(e);
         if (v >= 256) p->cblk = v;
     }

@@ -98,6 +98,8 @@ class DeviceCSR(object):
         if h is None:
             import ctypes
             h = ctypes.c_void_p()
+            if not long_rows_from:      # tuning switch: rows of at least this many entries are cut into column-blocked tasks (0 = 512)
+                long_rows_from = int(os.environ.get("SKR_SPMM_LONG_FROM", "0"))
             _hip.check(_hip.lib().skr_spmm_plan_create(self.shape[0], self.shape[1], _hip.ptr(self.rowptr), _hip.ptr(self.col),
                                                        _hip.ptr(self.val), self.nnz, int(long_rows_from), ctypes.byref(h),
                                                        _hip.stream()))

@@ -194,12 +194,18 @@ def test_spmm_plan_rectangular_blocks_and_determinism(n_rows, n_cols, long_from,
     info = (C.c_int64 * 4)()
     _hip.check(L.skr_spmm_plan_info(h, info))
     thr = long_from or 512
-    assert (info[0] & 0xffffffff) == int((lens >= thr).sum()) and info[2] == -(-n_cols // 16384) and (info[3] & 0xffffffff) == thr
+    # columns per block (spmm.hip plan_default_cblk): a multiple of 8 blocks of ~28 k columns, equal widths (multiples of 64)
+    if n_cols < 8 * 256:
+        cblk = 16384
+    else:
+        nb = 8 * max(1, (n_cols + 4 * 28672) // (8 * 28672))
+        cblk = max(((-(-n_cols // nb)) + 63) // 64 * 64, 2048)
+    assert (info[0] & 0xffffffff) == int((lens >= thr).sum()) and info[2] == -(-n_cols // cblk) and (info[3] & 0xffffffff) == thr
     assert (info[3] >> 32) == (int(windows) if windows else 1)
     # tasks: one per 256 entries of every (long row, column block) segment
     want_tasks = 0
     for r in np.flatnonzero(lens >= thr):
-        blk = col[rowptr[r]:rowptr[r + 1]] // 16384
+        blk = col[rowptr[r]:rowptr[r + 1]] // cblk
         want_tasks += int(sum(-(-c // 256) for c in np.bincount(blk)))
     assert info[1] == want_tasks
     outs = []
