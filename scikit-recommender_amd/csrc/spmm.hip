@@ -297,21 +297,22 @@ __global__ void window_split_kernel(int n_rows, int long_thr, int n_win, int64_t
     split[i] = lo;
 }
 
-// long rows: the tasks of column block 8 * group + (blockIdx % 8)
+// long rows: the tasks of the column blocks 8 * g + (blockIdx % 8), g = group .. group + span - 1, one block after the other
 template <bool COLMASK>
-__global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_t* __restrict__ first_task, int n_long, int n_blocks, int group,
+__global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_t* __restrict__ first_task, int n_long, int n_blocks, int group, int span,
                                                                     const Task* __restrict__ tasks, const int32_t* __restrict__ col,
                                                                     const float* __restrict__ val, const float* __restrict__ X,
                                                                     float* __restrict__ part, const int32_t* __restrict__ long_rows,
                                                                     const uint8_t* __restrict__ row_mask,
                                                                     const uint8_t* __restrict__ col_mask, int ld4,
                                                                     const uint8_t* __restrict__ hot_flag) {
-    const int b = group * 8 + (blockIdx.x & 7);
-    if (b >= n_blocks) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
     const float4* X4 = reinterpret_cast<const float4*>(X);
     const int64_t n_w = static_cast<int64_t>(gridDim.x >> 3) * ROW_WAVES;
+    for (int g = group; g < group + span; ++g) {
+    const int b = g * 8 + (blockIdx.x & 7);
+    if (b >= n_blocks) return;
     const int64_t t_end = first_task[static_cast<int64_t>(b + 1) * n_long];
     for (int64_t t = first_task[static_cast<int64_t>(b) * n_long] + (blockIdx.x >> 3) * ROW_WAVES + wv; t < t_end; t += n_w) {
         const Task tk = tasks[t];
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(ROW_WAVES * 64) void spmm_tasks_kernel(const int64_
         }
         sum_groups(acc);
         if (grp == 0) reinterpret_cast<float4*>(part)[static_cast<int64_t>(tk.part) * 16 + sub] = acc;
+    }
     }
 }
 
@@ -999,12 +1001,15 @@ int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, c
             const int groups = (plan->n_blocks + 7) / 8;
             // (tried: the next task's descriptor and entries requested before this task's gathers -- 1.389 vs 1.394 ms on the
             //  item side: the gather path, not the task's fixed cost, is the limit.  profiles/r02_spmm_lab.txt, run 7)
-            for (int g = 0; g < groups; ++g) {
+            // SKR_SPMM_TASK_SPAN: groups of 8 blocks per launch (experiment; default 1 = a launch per group)
+            static const int span_cfg = [] { const char* e = getenv("SKR_SPMM_TASK_SPAN"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+            for (int g = 0; g < groups; g += span_cfg) {
+                const int span = std::min(span_cfg, groups - g);
                 if (d_col_mask)
-                    hipLaunchKernelGGL(spmm_tasks_kernel<true>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
+                    hipLaunchKernelGGL(spmm_tasks_kernel<true>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, span, plan->tasks,
                                        plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask, ld >> 2, hot_flag);
                 else
-                    hipLaunchKernelGGL(spmm_tasks_kernel<false>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, plan->tasks,
+                    hipLaunchKernelGGL(spmm_tasks_kernel<false>, tgrid, blk, 0, st, plan->first_task, plan->n_long, plan->n_blocks, g, span, plan->tasks,
                                        plan->col, plan->val, d_X, plan->part, plan->long_rows, d_row_mask, d_col_mask, ld >> 2, hot_flag);
             }
             SKR_LAUNCH_CHECK();
