@@ -46,7 +46,13 @@ inline int plan_default_cblk(int n_cols) {
 constexpr int SPMM_TASK = 256;       // entries per task at most
 constexpr int ROW_WAVES = 4;         // wavefronts per workgroup, both kernels
 constexpr int ROW_NF = 4;            // 16-byte gathers in flight per lane
-constexpr int BLK_WGS_PER_XCD = 256;
+// workgroups per XCD of a task launch, at most.  Round 2 launched 256 (each wavefront striding through ~7 tasks of 1 .. 256
+// entries); with 2 048 a wavefront has one or two tasks and the hardware dispatcher does the balancing: LightGCN step
+// 10.25 -> 9.83 ms together with 16 384 instead of 8 192 workgroups of the short-row kernel (tools/r3_spmm_params.sh, same
+// box: 128 / 256 / 512 / 1 024 / 2 048 / 4 096 / 8 192 per XCD = 10.70 / 10.25 / 10.16 / 9.92 / 9.83 / 9.88 / 10.00 ms; rows
+// kernel 4 096 / 8 192 / 16 384 / 65 536 / 262 144 workgroups: user side 0.885 / 0.870 / 0.841 / 0.838 / 0.907 ms)
+constexpr int BLK_WGS_PER_XCD = 2048;
+constexpr int ROWS_WGS_MAX = 16384;
 // the DENSEST rows (round 3): a row that names a sizeable share of ALL columns does not gather -- X is streamed through LDS
 // in blocks of HOT_UB rows and the row's entries read it there
 constexpr int HOT_UB = 128;          // rows of X per LDS block (32 KB)
@@ -966,8 +972,15 @@ int skr_spmm_plan_run_ex(const skr_spmm_plan* plan, const float* d_X, int dim, c
     if (plan->n_rows == 0) return SKR_OK;
     hipStream_t st = skr::as_stream(stream);
     int64_t wgs = (static_cast<int64_t>(plan->n_rows) + ROW_WAVES - 1) / ROW_WAVES;
-    if (wgs > 8192) wgs = 8192;
-    const dim3 rgrid(static_cast<unsigned>(wgs)), blk(ROW_WAVES * 64), tgrid(8 * BLK_WGS_PER_XCD);
+    // tuning switches: SKR_SPMM_ROWS_WGS (workgroups of the short-row kernel at most), SKR_SPMM_TASK_WGS (per XCD and task launch)
+    static const int rows_cap = [] { const char* e = getenv("SKR_SPMM_ROWS_WGS"); const int v = e ? atoi(e) : ROWS_WGS_MAX; return v < 256 ? 256 : v; }();
+    static const int task_cap = [] { const char* e = getenv("SKR_SPMM_TASK_WGS"); const int v = e ? atoi(e) : BLK_WGS_PER_XCD; return v < 8 ? 8 : v; }();
+    if (wgs > rows_cap) wgs = rows_cap;
+    // a task launch covers 8 blocks; no more workgroups than ~1.25 x the average block has tasks for (a matrix with a handful
+    // of long rows launches a handful of workgroups)
+    int64_t task_wgs = plan->n_blocks > 0 ? (5 * plan->n_tasks / (4 * static_cast<int64_t>(plan->n_blocks)) + ROW_WAVES - 1) / ROW_WAVES : 1;
+    task_wgs = std::min<int64_t>(std::max<int64_t>(task_wgs, 8), task_cap);
+    const dim3 rgrid(static_cast<unsigned>(wgs)), blk(ROW_WAVES * 64), tgrid(static_cast<unsigned>(8 * task_wgs));
     for (int w = 0; w < plan->n_win; ++w) {
         if (d_col_mask)
             hipLaunchKernelGGL(spmm_rows_kernel<true>, rgrid, blk, 0, st, plan->n_rows, plan->long_thr, plan->rowptr, plan->col, plan->val,
