@@ -594,7 +594,7 @@ int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_
 
 /* logits = final_act(out . E[Y]^T + bias[Y]) for B sessions against n_y targets (the batch's own next
  * items first: column b is session b's positive, :180-186), bpr_max / top1_max loss (:137-166) and its
- * gradient.  d_loss[0] += mean loss; d_dlogits [B, n_y] = dL/d(pre-activation logits);
+ * gradient.  d_loss[0] = mean loss (the call clears the word first); d_dlogits [B, n_y] = dL/d(pre-activation logits);
  * d_dout [B, hid] = dL/d out.  B <= n_y <= 8192. */
 int skr_session_loss(const float* d_out, int B, int hid, const float* d_item_table, const float* d_item_bias,
                      const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,

@@ -595,10 +595,15 @@ template <int H>      // compile-time hidden size: index arithmetic by shifts, s
 __global__ __launch_bounds__(G_T) void session_logits_kernel(const float* __restrict__ out, int B, int /*hid*/,
                                                              const float* __restrict__ E, const float* __restrict__ bias,
                                                              const int32_t* __restrict__ Y, int n_y, int fact,
-                                                             float* __restrict__ logits) {
+                                                             float* __restrict__ logits, float* __restrict__ dout_clear,
+                                                             int n_clear, float* __restrict__ loss_clear) {
     __shared__ float et[L_TY][G_HMAX + 4];
     __shared__ float bs[L_TY];
     const int tid = threadIdx.x, y0 = blockIdx.x * L_TY;
+    // the two accumulators of the launches behind this one start from zero: dL/dout (session_dout_kernel adds into it) and the
+    // loss word (session_rowloss_kernel adds the rows' shares) -- cleared here instead of by a memset and a fill of their own
+    for (int i = blockIdx.x * G_T + tid; i < n_clear; i += gridDim.x * G_T) dout_clear[i] = 0.0f;
+    if (blockIdx.x == 0 && tid == 0) *loss_clear = 0.0f;
     for (int idx = tid; idx < L_TY * H; idx += G_T) {
         const int y = idx / H, d = idx - y * H;
         et[y][d] = (y0 + y < n_y) ? E[static_cast<int64_t>(Y[y0 + y]) * H + d] : 0.0f;
@@ -915,16 +920,15 @@ static int session_loss_launch(const float* d_out, int B, int hid, const float* 
     SKR_REQUIRE(loss_kind == 0 || loss_kind == 1, "There is not loss named '%d'.", loss_kind);
     hipStream_t st = skr::as_stream(stream);
 if (hid == 32) hipLaunchKernelGGL(session_logits_kernel<32>, dim3((n_y + L_TY - 1) / L_TY), dim3(G_T), 0, st, d_out, B, hid, d_item_table,
-                       d_item_bias, d_y, n_y, final_act_kind, d_dlogits);
+                       d_item_bias, d_y, n_y, final_act_kind, d_dlogits, d_dout, B * hid, d_loss);
     else if (hid == 64) hipLaunchKernelGGL(session_logits_kernel<64>, dim3((n_y + L_TY - 1) / L_TY), dim3(G_T), 0, st, d_out, B, hid, d_item_table,
-                       d_item_bias, d_y, n_y, final_act_kind, d_dlogits);
+                       d_item_bias, d_y, n_y, final_act_kind, d_dlogits, d_dout, B * hid, d_loss);
     else hipLaunchKernelGGL(session_logits_kernel<128>, dim3((n_y + L_TY - 1) / L_TY), dim3(G_T), 0, st, d_out, B, hid, d_item_table,
-                       d_item_bias, d_y, n_y, final_act_kind, d_dlogits);
+                       d_item_bias, d_y, n_y, final_act_kind, d_dlogits, d_dout, B * hid, d_loss);
     SKR_LAUNCH_CHECK();
     hipLaunchKernelGGL(session_rowloss_kernel, dim3(B), dim3(G_T), 0, st, B, n_y, final_act_kind, loss_kind, bpr_reg,
                        d_dlogits, d_loss, pos_off, B_mean);
     SKR_LAUNCH_CHECK();
-    SKR_HIP(hipMemsetAsync(d_dout, 0, static_cast<size_t>(B) * hid * sizeof(float), st));
 if (hid == 32) hipLaunchKernelGGL(session_dout_kernel<32>, dim3((n_y + L_CY - 1) / L_CY, (B + L_CB - 1) / L_CB), dim3(G_T), 0, st, d_dlogits,
                        B, hid, d_item_table, d_y, n_y, d_dout);
     else if (hid == 64) hipLaunchKernelGGL(session_dout_kernel<64>, dim3((n_y + L_CY - 1) / L_CY, (B + L_CB - 1) / L_CB), dim3(G_T), 0, st, d_dlogits,

@@ -202,8 +202,7 @@ class SessionGRU(object):
         new_states, saved = self.forward(x_index, states, save=True, tag=f"t{self._parity}")
         out = new_states[-1]
         dlog, dout = self._buf("dlogits", (b, n_y)), self._buf("dout", (b, hn))
-        self.loss.zero_()
-        g = self.opt
+        g = self.opt                     # (skr_session_loss clears the loss word itself)
         # inside a block the hot step knows the rows by the block's id list: no touch bytes
         p_touch, p_base = (None, None) if self._blk_left > 0 else (_hip.ptr(g.touch), _hip.ptr(g.grad))
         _hip.check(L.skr_session_loss(_hip.ptr(out), b, hn, _hip.ptr(self.E_out), _hip.ptr(self.b_out), _hip.ptr(y_index),
@@ -277,8 +276,7 @@ class ShardedSessionGRU(SessionGRU):
         new_states, saved = self.forward(x_local, states, save=True, tag=f"t{self._parity}")
         out = new_states[-1]
         dlog, dout = self._buf("dlogits", (bl, n_y)), self._buf("dout", (bl, hn))
-        self.loss.zero_()
-        g = self.opt
+        g = self.opt                     # (skr_session_loss_sharded clears the loss word itself)
         _hip.check(L.skr_session_loss_sharded(_hip.ptr(out), bl, hn, _hip.ptr(self.E_out), _hip.ptr(self.b_out), _hip.ptr(y_index),
                                               n_y, self.final_act, self.loss_kind, self.bpr_reg, _hip.ptr(dlog), _hip.ptr(dout),
                                               _hip.ptr(self.loss), lo, b, st))
