@@ -607,6 +607,13 @@ int skr_session_loss_sharded(const float* d_out, int B_local, int hid, const flo
                              const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
                              float* d_dout, float* d_loss, int slot_offset, int B_global, void* stream);
 
+/* skr_session_loss_sharded followed by skr_session_out_grads (arguments as there; slot_offset = 0 and B_global = B_local for
+ * a whole batch) with dL/dout and the output-side gradients in ONE launch: three launches per call instead of four. */
+int skr_session_loss_grads(const float* d_out, int B_local, int hid, const float* d_item_table, const float* d_item_bias,
+                           const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
+                           float* d_dout, float* d_loss, int slot_offset, int B_global, float reg, float* d_g_table,
+                           float* d_g_bias, uint8_t* d_touch, const float* d_touch_base, void* stream);
+
 /* Output-side gradients of the same step, accumulated into dense gradient tables:
  *   d_g_table[Y[y]] += sum_b dlogits[b,y] out[b] + reg * E[Y[y]],  d_g_bias[Y[y]] += sum_b dlogits[b,y] + reg * bias[Y[y]]
  * (reg: the l2_loss term of :189-191; repeated targets count each time).  d_touch / d_touch_base as in skr_bpr_step. */

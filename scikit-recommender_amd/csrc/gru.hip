@@ -712,12 +712,12 @@ constexpr int L_CY = 64;
 constexpr int L_CB = 16;
 
 template <int H>
-__global__ __launch_bounds__(G_T) void session_dout_kernel(const float* __restrict__ dlogits, int B, int /*hid*/,
-                                                           const float* __restrict__ E, const int32_t* __restrict__ Y,
-                                                           int n_y, float* __restrict__ dout) {
+__device__ __forceinline__ void session_dout_body(int block_x, int block_y, const float* __restrict__ dlogits, int B,
+                                                  const float* __restrict__ E, const int32_t* __restrict__ Y, int n_y,
+                                                  float* __restrict__ dout) {
     __shared__ float et[L_CY][G_HMAX];
     __shared__ float gl[L_CB][L_CY + 1];
-    const int tid = threadIdx.x, y0 = blockIdx.x * L_CY, b0 = blockIdx.y * L_CB;
+    const int tid = threadIdx.x, y0 = block_x * L_CY, b0 = block_y * L_CB;
     const int ny = (n_y - y0) < L_CY ? (n_y - y0) : L_CY;
     for (int idx = tid; idx < ny * H; idx += G_T) {
         const int y = idx / H, d = idx - y * H;
@@ -745,6 +745,13 @@ __global__ __launch_bounds__(G_T) void session_dout_kernel(const float* __restri
     }
 }
 
+template <int H>
+__global__ __launch_bounds__(G_T) void session_dout_kernel(const float* __restrict__ dlogits, int B, int /*hid*/,
+                                                           const float* __restrict__ E, const int32_t* __restrict__ Y,
+                                                           int n_y, float* __restrict__ dout) {
+    session_dout_body<H>(blockIdx.x, blockIdx.y, dlogits, B, E, Y, n_y, dout);
+}
+
 // mark the 64-float blocks of the flat gradient buffer that [a, a+n) overlaps (DenseAdam's touch bytes)
 __device__ __forceinline__ void mark_range(uint8_t* touch, const float* base, const float* a, int n) {
     const int64_t b0 = (a - base) >> 6, b1 = (a + n - 1 - base) >> 6;
@@ -756,14 +763,14 @@ __device__ __forceinline__ void mark_range(uint8_t* touch, const float* base, co
 //   gE[Y[y]] += sum_b dlogits[b, y] out[b] + reg E[Y[y]] ;  gb[Y[y]] += sum_b dlogits[b, y] + reg bias[Y[y]]
 // (an item that occurs several times in Y is counted each time, like tf.gather's gradient and l2_loss)
 template <int H>
-__global__ __launch_bounds__(G_T) void session_out_grads_kernel(const float* __restrict__ dlogits,
-                                                                const float* __restrict__ out, int B, int /*hid*/,
-                                                                const int32_t* __restrict__ Y, int n_y,
-                                                                const float* __restrict__ E, const float* __restrict__ bias,
-                                                                float reg, float* __restrict__ gE, float* __restrict__ gb,
-                                                                uint8_t* __restrict__ touch, const float* touch_base) {
+__device__ __forceinline__ void session_out_grads_body(int block_x, const float* __restrict__ dlogits,
+                                                       const float* __restrict__ out, int B,
+                                                       const int32_t* __restrict__ Y, int n_y,
+                                                       const float* __restrict__ E, const float* __restrict__ bias,
+                                                       float reg, float* __restrict__ gE, float* __restrict__ gb,
+                                                       uint8_t* __restrict__ touch, const float* touch_base) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int y = blockIdx.x * (G_T / 64) + wv;
+    const int y = block_x * (G_T / 64) + wv;
     if (y >= n_y) return;
     const int64_t item = Y[y];
     float acc0 = 0.0f, acc1 = 0.0f, colsum = 0.0f;
@@ -791,6 +798,31 @@ __global__ __launch_bounds__(G_T) void session_out_grads_kernel(const float* __r
             mark_range(touch, touch_base, &gb[item], 1);
         }
     }
+}
+
+template <int H>
+__global__ __launch_bounds__(G_T) void session_out_grads_kernel(const float* __restrict__ dlogits,
+                                                                const float* __restrict__ out, int B, int /*hid*/,
+                                                                const int32_t* __restrict__ Y, int n_y,
+                                                                const float* __restrict__ E, const float* __restrict__ bias,
+                                                                float reg, float* __restrict__ gE, float* __restrict__ gb,
+                                                                uint8_t* __restrict__ touch, const float* touch_base) {
+    session_out_grads_body<H>(blockIdx.x, dlogits, out, B, Y, n_y, E, bias, reg, gE, gb, touch, touch_base);
+}
+
+// (c) and the output-side gradients in ONE launch: both only read dlogits, and (c)'s few dozen workgroups would otherwise
+// hold the chip for a launch of their own (10.8 of a step's ~115 us).  Workgroups [0, n_dx * n_dy) take tiles of (c), the
+// rest one target each; a workgroup takes one branch as a whole, so the barrier inside (c) is met by all its threads.
+template <int H>
+__global__ __launch_bounds__(G_T) void session_grads_kernel(const float* __restrict__ dlogits, const float* __restrict__ out, int B,
+                                                            const int32_t* __restrict__ Y, int n_y,
+                                                            const float* __restrict__ E, const float* __restrict__ bias,
+                                                            float reg, float* __restrict__ dout, float* __restrict__ gE,
+                                                            float* __restrict__ gb, uint8_t* __restrict__ touch,
+                                                            const float* touch_base, int n_dx, int n_dy) {
+    const int n_d = n_dx * n_dy, bx = static_cast<int>(blockIdx.x);
+    if (bx < n_d) session_dout_body<H>(bx % n_dx, bx / n_dx, dlogits, B, E, Y, n_y, dout);
+    else session_out_grads_body<H>(bx - n_d, dlogits, out, B, Y, n_y, E, bias, reg, gE, gb, touch, touch_base);
 }
 
 // g_table[index[n]] += src[n] + reg * table[index[n]]   (the input-embedding gradient)
@@ -911,8 +943,12 @@ int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_
 
 static int session_loss_launch(const float* d_out, int B, int hid, const float* d_item_table, const float* d_item_bias,
                                const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
-                               float* d_dout, float* d_loss, int pos_off, int B_mean, void* stream) {
+                               float* d_dout, float* d_loss, int pos_off, int B_mean, void* stream,
+                               bool with_grads = false, float reg = 0.0f, float* d_g_table = nullptr, float* d_g_bias = nullptr,
+                               uint8_t* d_touch = nullptr, const float* d_touch_base = nullptr) {
     SKR_REQUIRE(d_out && d_item_table && d_item_bias && d_y && d_dlogits && d_dout && d_loss, "skr_session_loss: NULL argument");
+    SKR_REQUIRE(!with_grads || (d_g_table && d_g_bias), "skr_session_loss_grads: NULL argument");
+    SKR_REQUIRE((d_touch == nullptr) == (d_touch_base == nullptr), "touch: both pointers or neither");
     SKR_REQUIRE(hid == 32 || hid == 64 || hid == 128, "skr_session_loss: hid must be 32, 64 or 128 (got %d)", hid);
     SKR_REQUIRE(B >= 1 && pos_off >= 0 && pos_off + B <= B_mean && n_y >= B_mean && n_y <= L_NY_MAX,
                 "skr_session_loss: need slots [%d, %d) inside a batch of %d <= n_y = %d <= %d", pos_off, pos_off + B, B_mean, n_y, L_NY_MAX);
@@ -929,6 +965,18 @@ if (hid == 32) hipLaunchKernelGGL(session_logits_kernel<32>, dim3((n_y + L_TY - 
     hipLaunchKernelGGL(session_rowloss_kernel, dim3(B), dim3(G_T), 0, st, B, n_y, final_act_kind, loss_kind, bpr_reg,
                        d_dlogits, d_loss, pos_off, B_mean);
     SKR_LAUNCH_CHECK();
+    if (with_grads) {
+        const int n_dx = (n_y + L_CY - 1) / L_CY, n_dy = (B + L_CB - 1) / L_CB, n_g = (n_y + G_T / 64 - 1) / (G_T / 64);
+        const dim3 grid(static_cast<unsigned>(n_dx * n_dy + n_g));
+        if (hid == 32) hipLaunchKernelGGL(session_grads_kernel<32>, grid, dim3(G_T), 0, st, d_dlogits, d_out, B, d_y, n_y, d_item_table,
+                                          d_item_bias, reg, d_dout, d_g_table, d_g_bias, d_touch, d_touch_base, n_dx, n_dy);
+        else if (hid == 64) hipLaunchKernelGGL(session_grads_kernel<64>, grid, dim3(G_T), 0, st, d_dlogits, d_out, B, d_y, n_y, d_item_table,
+                                               d_item_bias, reg, d_dout, d_g_table, d_g_bias, d_touch, d_touch_base, n_dx, n_dy);
+        else hipLaunchKernelGGL(session_grads_kernel<128>, grid, dim3(G_T), 0, st, d_dlogits, d_out, B, d_y, n_y, d_item_table,
+                                d_item_bias, reg, d_dout, d_g_table, d_g_bias, d_touch, d_touch_base, n_dx, n_dy);
+        SKR_LAUNCH_CHECK();
+        return SKR_OK;
+    }
 if (hid == 32) hipLaunchKernelGGL(session_dout_kernel<32>, dim3((n_y + L_CY - 1) / L_CY, (B + L_CB - 1) / L_CB), dim3(G_T), 0, st, d_dlogits,
                        B, hid, d_item_table, d_y, n_y, d_dout);
     else if (hid == 64) hipLaunchKernelGGL(session_dout_kernel<64>, dim3((n_y + L_CY - 1) / L_CY, (B + L_CB - 1) / L_CB), dim3(G_T), 0, st, d_dlogits,
@@ -951,6 +999,15 @@ int skr_session_loss_sharded(const float* d_out, int B_local, int hid, const flo
                              float* d_dout, float* d_loss, int slot_offset, int B_global, void* stream) {
     return session_loss_launch(d_out, B_local, hid, d_item_table, d_item_bias, d_y, n_y, final_act_kind, loss_kind, bpr_reg,
                                d_dlogits, d_dout, d_loss, slot_offset, B_global, stream);
+}
+
+int skr_session_loss_grads(const float* d_out, int B_local, int hid, const float* d_item_table, const float* d_item_bias,
+                           const int32_t* d_y, int n_y, int final_act_kind, int loss_kind, float bpr_reg, float* d_dlogits,
+                           float* d_dout, float* d_loss, int slot_offset, int B_global, float reg, float* d_g_table,
+                           float* d_g_bias, uint8_t* d_touch, const float* d_touch_base, void* stream) {
+    return session_loss_launch(d_out, B_local, hid, d_item_table, d_item_bias, d_y, n_y, final_act_kind, loss_kind, bpr_reg,
+                               d_dlogits, d_dout, d_loss, slot_offset, B_global, stream, true, reg, d_g_table, d_g_bias, d_touch,
+                               d_touch_base);
 }
 
 int skr_session_out_grads(const float* d_dlogits, const float* d_out, int B, int hid, const int32_t* d_y, int n_y,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "skr_gru_cell_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "skr_session_loss": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]),
     "skr_session_loss_sharded": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp]),
+    "skr_session_loss_grads": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]),
     "skr_session_out_grads": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, f32, vp, vp, vp, vp, vp]),
     "skr_pop_sample": (i32, [vp, i32, vp, u64, i64, vp, vp]),
     "skr_scatter_add_rows": (i32, [vp, vp, i32, i32, vp, f32, vp, vp, vp, vp]),

@@ -202,15 +202,14 @@ class SessionGRU(object):
         new_states, saved = self.forward(x_index, states, save=True, tag=f"t{self._parity}")
         out = new_states[-1]
         dlog, dout = self._buf("dlogits", (b, n_y)), self._buf("dout", (b, hn))
-        g = self.opt                     # (skr_session_loss clears the loss word itself)
+        g = self.opt                     # (skr_session_loss_grads clears the loss word itself)
         # inside a block the hot step knows the rows by the block's id list: no touch bytes
         p_touch, p_base = (None, None) if self._blk_left > 0 else (_hip.ptr(g.touch), _hip.ptr(g.grad))
-        _hip.check(L.skr_session_loss(_hip.ptr(out), b, hn, _hip.ptr(self.E_out), _hip.ptr(self.b_out), _hip.ptr(y_index),
-                                      n_y, self.final_act, self.loss_kind, self.bpr_reg, _hip.ptr(dlog), _hip.ptr(dout),
-                                      _hip.ptr(self.loss), st))
-        _hip.check(L.skr_session_out_grads(_hip.ptr(dlog), _hip.ptr(out), b, hn, _hip.ptr(y_index), n_y,
-                                           _hip.ptr(self.E_out), _hip.ptr(self.b_out), self.reg, _hip.ptr(self.gE_out),
-                                           _hip.ptr(self.gb_out), p_touch, p_base, st))
+        # logits, row losses, then dL/dout together with the output-side gradients (both only read dlogits): three launches
+        _hip.check(L.skr_session_loss_grads(_hip.ptr(out), b, hn, _hip.ptr(self.E_out), _hip.ptr(self.b_out), _hip.ptr(y_index),
+                                            n_y, self.final_act, self.loss_kind, self.bpr_reg, _hip.ptr(dlog), _hip.ptr(dout),
+                                            _hip.ptr(self.loss), 0, b, self.reg, _hip.ptr(self.gE_out), _hip.ptr(self.gb_out),
+                                            p_touch, p_base, st))
         dh = dout
         for l in range(len(self.cells) - 1, -1, -1):
             (Wg, bg, Wc, bc), (gWg, gbg, gWc, gbc) = self.cells[l], self.gcells[l]
@@ -276,14 +275,12 @@ class ShardedSessionGRU(SessionGRU):
         new_states, saved = self.forward(x_local, states, save=True, tag=f"t{self._parity}")
         out = new_states[-1]
         dlog, dout = self._buf("dlogits", (bl, n_y)), self._buf("dout", (bl, hn))
-        g = self.opt                     # (skr_session_loss_sharded clears the loss word itself)
-        _hip.check(L.skr_session_loss_sharded(_hip.ptr(out), bl, hn, _hip.ptr(self.E_out), _hip.ptr(self.b_out), _hip.ptr(y_index),
-                                              n_y, self.final_act, self.loss_kind, self.bpr_reg, _hip.ptr(dlog), _hip.ptr(dout),
-                                              _hip.ptr(self.loss), lo, b, st))
+        g = self.opt                     # (skr_session_loss_grads clears the loss word itself)
         reg_y = self.reg if self.ctx.rank == 0 else 0.0
-        _hip.check(L.skr_session_out_grads(_hip.ptr(dlog), _hip.ptr(out), bl, hn, _hip.ptr(y_index), n_y,
-                                           _hip.ptr(self.E_out), _hip.ptr(self.b_out), reg_y, _hip.ptr(self.gE_out),
-                                           _hip.ptr(self.gb_out), _hip.ptr(g.touch), _hip.ptr(g.grad), st))
+        _hip.check(L.skr_session_loss_grads(_hip.ptr(out), bl, hn, _hip.ptr(self.E_out), _hip.ptr(self.b_out), _hip.ptr(y_index),
+                                            n_y, self.final_act, self.loss_kind, self.bpr_reg, _hip.ptr(dlog), _hip.ptr(dout),
+                                            _hip.ptr(self.loss), lo, b, reg_y, _hip.ptr(self.gE_out), _hip.ptr(self.gb_out),
+                                            _hip.ptr(g.touch), _hip.ptr(g.grad), st))
         dh = dout
         for l in range(len(self.cells) - 1, -1, -1):
             (Wg, bg, Wc, bc), (gWg, gbg, gWc, gbc) = self.cells[l], self.gcells[l]

@@ -156,6 +156,21 @@ def test_session_loss_and_grads(loss, fact, B, S, h):
                                        _hip.ptr(gE), _hip.ptr(gb), None, None, st))
     _close(gE.cpu().numpy(), tE.grad.numpy(), 5e-5, 1e-7)
     _close(gb.cpu().numpy(), tb.grad.numpy(), 5e-5, 1e-7)
+    # the one-call form (dL/dout and the output-side gradients in ONE launch, loss word and dout cleared by the call itself):
+    # same dlogits bit for bit, the atomically summed outputs to their tolerance -- also from dirty output buffers
+    dlog2 = torch.full((B, n_y), 3.0, device="cuda")
+    dout2 = torch.full((B, h), 5.0, device="cuda")
+    loss2 = torch.full((1,), 7.0, device="cuda")
+    gE2, gb2 = torch.zeros_like(dE), torch.zeros_like(db)
+    _hip.check(L.skr_session_loss_grads(_hip.ptr(do), B, h, _hip.ptr(dE), _hip.ptr(db), _hip.ptr(dY), n_y, fk, lk, bpr_reg,
+                                        _hip.ptr(dlog2), _hip.ptr(dout2), _hip.ptr(loss2), 0, B, reg, _hip.ptr(gE2), _hip.ptr(gb2),
+                                        None, None, st))
+    torch.cuda.synchronize()
+    assert np.array_equal(dlog2.cpu().numpy(), dlog.cpu().numpy())
+    assert abs(float(loss2) - float(lossbuf)) <= 1e-6 * abs(float(lossbuf)) + 1e-9
+    _close(dout2.cpu().numpy(), dout.cpu().numpy(), 2e-6, 1e-8)
+    _close(gE2.cpu().numpy(), gE.cpu().numpy(), 2e-6, 1e-8)
+    _close(gb2.cpu().numpy(), gb.cpu().numpy(), 2e-6, 1e-8)
 
 
 @pytest.mark.parametrize("layers,loss,fact,act,reg", [([64], "bpr_max", "linear", "tanh", 0.0),
