@@ -592,6 +592,15 @@ int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_
                      const float* d_c, const float* d_dh_new, float* d_gWg, float* d_gbg, float* d_gWc, float* d_gbc,
                      float* d_dx, float* d_work, void* stream);
 
+/* skr_gru_cell_bwd of the FIRST layer (its input rows are gathered: d_x = the input item table, d_x_index = the batch's
+ * items) followed by skr_scatter_add_rows(d_dx, d_x_index, B, in_dim, d_x, reg, d_g_table, ...): the input-embedding
+ * gradient rides in the weight-gradient launch (both only need what the rows kernel in front of them has written). */
+int skr_gru_cell_bwd_scatter(const float* d_x, const int32_t* d_x_index, const float* d_h, int B, int in_dim, int hid,
+                             const float* d_Wg, const float* d_Wc, int hidden_act_kind, const float* d_r, const float* d_u,
+                             const float* d_c, const float* d_dh_new, float* d_gWg, float* d_gbg, float* d_gWc, float* d_gbc,
+                             float* d_dx, float* d_work, float reg, float* d_g_table, uint8_t* d_touch,
+                             const float* d_touch_base, void* stream);
+
 /* logits = final_act(out . E[Y]^T + bias[Y]) for B sessions against n_y targets (the batch's own next
  * items first: column b is session b's positive, :180-186), bpr_max / top1_max loss (:137-166) and its
  * gradient.  d_loss[0] = mean loss (the call clears the word first); d_dlogits [B, n_y] = dL/d(pre-activation logits);

@@ -3,7 +3,7 @@
 
 #include <cstdarg>
 
-#define SKR_ABI_VERSION 8
+#define SKR_ABI_VERSION 9
 
 namespace skr {
 static thread_local std::string g_err;

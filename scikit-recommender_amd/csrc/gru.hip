@@ -498,10 +498,30 @@ __global__ __launch_bounds__(T) void gru_bwd_rows_kernel(GruIn g, const float* _
 
 // backward, part 2 (per weight): dWg += [x,h]^T [dr~|du~] ; dWc += [x, r*h]^T dc~ ; bias sums.
 // One thread per weight, a loop over the (few) sessions of the batch.
+// the input-embedding gradient of the FIRST layer (scatter_add_rows_kernel's body, below) may ride in the weights launch: it
+// only needs dx, which the rows kernel in front of both has written, and its 32 workgroups (4.6 us as a launch of their own)
+// disappear among the weights' ~390
+struct ScatterArgs {
+    const float* src;          // [n, dim]  (NULL: no scatter in this launch)
+    const int32_t* index;
+    int n, dim;
+    const float* table;
+    float reg;
+    float* g_table;
+    uint8_t* touch;
+    const float* touch_base;
+    int first_block;           // workgroups from this one on scatter
+};
+__device__ void scatter_add_rows_body(int block_x, const ScatterArgs& a);
+
 __global__ __launch_bounds__(G_T) void gru_bwd_weights_kernel(GruIn g, const float* __restrict__ r_in,
                                                               const float* __restrict__ dcp, const float* __restrict__ dgp,
                                                               float* __restrict__ gWg, float* __restrict__ gbg,
-                                                              float* __restrict__ gWc, float* __restrict__ gbc) {
+                                                              float* __restrict__ gWc, float* __restrict__ gbc, ScatterArgs sc) {
+    if (sc.src && static_cast<int>(blockIdx.x) >= sc.first_block) {
+        scatter_add_rows_body(static_cast<int>(blockIdx.x) - sc.first_block, sc);
+        return;
+    }
     const int IN = g.in_dim, H = g.hid, K = IN + H;
     const int64_t n_g = static_cast<int64_t>(K) * 2 * H, n_c = static_cast<int64_t>(K) * H;
     const int64_t t = static_cast<int64_t>(blockIdx.x) * G_T + threadIdx.x;
@@ -826,21 +846,25 @@ __global__ __launch_bounds__(G_T) void session_grads_kernel(const float* __restr
 }
 
 // g_table[index[n]] += src[n] + reg * table[index[n]]   (the input-embedding gradient)
+__device__ void scatter_add_rows_body(int block_x, const ScatterArgs& a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = block_x * (G_T / 64) + wv;
+    if (r >= a.n) return;
+    const int64_t row = a.index[r];
+    for (int d = lane; d < a.dim; d += 64) {
+        float v = a.src[static_cast<int64_t>(r) * a.dim + d];
+        if (a.reg != 0.0f) v += a.reg * a.table[row * a.dim + d];
+        atomicAdd(&a.g_table[row * a.dim + d], v);
+    }
+    if (a.touch && lane == 0) mark_range(a.touch, a.touch_base, a.g_table + row * a.dim, a.dim);
+}
+
 __global__ __launch_bounds__(G_T) void scatter_add_rows_kernel(const float* __restrict__ src,
                                                                const int32_t* __restrict__ index, int n, int dim,
                                                                const float* __restrict__ table, float reg,
                                                                float* __restrict__ g_table, uint8_t* __restrict__ touch,
                                                                const float* touch_base) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = blockIdx.x * (G_T / 64) + wv;
-    if (r >= n) return;
-    const int64_t row = index[r];
-    for (int d = lane; d < dim; d += 64) {
-        float v = src[static_cast<int64_t>(r) * dim + d];
-        if (reg != 0.0f) v += reg * table[row * dim + d];
-        atomicAdd(&g_table[row * dim + d], v);
-    }
-    if (touch && lane == 0) mark_range(touch, touch_base, g_table + row * dim, dim);
+    scatter_add_rows_body(static_cast<int>(blockIdx.x), ScatterArgs{src, index, n, dim, table, reg, g_table, touch, touch_base, 0});
 }
 
 bool dims_ok(int in_dim, int hid) {
@@ -903,10 +927,10 @@ int skr_gru_cell_fwd(const float* d_x, const int32_t* d_x_index, const float* d_
     return SKR_OK;
 }
 
-int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_h, int B, int in_dim, int hid,
+static int gru_cell_bwd_impl(const float* d_x, const int32_t* d_x_index, const float* d_h, int B, int in_dim, int hid,
                      const float* d_Wg, const float* d_Wc, int hidden_act_kind, const float* d_r, const float* d_u,
                      const float* d_c, const float* d_dh_new, float* d_gWg, float* d_gbg, float* d_gWc, float* d_gbc,
-                     float* d_dx, float* d_work, void* stream) {
+                     float* d_dx, float* d_work, ScatterArgs sc, void* stream) {
     SKR_REQUIRE(d_x && d_h && d_Wg && d_Wc && d_r && d_u && d_c && d_dh_new && d_gWg && d_gbg && d_gWc && d_gbc && d_dx &&
                 d_work, "skr_gru_cell_bwd: NULL argument");
     SKR_REQUIRE(dims_ok(in_dim, hid), "skr_gru_cell_bwd: hid must be 32, 64 or 128 and in_dim <= 128 (got %d, %d)", in_dim, hid);
@@ -935,10 +959,32 @@ int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_
     if (B <= G_SMALL_B) by_hid(std::integral_constant<int, 4>{}); else by_hid(std::integral_constant<int, G_ROWS>{});
     SKR_LAUNCH_CHECK();
     const int64_t n_out = static_cast<int64_t>(in_dim + hid) * 3 * hid + 3 * hid;
-    hipLaunchKernelGGL(gru_bwd_weights_kernel, dim3(static_cast<unsigned>((n_out + G_T - 1) / G_T)), dim3(G_T), 0, st, g,
-                       d_r, dcp, dgp, d_gWg, d_gbg, d_gWc, d_gbc);
+    const unsigned n_w = static_cast<unsigned>((n_out + G_T - 1) / G_T);
+    sc.first_block = static_cast<int>(n_w);
+    const unsigned n_s = sc.src ? static_cast<unsigned>((sc.n + G_T / 64 - 1) / (G_T / 64)) : 0u;
+    hipLaunchKernelGGL(gru_bwd_weights_kernel, dim3(n_w + n_s), dim3(G_T), 0, st, g, d_r, dcp, dgp, d_gWg, d_gbg, d_gWc, d_gbc, sc);
     SKR_LAUNCH_CHECK();
     return SKR_OK;
+}
+
+int skr_gru_cell_bwd(const float* d_x, const int32_t* d_x_index, const float* d_h, int B, int in_dim, int hid,
+                     const float* d_Wg, const float* d_Wc, int hidden_act_kind, const float* d_r, const float* d_u,
+                     const float* d_c, const float* d_dh_new, float* d_gWg, float* d_gbg, float* d_gWc, float* d_gbc,
+                     float* d_dx, float* d_work, void* stream) {
+    return gru_cell_bwd_impl(d_x, d_x_index, d_h, B, in_dim, hid, d_Wg, d_Wc, hidden_act_kind, d_r, d_u, d_c, d_dh_new, d_gWg, d_gbg,
+                             d_gWc, d_gbc, d_dx, d_work, ScatterArgs{}, stream);
+}
+
+int skr_gru_cell_bwd_scatter(const float* d_x, const int32_t* d_x_index, const float* d_h, int B, int in_dim, int hid,
+                             const float* d_Wg, const float* d_Wc, int hidden_act_kind, const float* d_r, const float* d_u,
+                             const float* d_c, const float* d_dh_new, float* d_gWg, float* d_gbg, float* d_gWc, float* d_gbc,
+                             float* d_dx, float* d_work, float reg, float* d_g_table, uint8_t* d_touch, const float* d_touch_base,
+                             void* stream) {
+    SKR_REQUIRE(d_x && d_x_index && d_g_table, "skr_gru_cell_bwd_scatter: the first layer's gathered input (table + index) and its gradient table");
+    SKR_REQUIRE((d_touch == nullptr) == (d_touch_base == nullptr), "touch: both pointers or neither");
+    return gru_cell_bwd_impl(d_x, d_x_index, d_h, B, in_dim, hid, d_Wg, d_Wc, hidden_act_kind, d_r, d_u, d_c, d_dh_new, d_gWg, d_gbg,
+                             d_gWc, d_gbc, d_dx, d_work, ScatterArgs{d_dx, d_x_index, B, in_dim, d_x, reg, d_g_table, d_touch, d_touch_base, 0},
+                             stream);
 }
 
 static int session_loss_launch(const float* d_out, int B, int hid, const float* d_item_table, const float* d_item_bias,

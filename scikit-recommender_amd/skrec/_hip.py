@@ -64,6 +64,8 @@ SIGNATURES = {
     "skr_unpack_grad_rows_sorted": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp]),
     "skr_gru_cell_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "skr_gru_cell_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "skr_gru_cell_bwd_scatter": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp,
+                                       vp]),
     "skr_session_loss": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]),
     "skr_session_loss_sharded": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp]),
     "skr_session_loss_grads": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]),

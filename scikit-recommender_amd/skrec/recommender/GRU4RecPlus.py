@@ -216,13 +216,18 @@ class SessionGRU(object):
             src, idx, r, u, c = saved[l]
             i_d, h = self.dims_in[l], self.hids[l]
             dx, work = self._buf(f"dx{l}", (b, i_d)), self._buf(f"work{l}", (3 * b * h,))
-            _hip.check(L.skr_gru_cell_bwd(_hip.ptr(src), _hip.ptr(idx), _hip.ptr(states[l]), b, i_d, h, _hip.ptr(Wg),
-                                          _hip.ptr(Wc), self.hidden_act, _hip.ptr(r), _hip.ptr(u), _hip.ptr(c), _hip.ptr(dh),
-                                          _hip.ptr(gWg), _hip.ptr(gbg), _hip.ptr(gWc), _hip.ptr(gbc), _hip.ptr(dx),
-                                          _hip.ptr(work), st))
+            if l == 0:      # the input-embedding gradient (dx scattered to the batch's input rows) rides in the weights launch
+                _hip.check(L.skr_gru_cell_bwd_scatter(_hip.ptr(src), _hip.ptr(idx), _hip.ptr(states[l]), b, i_d, h, _hip.ptr(Wg),
+                                                      _hip.ptr(Wc), self.hidden_act, _hip.ptr(r), _hip.ptr(u), _hip.ptr(c),
+                                                      _hip.ptr(dh), _hip.ptr(gWg), _hip.ptr(gbg), _hip.ptr(gWc), _hip.ptr(gbc),
+                                                      _hip.ptr(dx), _hip.ptr(work), self.reg, _hip.ptr(self.gE_in), p_touch, p_base,
+                                                      st))
+            else:
+                _hip.check(L.skr_gru_cell_bwd(_hip.ptr(src), _hip.ptr(idx), _hip.ptr(states[l]), b, i_d, h, _hip.ptr(Wg),
+                                              _hip.ptr(Wc), self.hidden_act, _hip.ptr(r), _hip.ptr(u), _hip.ptr(c), _hip.ptr(dh),
+                                              _hip.ptr(gWg), _hip.ptr(gbg), _hip.ptr(gWc), _hip.ptr(gbc), _hip.ptr(dx),
+                                              _hip.ptr(work), st))
             dh = dx
-        _hip.check(L.skr_scatter_add_rows(_hip.ptr(dh), _hip.ptr(x_index), b, self.in_dim, _hip.ptr(self.E_in), self.reg,
-                                          _hip.ptr(self.gE_in), p_touch, p_base, st))
         self._optimizer_step()
         return new_states
 
@@ -287,13 +292,18 @@ class ShardedSessionGRU(SessionGRU):
             src, idx, r, u, c = saved[l]
             i_d, h = self.dims_in[l], self.hids[l]
             dx, work = self._buf(f"dx{l}", (bl, i_d)), self._buf(f"work{l}", (3 * bl * h,))
-            _hip.check(L.skr_gru_cell_bwd(_hip.ptr(src), _hip.ptr(idx), _hip.ptr(states[l]), bl, i_d, h, _hip.ptr(Wg),
-                                          _hip.ptr(Wc), self.hidden_act, _hip.ptr(r), _hip.ptr(u), _hip.ptr(c), _hip.ptr(dh),
-                                          _hip.ptr(gWg), _hip.ptr(gbg), _hip.ptr(gWc), _hip.ptr(gbc), _hip.ptr(dx),
-                                          _hip.ptr(work), st))
+            if l == 0:      # (the input-embedding gradient rides in the weights launch, as in SessionGRU.train_step)
+                _hip.check(L.skr_gru_cell_bwd_scatter(_hip.ptr(src), _hip.ptr(idx), _hip.ptr(states[l]), bl, i_d, h, _hip.ptr(Wg),
+                                                      _hip.ptr(Wc), self.hidden_act, _hip.ptr(r), _hip.ptr(u), _hip.ptr(c),
+                                                      _hip.ptr(dh), _hip.ptr(gWg), _hip.ptr(gbg), _hip.ptr(gWc), _hip.ptr(gbc),
+                                                      _hip.ptr(dx), _hip.ptr(work), self.reg, _hip.ptr(self.gE_in),
+                                                      _hip.ptr(g.touch), _hip.ptr(g.grad), st))
+            else:
+                _hip.check(L.skr_gru_cell_bwd(_hip.ptr(src), _hip.ptr(idx), _hip.ptr(states[l]), bl, i_d, h, _hip.ptr(Wg),
+                                              _hip.ptr(Wc), self.hidden_act, _hip.ptr(r), _hip.ptr(u), _hip.ptr(c), _hip.ptr(dh),
+                                              _hip.ptr(gWg), _hip.ptr(gbg), _hip.ptr(gWc), _hip.ptr(gbc), _hip.ptr(dx),
+                                              _hip.ptr(work), st))
             dh = dx
-        _hip.check(L.skr_scatter_add_rows(_hip.ptr(dh), _hip.ptr(x_local), bl, self.in_dim, _hip.ptr(self.E_in), self.reg,
-                                          _hip.ptr(self.gE_in), _hip.ptr(g.touch), _hip.ptr(g.grad), st))
         # ---- the step's one exchange: [dE_out rows of y | db_out of y | dE_in rows of x | GRU gradients | loss]
         world = self.ctx.world
         n_cells = g.grad.numel() - self._cells_lo
