@@ -63,6 +63,23 @@ def test_gru_cell_fwd_bwd(i_d, h, B, act):
     gtab = torch.zeros((n_rows, i_d), device="cuda")
     _hip.check(L.skr_scatter_add_rows(_hip.ptr(dx), _hip.ptr(d["idx"]), B, i_d, None, 0.0, _hip.ptr(gtab), None, None, st))
     _close(gtab.cpu().numpy(), tt[0].grad.numpy(), 2e-5)
+    # the one-call form of the first layer (skr_gru_cell_bwd_scatter): the scatter rides in the weight-gradient launch -- the
+    # weights' gradients and dx bit for bit (same threads, same order), the atomically scattered table gradient to its
+    # tolerance, here with the l2 term of the looked-up rows (repeated inputs count each time)
+    g2 = [torch.zeros_like(d[k]) for k in ("Wg", "bg", "Wc", "bc")]
+    dx2 = torch.empty((B, i_d), device="cuda")
+    gtab2 = torch.zeros((n_rows, i_d), device="cuda")
+    reg = 0.03
+    _hip.check(L.skr_gru_cell_bwd_scatter(_hip.ptr(d["table"]), _hip.ptr(d["idx"]), _hip.ptr(d["h"]), B, i_d, h, _hip.ptr(d["Wg"]),
+                                          _hip.ptr(d["Wc"]), kind, _hip.ptr(r), _hip.ptr(u), _hip.ptr(c), _hip.ptr(d["dh"]),
+                                          _hip.ptr(g2[0]), _hip.ptr(g2[1]), _hip.ptr(g2[2]), _hip.ptr(g2[3]), _hip.ptr(dx2),
+                                          _hip.ptr(work), reg, _hip.ptr(gtab2), None, None, st))
+    torch.cuda.synchronize()
+    for a, b in zip(g2, (gWg, gbg, gWc, gbc)):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    assert np.array_equal(dx2.cpu().numpy(), dx.cpu().numpy())
+    counts = np.bincount(idx, minlength=n_rows).astype(np.float32)
+    _close(gtab2.cpu().numpy(), tt[0].grad.numpy() + reg * counts[:, None] * table, 2e-5)
     # the row mask of the inference sweep: inactive rows keep their state
     active = (rng.random(B) < 0.5).astype(np.uint8)
     out2 = torch.empty((B, h), device="cuda")
